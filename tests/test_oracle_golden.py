@@ -1,0 +1,199 @@
+"""CPU tests: the C oracle against golden vectors captured from the imported reference.
+
+Contract: every integer quantity exact (rewards, flags, counts, number AND values of the uniform draws --
+the draw values are pure integer arithmetic on the MT19937 stream); and, because the oracle reproduces the
+reference's float operations one for one on the same libm (fp64 accumulated yaw, libm sin/cos/pow), agent
+positions, yaw, obs and state are required to be BIT-IDENTICAL (atol = 0).  Target positions go through
+libm log/sqrt in the polar gaussian and are bit-identical too.
+"""
+import numpy as np
+import pytest
+
+from golden_util import load_trace, trace_names, target_table
+from oracle import oracle as orc
+
+POS_TOL = 0.0
+
+
+def replay(meta, z, check):
+    cfg = orc.make_config(variant=meta["env"], n_agents=meta["n_agents"], agent_mode=meta["agent_mode"],
+                          target_mode=meta["target_mode"])
+    env = orc.OracleEnv(cfg)
+    env.seed(meta["seed"])
+    env.start_draw_log()
+    flight = meta["env"] == "flight"
+    for e, ep in enumerate(meta["episodes"]):
+        p = f"e{e}_"
+        env.reset(init=ep["init"])
+        check.reset(env, z, p, flight)
+        pokes = {}
+        if p + "poke_steps" in z:
+            for k, t in enumerate(z[p + "poke_steps"]):
+                pokes[int(t)] = (z[p + "poke_agent_pos"][k], z[p + "poke_yaw_idx"][k] * (np.pi / 18.0))
+        maps = {}
+        if p + "prob_map_steps" in z:
+            maps = {int(t): z[p + "prob_maps"][k] for k, t in enumerate(z[p + "prob_map_steps"])}
+        acts = z[p + "actions"]
+        for t in range(ep["steps"]):
+            if t in pokes:
+                env.set_agents(*pokes[t])
+            r, term, win = env.step(acts[t])
+            check.step(env, z, p, t, r, term, win)
+            if (t + 1) in maps:
+                np.testing.assert_allclose(env.prob_map(), maps[t + 1], rtol=1e-9, atol=1e-300,
+                                           err_msg=f"{meta['name']} prob_map ep{e} after step {t+1}")
+    return env
+
+
+class Checker:
+    def __init__(self, name):
+        self.name = name
+
+    def reset(self, env, z, p, flight):
+        tp, found = env.targets()
+        np.testing.assert_allclose(tp, z[p + "target_pos"], rtol=0, atol=0, err_msg=self.name + " target_pos")
+        assert np.array_equal(found, z[p + "reset_found"])
+        pos, yaw, out = env.agents()
+        np.testing.assert_allclose(pos, z[p + "reset_agent_pos"], rtol=0, atol=POS_TOL)
+        assert np.array_equal(yaw, z[p + "reset_yaw"])
+        assert np.array_equal(out, z[p + "reset_out_flag"])
+        c = env.counters()
+        assert c["target_find"] == int(z[p + "reset_target_find"]) and c["win"] == int(z[p + "reset_win"])
+        d = env.take_draws()
+        assert np.array_equal(d, z[p + "reset_draws"]), self.name + " reset draws"
+        np.testing.assert_allclose(env.get_obs()[:, -4:], z[p + "reset_obs"], rtol=0, atol=0)
+        np.testing.assert_allclose(env.get_state(), z[p + "reset_state"], rtol=0, atol=0)
+        if flight:
+            np.testing.assert_allclose(env.prob_map(), z[p + "reset_prob_map"], rtol=1e-9, atol=1e-300)
+        self.draw_cursor = 0
+
+    def step(self, env, z, p, t, r, term, win):
+        tag = f"{self.name} {p}step {t}"
+        assert r == int(z[p + "reward"][t]), tag + " reward"
+        assert int(term) == int(z[p + "terminated"][t]), tag + " terminated"
+        assert int(win) == int(z[p + "win"][t]), tag + " win"
+        c = env.counters()
+        assert c["target_find"] == int(z[p + "target_find"][t]), tag
+        assert c["time_step"] == int(z[p + "time_step"][t]), tag
+        pos, yaw, out = env.agents()
+        _, found = env.targets()
+        assert np.array_equal(found, z[p + "found"][t]), tag + " found"
+        assert np.array_equal(out, z[p + "out_flag"][t]), tag + " out_flag"
+        assert np.array_equal(yaw, z[p + "yaw"][t]), tag + " yaw"
+        np.testing.assert_allclose(pos, z[p + "agent_pos"][t], rtol=0, atol=POS_TOL, err_msg=tag + " pos")
+        d = env.take_draws()
+        nd = int(z[p + "n_draws"][t])
+        assert len(d) == nd, tag + " n_draws"
+        assert np.array_equal(d, z[p + "draws"][self.draw_cursor:self.draw_cursor + nd]), tag + " draw values"
+        self.draw_cursor += nd
+        np.testing.assert_allclose(env.get_obs()[:, -4:], z[p + "obs"][t], rtol=0, atol=0, err_msg=tag + " obs")
+        np.testing.assert_allclose(env.get_state(), z[p + "state"][t], rtol=0, atol=0, err_msg=tag + " state")
+
+
+@pytest.mark.parametrize("name", trace_names())
+def test_oracle_replays_golden_trace(name):
+    meta, z = load_trace(name)
+    replay(meta, z, Checker(name))
+
+
+def test_known_answers_from_survey():
+    """SURVEY.md section 8c known-answer values (measured on the imported reference)."""
+    meta, z = load_trace("easy_n3_am0_s0_a1")
+    env = replay(meta, z, Checker("ka"))
+    assert meta["episodes"][0]["sum_reward"] == -470 and meta["episodes"][0]["n_draws"] == 378
+    c = env.counters()
+    assert c["total_reward"] == -470 and c["target_find"] == 8 and c["win"] == 0
+    tp, _ = env.targets()
+    np.testing.assert_allclose(tp[0], [27.528104691935, 45.300314416734], atol=1e-11)
+    pos, yaw, _ = env.agents()
+    np.testing.assert_allclose(pos, [[4.044356360706, 50.0], [23.156537015704, 29.021131058379],
+                                     [46.674988878054, 50.0]], atol=1e-9)
+    assert [int(np.rint(y / (np.pi / 18))) % 36 for y in yaw] == [11, 4, 13]
+    meta, _ = load_trace("easy_n5_am0_s0_a1")
+    assert (meta["episodes"][0]["steps"], meta["episodes"][0]["sum_reward"], meta["episodes"][0]["n_draws"]) == (76, 108, 232)
+    meta, _ = load_trace("easy_n3_am2_s7_a1")
+    assert (meta["episodes"][0]["steps"], meta["episodes"][0]["sum_reward"], meta["episodes"][0]["n_draws"]) == (184, -234, 218)
+
+
+def test_flight_known_answer_first_20_steps():
+    """flight n=3 AM0 seed 0 aseed 1, after 20 steps: sum(prob_map)=853.771227822280, min=2.178e-19."""
+    meta, z = load_trace("flight_n3_am0_s0_a1")
+    m20 = z["e0_prob_maps"][list(z["e0_prob_map_steps"]).index(20)]
+    assert abs(m20.sum() - 853.771227822280) < 1e-9
+    assert abs(m20.min() - 2.178e-19) < 1e-21
+    assert int(z["e0_reward"][:20].sum()) == -28 and int(z["e0_target_find"][19]) == 0
+
+
+def test_rng_matches_numpy_legacy_stream():
+    """MT19937 words, 53-bit doubles and polar gaussians against numpy's RandomState (Appendix B)."""
+    for seed in (0, 1, 7, 20240000, 2**32 - 1):
+        env = orc.OracleEnv(orc.make_config())
+        env.seed(seed)
+        rs = np.random.RandomState(seed)
+        ref_words = rs.randint(0, 2**32, size=1500, dtype=np.uint64)  # 32-bit draws use one word each
+        got = [env.rng_u32() for _ in range(1500)]
+        assert np.array_equal(np.array(got, dtype=np.uint64), ref_words)
+        env.seed(seed)
+        rs = np.random.RandomState(seed)
+        for _ in range(700):
+            assert env.rng_rand() == rs.random_sample()
+        for _ in range(301):   # odd count: leaves a cached gaussian behind
+            assert env.rng_randn() == rs.standard_normal()   # same libm log/sqrt -> bit-identical
+        # interleaving rand after a cached gauss must not disturb either stream
+        assert env.rng_rand() == rs.random_sample()
+
+
+def test_detect_threshold_integer_form():
+    """U <= 0.9 <=> (a>>5)*2^26 + (b>>6) <= K, K = floor(0.9 * 2^53) (Appendix B)."""
+    from fractions import Fraction
+    K = 8106479329266893
+    assert Fraction(K, 2**53) <= Fraction(0.9) < Fraction(K + 1, 2**53)
+    assert float(K) / 2**53 <= 0.9 < float(K + 1) / 2**53
+
+
+def test_target_table_matches_fixture():
+    t = target_table()
+    d = orc.DEFAULT_CIRCLE
+    for k in ("x", "y", "dx", "dy"):
+        assert [float(v) for v in d[k]] == [float(v) for v in t[k]]
+    assert list(d["deter"]) == list(t["deter"]) and list(d["priority"]) == list(t["priority"])
+
+
+def test_reward_is_integer_and_bounded_property():
+    rng = np.random.RandomState(123)
+    for n in (1, 3, 5, 8):
+        env = orc.OracleEnv(orc.make_config(n_agents=n, agent_mode=int(rng.randint(0, 4))), seed=int(rng.randint(1 << 30)))
+        env.reset(init=True)
+        last_find = 0
+        for t in range(200):
+            r, term, win = env.step(rng.randint(0, 3, size=n))
+            assert r >= -1 - n and (r + 1 + n) >= 0
+            c = env.counters()
+            assert c["target_find"] >= last_find
+            last_find = c["target_find"]
+            pos, yaw, out = env.agents()
+            assert (pos >= 0).all() and (pos <= 50).all() and (yaw >= 0).all() and (yaw <= 2 * np.pi).all()
+            assert term == (c["target_find"] >= 15 or t + 1 >= 200)
+
+
+def test_batch_driver_equals_single_envs():
+    cfg = orc.make_config(n_agents=3)
+    B = 64
+    seeds = np.arange(B, dtype=np.uint32) + 1000
+    batch = orc.OracleBatch(cfg, B, seeds)
+    singles = [orc.OracleEnv(cfg, seed=int(s)) for s in seeds]
+    batch.reset(init=True, threads=4)
+    for e in singles:
+        e.reset(init=True)
+    rng = np.random.RandomState(5)
+    for t in range(230):
+        a = rng.randint(0, 3, size=(B, 3)).astype(np.int32)
+        r, term, win = batch.step(a, auto_reset=False, freeze_done=True, threads=4)
+        for b, e in enumerate(singles):
+            c = e.counters()
+            if c["target_find"] >= 15 or c["time_step"] >= 200:
+                assert r[b] == 0 and term[b] == 1
+                continue
+            rr, tt, ww = e.step(a[b])
+            assert (rr, tt, ww) == (int(r[b]), bool(term[b]), bool(win[b]))
+            np.testing.assert_allclose(batch.state[b], e.get_state().astype(np.float32), rtol=0, atol=0)
