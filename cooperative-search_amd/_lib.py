@@ -1,0 +1,85 @@
+"""ctypes binding of libcoopsearch_hip.so (include/coopsearch.h).  No fallback: a missing library raises."""
+import ctypes as C
+import os
+
+from . import build as _build
+
+MAX_AGENTS = 8
+MAX_TARGETS = 16
+H_WORDS = 16
+# header word indices (enum CS_H_* in coopsearch.h)
+H_FOUND, H_NEWLY, H_TARGET_FIND, H_FLAGS, H_TIME_STEP, H_TOTAL_REWARD, H_MT_POS, H_EPISODES = range(8)
+H_WORDS_LO, H_WORDS_HI, H_CURR_REWARD = 8, 9, 10
+FREEZE_DONE, AUTO_RESET, ACTIONS_I64 = 1, 2, 4
+
+EXPORTS = ["cs_abi_version", "cs_last_error", "cs_state_layout", "cs_init", "cs_seed", "cs_reset", "cs_step",
+           "cs_rollout", "cs_emit", "cs_metrics"]
+
+
+class CsConfig(C.Structure):
+    _fields_ = [
+        ("variant", C.c_int32), ("n_agents", C.c_int32), ("n_targets", C.c_int32), ("map_size", C.c_int32),
+        ("view_range", C.c_int32), ("time_limit", C.c_int32), ("agent_mode", C.c_int32), ("target_mode", C.c_int32),
+        ("velocity", C.c_double), ("safe_dist", C.c_double), ("detect_prob", C.c_double),
+        ("force_dist", C.c_double), ("force_factor", C.c_double),
+        ("cx", C.c_double * MAX_TARGETS), ("cy", C.c_double * MAX_TARGETS),
+        ("dx", C.c_double * MAX_TARGETS), ("dy", C.c_double * MAX_TARGETS),
+        ("deter", C.c_int32 * MAX_TARGETS),
+        ("batch", C.c_int64),
+    ]
+
+
+class CsLayout(C.Structure):
+    _fields_ = [("total_bytes", C.c_size_t), ("tgt_off", C.c_size_t), ("agent_off", C.c_size_t),
+                ("hdr_off", C.c_size_t), ("mt_off", C.c_size_t), ("prob_off", C.c_size_t)]
+
+
+class CoopSearchError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def library_path():
+    return _build.LIB_PATH
+
+
+def load():
+    """Load (building first if the in-tree .so is missing or older than its sources)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_PATH
+    if _build.is_stale():
+        if _build.hipcc_path() is None:
+            if not os.path.exists(path):
+                raise CoopSearchError(
+                    f"{path} is missing and hipcc is not available: the HIP extension is required (no CPU fallback)")
+        else:
+            _build.build_extension()
+    L = C.CDLL(path)
+    vp = C.c_void_p
+    L.cs_abi_version.restype = C.c_int
+    L.cs_last_error.restype = C.c_char_p
+    L.cs_state_layout.argtypes = [C.POINTER(CsConfig), C.POINTER(CsLayout)]
+    L.cs_init.argtypes = [C.POINTER(CsConfig), vp, vp]
+    L.cs_seed.argtypes = [C.POINTER(CsConfig), vp, vp, vp]
+    L.cs_reset.argtypes = [C.POINTER(CsConfig), vp, vp, C.c_int, vp, vp, vp]
+    L.cs_step.argtypes = [C.POINTER(CsConfig), vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
+    L.cs_rollout.argtypes = [C.POINTER(CsConfig), vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
+    L.cs_emit.argtypes = [C.POINTER(CsConfig), vp, vp, vp, vp]
+    L.cs_metrics.argtypes = [C.POINTER(CsConfig), vp, vp, vp]
+    for name in EXPORTS:
+        fn = getattr(L, name)
+        if name not in ("cs_abi_version", "cs_last_error"):
+            fn.restype = C.c_int
+    if L.cs_abi_version() != 1:
+        raise CoopSearchError("libcoopsearch_hip.so: ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise CoopSearchError(f"coopsearch error {rc}: {load().cs_last_error().decode()}")

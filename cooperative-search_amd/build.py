@@ -1,0 +1,47 @@
+"""Builds csrc/libcoopsearch_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+ROOT = os.path.dirname(HERE)
+LIB_PATH = os.path.join(CSRC, "libcoopsearch_hip.so")
+SOURCES = ["coopsearch.hip", "trig_table.inc"]
+HEADERS = [os.path.join(ROOT, "include", "coopsearch.h")]
+
+
+def hipcc_path():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    return None
+
+
+def is_stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_extension(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 ... -> csrc/libcoopsearch_hip.so.  -ffp-contract=off is part of the numerics
+    contract, not a tuning knob."""
+    if not force and not is_stale():
+        return LIB_PATH
+    hipcc = hipcc_path()
+    if hipcc is None:
+        raise RuntimeError("hipcc not found: cannot build libcoopsearch_hip.so")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+           "-I", os.path.join(ROOT, "include"), os.path.join(CSRC, "coopsearch.hip"), "-o", LIB_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_extension(force=True, verbose=True))

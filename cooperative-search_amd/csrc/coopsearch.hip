@@ -1,0 +1,907 @@
+// cooperative-search_amd/csrc/coopsearch.hip -- gfx950 (MI355X) kernels + the C ABI of include/coopsearch.h.
+//
+// Batched flight_easy / flight environment path of WZN1ng/Cooperative-Search, written for CDNA4:
+//   * one environment = one 16-lane group of a wave64 (4 envs per wavefront): lane t owns target t, the <= 8
+//     agents live replicated in every lane's registers, so the Gauss-Seidel kinematics need no communication
+//     and the 15 x n sensor tests of the detection pass run across lanes;
+//   * the detection mask is a wavefront ballot; a prefix popcount of the group's 16-bit slice gives every
+//     in-range (agent, target) pair its offset in the env's private NumPy-compatible MT19937 stream, in the
+//     reference's agent-major order;
+//   * MT19937 is kept in its circular (incremental) form, so a draw touches 5 state words and there is no
+//     624-word twist spike: word k is regenerated from words k, k+1, k+397 at the moment it is consumed;
+//   * fp64 for everything that decides an integer outcome (positions, yaw, distance tests), fp32 only for
+//     the emitted obs / state / reward tensors.  Compiled with -ffp-contract=off: the reference's CPython
+//     arithmetic never fuses, and its wall test is knife-edged at the 1-ulp level.
+//
+// Reference citations are relative to the reference repo root.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "coopsearch.h"
+
+namespace {
+
+constexpr int G = 16;        // lanes per environment
+constexpr int BLOCK = 256;   // 4 wavefronts, 16 environments
+constexpr int MT_N = 624;
+constexpr int MT_M = 397;
+constexpr int TRIG_ROWS = 37, TRIG_COLS = 7;
+constexpr int FLAG_WIN = 1, FLAG_DIRTY = 2;
+
+// {A_hi, A_lo, A_lo2, S_hi, S_lo, C_hi, C_lo} for A = k*pi/18 (gen_trig_table.py)
+__device__ const double g_trig[TRIG_ROWS][TRIG_COLS] = {
+#include "trig_table.inc"
+};
+
+struct DevParams {
+    int B, n_targets, map_size, cells, time_limit, agent_mode, target_mode, variant;
+    double velocity, force_k, force_d2, view_r2, L, q;
+    unsigned long long detect_K;  // U <= detect_prob  <=>  53-bit integer draw <= floor(detect_prob * 2^53)
+    double tx0[CS_MAX_TARGETS], ty0[CS_MAX_TARGETS], jx2[CS_MAX_TARGETS], jy2[CS_MAX_TARGETS];
+    unsigned deter_mask;
+    double *tgt;     // [B][16][2]
+    double *agent;   // [B][8][4]
+    int *hdr;        // [B][16]
+    unsigned *mt;    // [B][624]
+    float *prob;     // [B][cells]
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// MT19937, circular form.  At cursor k, entries < k belong to the next block, entries >= k to the current
+// one -- exactly the intermediate states of NumPy's in-place block twist -- so outputs are bit-identical to
+// numpy.random.RandomState.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned mt_mix(unsigned cur, unsigned nxt, unsigned far) {
+    unsigned y = (cur & 0x80000000u) | (nxt & 0x7fffffffu);
+    return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+__device__ __forceinline__ unsigned mt_temper(unsigned y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+__device__ __forceinline__ int wrap624(int v) { return v >= MT_N ? v - MT_N : v; }  // v < 2*624
+
+// Sequential consumer used by reset (polar gaussians need a data-dependent number of words).  The 16 lanes of
+// the group generate 64 candidate words at once (4 per lane, one memory round trip), all lanes consume them
+// in lock-step through a wave shuffle, and only the consumed prefix is committed back to the state.
+struct SeqGen {
+    unsigned *mt;
+    int pos, l16, wave_base, c;
+    unsigned long long words;
+    unsigned nw[4], tw[4];
+
+    __device__ __forceinline__ void fill() {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            int i0 = wrap624(pos + l16 + 16 * q);
+            unsigned a = mt[i0], b = mt[wrap624(i0 + 1)], f = mt[wrap624(i0 + MT_M)];
+            nw[q] = mt_mix(a, b, f);
+            tw[q] = mt_temper(nw[q]);
+        }
+        c = 0;
+    }
+    __device__ __forceinline__ void commit(int cnt) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            int j = l16 + 16 * q;
+            if (j < cnt) mt[wrap624(pos + j)] = nw[q];
+        }
+        pos = wrap624(pos + cnt);
+        words += (unsigned long long)cnt;
+    }
+    __device__ __forceinline__ unsigned next() {
+        if (c == 64) {
+            commit(64);
+            fill();
+        }
+        int q = c >> 4;
+        unsigned v = q == 0 ? tw[0] : (q == 1 ? tw[1] : (q == 2 ? tw[2] : tw[3]));
+        unsigned r = (unsigned)__shfl((int)v, wave_base + (c & 15), 64);
+        c++;
+        return r;
+    }
+    // numpy random_sample: 53-bit double from two words
+    __device__ __forceinline__ double rand() {
+        unsigned a = next() >> 5, b = next() >> 6;
+        return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// Correctly rounded sin/cos of an accumulated heading (see gen_trig_table.py).  T points at the LDS copy.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void trig_heading(const double *T, double yaw, double &s, double &c) {
+    int k = (int)(yaw * 5.729577951308232 + 0.5);  // 18/pi
+    k = k < 0 ? 0 : (k > 36 ? 36 : k);
+    const double *r = T + k * TRIG_COLS;
+    double t = yaw - r[0];  // exact (Sterbenz) for headings on the pi/18 grid
+    double dh = t - r[1];
+    double bb = dh - t;
+    double err = (t - (dh - bb)) + ((-r[1]) - bb);  // TwoSum tail
+    double dl = err - r[2];
+    if (fabs(dh) > 1e-6) {  // off-grid heading injected through the raw state: generic path
+        s = sin(yaw);
+        c = cos(yaw);
+        return;
+    }
+    s = r[3] + ((r[4] + dh * (r[5] - 0.5 * dh * r[3])) + dl * r[5]);
+    c = r[5] + ((r[6] - dh * (r[3] + 0.5 * dh * r[5])) - dl * r[3]);
+}
+
+__device__ __forceinline__ void load_trig_to_lds(double *T) {
+    for (int i = threadIdx.x; i < TRIG_ROWS * TRIG_COLS; i += blockDim.x) T[i] = (&g_trig[0][0])[i];
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Per-env register state (group-uniform values are replicated in all 16 lanes).
+// ---------------------------------------------------------------------------------------------------------
+template <int N>
+struct Env {
+    double ax[N], ay[N], yaw[N], cs[N], sn[N];  // cs/sn: cos/sin of the CURRENT yaw (what get_obs emits)
+    double tx, ty;                               // this lane's target
+    unsigned found, newly;                       // bit masks over targets
+    int target_find, flags, time_step, total_reward, mt_pos, episodes, curr_reward;
+    unsigned long long words;
+};
+
+template <int N>
+__device__ __forceinline__ void env_trig(const double *T, Env<N> &e) {
+#pragma unroll
+    for (int i = 0; i < N; i++) trig_heading(T, e.yaw[i], e.sn[i], e.cs[i]);
+}
+
+template <int N>
+__device__ __forceinline__ void env_load(const DevParams &p, int b, int t, Env<N> &e) {
+    const int4 *h4 = reinterpret_cast<const int4 *>(p.hdr + (size_t)b * CS_H_WORDS);
+    int4 h0 = h4[0], h1 = h4[1], h2 = h4[2];
+    e.found = (unsigned)h0.x;
+    e.newly = (unsigned)h0.y;
+    e.target_find = h0.z;
+    e.flags = h0.w;
+    e.time_step = h1.x;
+    e.total_reward = h1.y;
+    e.mt_pos = h1.z;
+    e.episodes = h1.w;
+    e.words = (unsigned long long)(unsigned)h2.x | ((unsigned long long)(unsigned)h2.y << 32);
+    e.curr_reward = h2.z;
+    const double4 *a4 = reinterpret_cast<const double4 *>(p.agent + (size_t)b * CS_MAX_AGENTS * 4);
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        double4 a = a4[i];
+        e.ax[i] = a.x;
+        e.ay[i] = a.y;
+        e.yaw[i] = a.z;
+        e.cs[i] = 0.0;  // filled by kinematics / env_reset / env_trig before any emission
+        e.sn[i] = 0.0;
+    }
+    const double2 *t2 = reinterpret_cast<const double2 *>(p.tgt + (size_t)b * G * 2);
+    double2 tt = t2[t];
+    e.tx = tt.x;
+    e.ty = tt.y;
+}
+
+template <int N>
+__device__ __forceinline__ void env_store(const DevParams &p, int b, int t, const Env<N> &e, bool store_targets) {
+    if (t == 0) {
+        int4 *h4 = reinterpret_cast<int4 *>(p.hdr + (size_t)b * CS_H_WORDS);
+        h4[0] = make_int4((int)e.found, (int)e.newly, e.target_find, e.flags);
+        h4[1] = make_int4(e.time_step, e.total_reward, e.mt_pos, e.episodes);
+        h4[2] = make_int4((int)(unsigned)(e.words & 0xffffffffull), (int)(unsigned)(e.words >> 32), e.curr_reward, 0);
+    }
+    double4 *a4 = reinterpret_cast<double4 *>(p.agent + (size_t)b * CS_MAX_AGENTS * 4);
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        if (t == i) a4[i] = make_double4(e.ax[i], e.ay[i], e.yaw[i], 0.0);
+    if (store_targets) {
+        double2 *t2 = reinterpret_cast<double2 *>(p.tgt + (size_t)b * G * 2);
+        t2[t] = make_double2(e.tx, e.ty);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Detection pass + reward: flight_env_easy.py:223-253 (_update_obs), flight_env.py:232-266.
+// Returns curr_reward.  gshift = 16 * (group index inside the wavefront).
+// ---------------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ int detect_pass(const DevParams &p, int b, int t, int gshift, Env<N> &e) {
+    const bool is_tgt = t < p.n_targets;
+    unsigned *mt = p.mt + (size_t)b * MT_N;
+    bool inr[N];
+    int rank[N];
+    int base = 0;
+    const unsigned below = (1u << t) - 1u;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        double ddx = e.tx - e.ax[i], ddy = e.ty - e.ay[i];
+        inr[i] = is_tgt && (ddx * ddx + ddy * ddy <= p.view_r2);  // (t_x-x)**2 + (t_y-y)**2 <= view_range**2
+        unsigned gm = (unsigned)((__ballot(inr[i]) >> gshift) & 0xffffull);
+        rank[i] = base + __popc(gm & below);  // agent-major order of the reference's double loop
+        base += __popc(gm);
+    }
+    // one np.random.rand() per in-range pair (found or not: quirk Q4).  Circular MT: word k is rebuilt from
+    // words k, k+1 and k+397 == k-227, so up to 227 consecutive words can be regenerated independently from
+    // the state as it stood before the pass: all loads first, all stores after.  n*16*2 words fit that window
+    // for n <= 7; n = 8 draws in two agent-halves.
+    constexpr int PHASES = (N * G * 2 > 226) ? 2 : 1;
+    constexpr int PER = (N + PHASES - 1) / PHASES;
+    bool hit = false;
+#pragma unroll
+    for (int ph = 0; ph < PHASES; ph++) {
+        unsigned w[PER][5];
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int i = ph * PER + k;
+            if (i < N && inr[i]) {
+                int i0 = wrap624(e.mt_pos + 2 * rank[i]);
+                int i1 = wrap624(i0 + 1), i2 = wrap624(i0 + 2);
+                w[k][0] = mt[i0];
+                w[k][1] = mt[i1];
+                w[k][2] = mt[i2];
+                w[k][3] = mt[wrap624(i0 + MT_M)];
+                w[k][4] = mt[wrap624(i1 + MT_M)];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int i = ph * PER + k;
+            if (i < N && inr[i]) {
+                int i0 = wrap624(e.mt_pos + 2 * rank[i]);
+                int i1 = wrap624(i0 + 1);
+                unsigned n0 = mt_mix(w[k][0], w[k][1], w[k][3]);
+                unsigned n1 = mt_mix(w[k][1], w[k][2], w[k][4]);
+                mt[i0] = n0;
+                mt[i1] = n1;
+                unsigned long long u =
+                    ((unsigned long long)(mt_temper(n0) >> 5) << 26) | (unsigned long long)(mt_temper(n1) >> 6);
+                hit = hit || (u <= p.detect_K);  // prob <= self.detect_prob, evaluated exactly in integers
+            }
+        }
+    }
+    e.mt_pos = wrap624(e.mt_pos + 2 * base);
+    e.words += (unsigned long long)(2 * base);
+
+    bool lane_new = hit && !((e.found >> t) & 1u);
+    unsigned newly = (unsigned)((__ballot(lane_new) >> gshift) & 0xffffull);
+    int cnt = __popc(newly);
+    int r = -1;  // MOVE_COST
+    r += 10 * cnt;  // FIND_ONE_TGT
+    e.found |= newly;
+    e.newly = newly;
+    e.target_find += cnt;
+    if (cnt > 0 && e.target_find == p.n_targets && !(e.flags & FLAG_WIN)) {
+        r += 100;  // FIND_ALL_TGT
+        e.flags |= FLAG_WIN;
+    }
+    r -= __popc(((unsigned)e.flags >> 8) & 0xffu);  // OUT_PUNISH per agent with out_flag set
+    e.curr_reward = r;
+    e.flags |= FLAG_DIRTY;
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Kinematics: flight_env_easy.py:255-301 (_agent_step + _potential_energy_force), flight_env.py:305-355.
+// Sequential over agents (quirk Q7); every lane of the group computes the same values.
+// ---------------------------------------------------------------------------------------------------------
+template <int N, int VARIANT>
+__device__ __forceinline__ void kinematics(const DevParams &p, const double *T, const int (&act)[N], Env<N> &e) {
+    const double PI = 3.141592653589793, TWO_PI = 2.0 * 3.141592653589793, THREE_PI = 3.0 * 3.141592653589793;
+    const double DYAW = 3.141592653589793 / 18.0;
+    unsigned out = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        double yaw = e.yaw[i];
+        if (act[i] == 1) yaw += DYAW;
+        else if (act[i] == 2) yaw += -DYAW;
+        if (yaw > TWO_PI) yaw -= TWO_PI;
+        else if (yaw < 0.0) yaw += TWO_PI;
+        double s, c;
+        trig_heading(T, yaw, s, c);
+        const double x0 = e.ax[i], y0 = e.ay[i];
+        double x = x0 + p.velocity * c;
+        double y = y0 + p.velocity * s;
+        double fx = 0.0, fy = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            if (j == i) continue;
+            double xa = e.ax[j], ya = e.ay[j];  // already moved if j < i
+            double d2 = (xa - x0) * (xa - x0) + (ya - y0) * (ya - y0);
+            if (d2 < p.force_d2 && (xa != x0 || ya != y0)) {
+                double den = (x0 - xa) * (x0 - xa) + (y0 - ya) * (y0 - ya);
+                fx += p.force_k * (x0 - xa) / den;
+                fy += p.force_k * (y0 - ya) / den;
+            }
+        }
+        x += fx;
+        y += fy;
+        bool hit = VARIANT == 1 ? (x < 0.0 || x >= p.L || y < 0.0 || y >= p.L)   // flight_env.py:328
+                                : (x < 0.0 || x > p.L || y < 0.0 || y > p.L);    // flight_env_easy.py:278
+        if (hit) {
+            x = fmin(fmax(x, 0.0), p.L);
+            y = fmin(fmax(y, 0.0), p.L);
+            yaw = (yaw <= PI) ? PI - yaw : THREE_PI - yaw;
+            trig_heading(T, yaw, s, c);
+            out |= 1u << i;
+        }
+        e.ax[i] = x;
+        e.ay[i] = y;
+        e.yaw[i] = yaw;
+        e.cs[i] = c;
+        e.sn[i] = s;
+    }
+    e.flags = (e.flags & ~0xff00) | (int)(out << 8);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// reset: flight_env_easy.py:79-182 / flight_env.py:83-191.  Group-cooperative; ends with the reset-time
+// detection pass (quirk Q3) whose reward is discarded.
+// ---------------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void env_reset(const DevParams &p, const double *T, int b, int t, int gshift, int init,
+                                          Env<N> &e) {
+    if (p.variant == 1 && init) {  // flight_env.py:84-86
+        float4 *m4 = reinterpret_cast<float4 *>(p.prob + (size_t)b * p.cells);
+        for (int c = t; c < p.cells / 4; c += G) m4[c] = make_float4(0.5f, 0.5f, 0.5f, 0.5f);
+    }
+    SeqGen g;
+    g.mt = p.mt + (size_t)b * MT_N;
+    g.pos = e.mt_pos;
+    g.l16 = t;
+    g.wave_base = (int)(threadIdx.x & 63) & ~15;
+    g.words = e.words;
+    g.fill();
+    double mx = 0.0, my = 0.0;
+    for (int j = 0; j < p.n_targets; j++) {
+        double x, y;
+        if (p.target_mode == 0) {
+            x = p.tx0[j];
+            y = p.ty0[j];
+            if (!((p.deter_mask >> j) & 1u)) {
+                // two np.random.randn(): legacy polar method, second value of the pair comes out first
+                double x1, x2, r2;
+                do {
+                    x1 = 2.0 * g.rand() - 1.0;
+                    x2 = 2.0 * g.rand() - 1.0;
+                    r2 = x1 * x1 + x2 * x2;
+                } while (r2 >= 1.0 || r2 == 0.0);
+                double f = sqrt(-2.0 * log(r2) / r2);
+                double g1 = f * x2, g2 = f * x1;
+                x += p.jx2[j] * (g1 - 0.5);  // dx*2*(randn-0.5)
+                y += p.jy2[j] * (g2 - 0.5);
+            }
+        } else {
+            x = p.L * g.rand();
+            y = p.L * g.rand();
+        }
+        if (j == t) {
+            mx = x;
+            my = y;
+        }
+    }
+    g.commit(g.c);
+    e.mt_pos = g.pos;
+    e.words = g.words;
+    e.tx = mx;
+    e.ty = my;
+    e.found = 0;
+    e.newly = 0;
+    e.target_find = 0;
+    e.time_step = 0;
+    e.total_reward = 0;
+    e.flags = 0;
+    e.episodes += 1;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        double s = N != 1 ? (double)(i * p.map_size) / (double)(N - 1) : p.L / 2.0;
+        double yaw;
+        switch (p.agent_mode) {
+        case 0: e.ax[i] = s; e.ay[i] = 0.0; yaw = 3.141592653589793 / 2.0; break;
+        case 1: e.ax[i] = s; e.ay[i] = p.L / 2.0; yaw = 3.141592653589793 / 2.0; break;
+        case 2: e.ax[i] = 0.0; e.ay[i] = s; yaw = 0.0; break;
+        default: e.ax[i] = p.L; e.ay[i] = s; yaw = 3.141592653589793; break;
+        }
+        e.yaw[i] = yaw;
+        trig_heading(T, yaw, e.sn[i], e.cs[i]);
+    }
+    detect_pass<N>(p, b, t, gshift, e);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Emission: get_obs (flight_env_easy.py:218-221; flight_env.py:223-230 writes the 4 features after the map)
+// and get_state (flight_env_easy.py:190-216).
+// ---------------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void emit(const DevParams &p, int t, const Env<N> &e, float *obs_row, float *state_row) {
+    const double half = p.L / 2.0, mid = 0.5 * p.L;
+    const int obs_w = p.variant == 1 ? p.cells + 4 : 4;
+    const int feat_off = p.variant == 1 ? p.cells : 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        if (t == i) {
+            float4 f = make_float4((float)((e.ax[i] - mid) / half), (float)((e.ay[i] - mid) / half), (float)e.cs[i],
+                                   (float)e.sn[i]);
+            if (obs_row) *reinterpret_cast<float4 *>(obs_row + (size_t)i * obs_w + feat_off) = f;
+            if (state_row) {
+                state_row[4 * i + 0] = f.x;
+                state_row[4 * i + 1] = f.y;
+                state_row[4 * i + 2] = f.z;
+                state_row[4 * i + 3] = f.w;
+            }
+        }
+    }
+    if (state_row && t < p.n_targets) {
+        float *s = state_row + 4 * N + 3 * t;
+        s[0] = (float)((e.tx - mid) / half);
+        s[1] = (float)((e.ty - mid) / half);
+        s[2] = ((e.found >> t) & 1u) ? 1.0f : 0.0f;
+    }
+}
+
+struct StepIO {
+    const void *actions;  // [T][B][N] int32 / int64
+    float *reward;        // [T][B]
+    uint8_t *terminated, *win;
+    float *obs, *state;   // [T][B][...]
+    int flags, T;
+};
+
+template <int N>
+__device__ __forceinline__ void load_actions(const StepIO &io, size_t row, int (&act)[N]) {
+    if (io.flags & CS_ACTIONS_I64) {
+        const long long *a = reinterpret_cast<const long long *>(io.actions) + row * N;
+#pragma unroll
+        for (int i = 0; i < N; i++) act[i] = (int)a[i];
+    } else {
+        const int *a = reinterpret_cast<const int *>(io.actions) + row * N;
+#pragma unroll
+        for (int i = 0; i < N; i++) act[i] = a[i];
+    }
+}
+
+// One env.step for the group's env, state in registers.  Returns through io slot `slot` (= t*B + b).
+template <int N, int VARIANT>
+__device__ __forceinline__ void step_once(const DevParams &p, const double *T, const StepIO &io, int b, int t,
+                                          int gshift, size_t slot, Env<N> &e) {
+    bool done = e.target_find >= p.n_targets || e.time_step >= p.time_limit;
+    int reward = 0;
+    bool term = true;
+    if (done && (io.flags & CS_AUTO_RESET)) {
+        env_reset<N>(p, T, b, t, gshift, 0, e);
+        env_store<N>(p, b, t, e, true);  // targets changed
+        done = false;
+    }
+    if (!(done && (io.flags & CS_FREEZE_DONE))) {
+        int act[N];
+        load_actions<N>(io, slot, act);
+        kinematics<N, VARIANT>(p, T, act, e);
+        reward = detect_pass<N>(p, b, t, gshift, e);
+        e.total_reward += reward;
+        e.time_step += 1;
+        term = e.target_find >= p.n_targets || e.time_step >= p.time_limit;
+    } else {
+        env_trig<N>(T, e);  // frozen env: re-emit the unchanged observation
+    }
+    if (t == 0) {
+        io.reward[slot] = (float)reward;
+        io.terminated[slot] = term ? 1 : 0;
+        io.win[slot] = (e.flags & FLAG_WIN) ? 1 : 0;
+    }
+    const size_t obs_w = (size_t)N * (p.variant == 1 ? p.cells + 4 : 4);
+    const size_t st_w = (size_t)(4 * N + 3 * p.n_targets);
+    emit<N>(p, t, e, io.obs ? io.obs + slot * obs_w : nullptr, io.state ? io.state + slot * st_w : nullptr);
+}
+
+template <int N, int VARIANT>
+__global__ __launch_bounds__(BLOCK) void k_step(DevParams p, StepIO io) {
+    __shared__ double T[TRIG_ROWS * TRIG_COLS];
+    load_trig_to_lds(T);
+    const int gid = blockIdx.x * BLOCK + threadIdx.x;
+    const int b = gid / G, t = gid % G;
+    if (b >= p.B) return;
+    const int gshift = (int)(threadIdx.x & 63) & ~15;
+    Env<N> e;
+    env_load<N>(p, b, t, e);
+    step_once<N, VARIANT>(p, T, io, b, t, gshift, (size_t)b, e);
+    env_store<N>(p, b, t, e, false);
+}
+
+// T steps per launch, env resident in registers between steps (flight_easy).
+template <int N>
+__global__ __launch_bounds__(BLOCK) void k_rollout(DevParams p, StepIO io) {
+    __shared__ double T[TRIG_ROWS * TRIG_COLS];
+    load_trig_to_lds(T);
+    const int gid = blockIdx.x * BLOCK + threadIdx.x;
+    const int b = gid / G, t = gid % G;
+    if (b >= p.B) return;
+    const int gshift = (int)(threadIdx.x & 63) & ~15;
+    Env<N> e;
+    env_load<N>(p, b, t, e);
+    for (int s = 0; s < io.T; s++) step_once<N, 0>(p, T, io, b, t, gshift, (size_t)s * p.B + b, e);
+    env_store<N>(p, b, t, e, false);
+}
+
+template <int N>
+__global__ __launch_bounds__(BLOCK) void k_reset(DevParams p, const uint8_t *mask, int init, float *obs, float *state) {
+    __shared__ double T[TRIG_ROWS * TRIG_COLS];
+    load_trig_to_lds(T);
+    const int gid = blockIdx.x * BLOCK + threadIdx.x;
+    const int b = gid / G, t = gid % G;
+    if (b >= p.B) return;
+    const int gshift = (int)(threadIdx.x & 63) & ~15;
+    Env<N> e;
+    env_load<N>(p, b, t, e);
+    if (!mask || mask[b]) {
+        env_reset<N>(p, T, b, t, gshift, init, e);
+        env_store<N>(p, b, t, e, true);
+    } else {
+        env_trig<N>(T, e);
+    }
+    const size_t obs_w = (size_t)N * (p.variant == 1 ? p.cells + 4 : 4);
+    const size_t st_w = (size_t)(4 * N + 3 * p.n_targets);
+    emit<N>(p, t, e, obs ? obs + (size_t)b * obs_w : nullptr, state ? state + (size_t)b * st_w : nullptr);
+}
+
+template <int N>
+__global__ __launch_bounds__(BLOCK) void k_emit(DevParams p, float *obs, float *state) {
+    __shared__ double T[TRIG_ROWS * TRIG_COLS];
+    load_trig_to_lds(T);
+    const int gid = blockIdx.x * BLOCK + threadIdx.x;
+    const int b = gid / G, t = gid % G;
+    if (b >= p.B) return;
+    Env<N> e;
+    env_load<N>(p, b, t, e);
+    env_trig<N>(T, e);
+    const size_t obs_w = (size_t)N * (p.variant == 1 ? p.cells + 4 : 4);
+    const size_t st_w = (size_t)(4 * N + 3 * p.n_targets);
+    emit<N>(p, t, e, obs ? obs + (size_t)b * obs_w : nullptr, state ? state + (size_t)b * st_w : nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// flight: probability-map update (flight_env.py:275-303) fused with the map part of get_obs (:223-230).
+// One workgroup per env streams the 10 KB map once: float4 per lane, update the cells whose corners fall in a
+// sensor disc (only when the env ran a detection pass since the last call), write the map back only where it
+// changed, and write the n copies that get_obs emits.
+// ---------------------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(BLOCK) void k_map(DevParams p, float *obs) {
+    __shared__ int s_cell[CS_MAX_TARGETS];
+    __shared__ int s_dirty;
+    const int b = blockIdx.x;
+    int *hdr = p.hdr + (size_t)b * CS_H_WORDS;
+    const int flags = hdr[CS_H_FLAGS];
+    const unsigned newly = (unsigned)hdr[CS_H_NEWLY];
+    const bool dirty = flags & FLAG_DIRTY;
+    double ax[N], ay[N];
+    const double4 *a4 = reinterpret_cast<const double4 *>(p.agent + (size_t)b * CS_MAX_AGENTS * 4);
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        double4 a = a4[i];
+        ax[i] = a.x;
+        ay[i] = a.y;
+    }
+    if (threadIdx.x < CS_MAX_TARGETS) {
+        int cell = -1;
+        if (dirty && ((newly >> threadIdx.x) & 1u)) {
+            const double *tg = p.tgt + ((size_t)b * G + threadIdx.x) * 2;
+            int ix = (int)tg[0], iy = (int)tg[1];  // int(): truncation toward zero
+            ix = ix < p.map_size - 1 ? ix : p.map_size - 1;
+            iy = iy < p.map_size - 1 ? iy : p.map_size - 1;
+            cell = (ix >= 0 && iy >= 0) ? ix * p.map_size + iy : -1;
+        }
+        s_cell[threadIdx.x] = cell;
+    }
+    __syncthreads();
+    float4 *m4 = reinterpret_cast<float4 *>(p.prob + (size_t)b * p.cells);
+    const size_t row_w = (size_t)p.cells + 4;
+    const double reach = sqrt(p.view_r2) + 1.0;
+    for (int c = threadIdx.x; c < p.cells / 4; c += BLOCK) {
+        float4 v = m4[c];
+        if (dirty) {
+            float pv[4] = {v.x, v.y, v.z, v.w};
+            bool changed = false;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int cell = 4 * c + k;
+                const int ci = cell / p.map_size, cj = cell - ci * p.map_size;
+                bool near = false;
+#pragma unroll
+                for (int a = 0; a < N; a++)
+                    near = near || (fabs((double)ci + 0.5 - ax[a]) < reach && fabs((double)cj + 0.5 - ay[a]) < reach);
+                if (!near) continue;
+                int cnt = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const double x = (double)(ci + (q & 1)), y = (double)(cj + (q >> 1));
+                    bool in = false;
+#pragma unroll
+                    for (int a = 0; a < N; a++) in = in || ((x - ax[a]) * (x - ax[a]) + (y - ay[a]) * (y - ay[a]) < p.view_r2);
+                    cnt += in ? 1 : 0;
+                }
+                if (cnt == 0) continue;
+                bool is_found_cell = false;
+                for (int j = 0; j < p.n_targets; j++) is_found_cell = is_found_cell || (s_cell[j] == cell);
+                double pr = (double)pv[k];
+                double nv = is_found_cell ? 1.0 : ((double)cnt / 4.0) * p.q * pr / (p.q * pr + (1.0 - pr));
+                pv[k] = (float)nv;
+                changed = true;
+            }
+            if (changed) {
+                v = make_float4(pv[0], pv[1], pv[2], pv[3]);
+                m4[c] = v;
+            }
+        }
+        if (obs) {
+#pragma unroll
+            for (int a = 0; a < N; a++)
+                reinterpret_cast<float4 *>(obs + ((size_t)b * N + a) * row_w)[c] = v;
+        }
+    }
+    if (dirty && threadIdx.x == 0) hdr[CS_H_FLAGS] = flags & ~FLAG_DIRTY;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_seed(DevParams p, const uint32_t *seeds) {
+    // np.random.seed(s): init_genrand; the circular form starts at cursor 0 over the seed array
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= p.B) return;
+    unsigned *mt = p.mt + (size_t)b * MT_N;
+    unsigned x = seeds[b];
+    mt[0] = x;
+    for (int i = 1; i < MT_N; i++) {
+        x = 1812433253u * (x ^ (x >> 30)) + (unsigned)i;
+        mt[i] = x;
+    }
+    int *hdr = p.hdr + (size_t)b * CS_H_WORDS;
+    hdr[CS_H_MT_POS] = 0;
+    hdr[CS_H_WORDS_LO] = 0;
+    hdr[CS_H_WORDS_HI] = 0;
+}
+
+__global__ void k_fill_prob(float *prob, size_t n4) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) reinterpret_cast<float4 *>(prob)[i] = make_float4(0.5f, 0.5f, 0.5f, 0.5f);
+}
+
+__global__ void k_metrics(DevParams p, double *out4) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+    if (b < p.B) {
+        const int *hdr = p.hdr + (size_t)b * CS_H_WORDS;
+        v0 = (double)hdr[CS_H_TOTAL_REWARD];
+        v1 = (hdr[CS_H_FLAGS] & FLAG_WIN) ? 1.0 : 0.0;
+        v2 = (double)hdr[CS_H_TARGET_FIND];
+        v3 = 1.0;
+    }
+    for (int off = 32; off > 0; off >>= 1) {  // wave64 shuffle reduction (sums of small integers: exact)
+        v0 += __shfl_down(v0, off, 64);
+        v1 += __shfl_down(v1, off, 64);
+        v2 += __shfl_down(v2, off, 64);
+        v3 += __shfl_down(v3, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(out4 + 0, v0);
+        atomicAdd(out4 + 1, v1);
+        atomicAdd(out4 + 2, v2);
+        atomicAdd(out4 + 3, v3);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+thread_local char g_err[256] = "";
+
+int fail(int code, const char *msg) {
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int check_config(const cs_config *c) {
+    if (!c) return fail(CS_E_CONFIG, "null config");
+    if (c->variant != 0 && c->variant != 1) return fail(CS_E_CONFIG, "variant must be 0 (flight_easy) or 1 (flight)");
+    if (c->n_agents < 1 || c->n_agents > CS_MAX_AGENTS) return fail(CS_E_CONFIG, "n_agents must be 1..8");
+    if (c->n_targets < 1 || c->n_targets > CS_MAX_TARGETS) return fail(CS_E_CONFIG, "n_targets must be 1..16");
+    if (c->map_size < 2 || c->map_size > CS_MAX_MAP) return fail(CS_E_CONFIG, "map_size must be 2..64");
+    if (c->variant == 1 && (c->map_size * c->map_size) % 4 != 0) return fail(CS_E_CONFIG, "flight needs map_size^2 % 4 == 0");
+    if (c->agent_mode < 0 || c->agent_mode > 3) return fail(CS_E_CONFIG, "No such agent mode");
+    if (c->target_mode < 0 || c->target_mode > 1) return fail(CS_E_CONFIG, "No such target mode");
+    if (c->time_limit < 1) return fail(CS_E_CONFIG, "time_limit must be positive");
+    if (!(c->detect_prob >= 0.0 && c->detect_prob <= 1.0)) return fail(CS_E_CONFIG, "detect_prob must be in [0,1]");
+    if (c->batch < 1 || c->batch > (1ll << 27)) return fail(CS_E_CONFIG, "batch must be 1..2^27");
+    return CS_OK;
+}
+
+int make_params(const cs_config *c, void *state, DevParams *p) {
+    int rc = check_config(c);
+    if (rc) return rc;
+    if (!state) return fail(CS_E_ARG, "null state");
+    cs_layout lay;
+    cs_state_layout(c, &lay);
+    memset(p, 0, sizeof(*p));
+    p->B = (int)c->batch;
+    p->n_targets = c->n_targets;
+    p->map_size = c->map_size;
+    p->cells = c->map_size * c->map_size;
+    p->time_limit = c->time_limit;
+    p->agent_mode = c->agent_mode;
+    p->target_mode = c->target_mode;
+    p->variant = c->variant;
+    p->velocity = c->velocity;
+    p->force_k = c->safe_dist * c->force_factor * c->velocity;  // safe_dist*POTENTIAL_FORCE_FACTOR*velocity, left to right
+    p->force_d2 = c->force_dist * c->force_dist;
+    p->view_r2 = (double)(c->view_range * c->view_range);
+    p->L = (double)c->map_size;
+    p->q = 1.0 - c->detect_prob;
+    p->detect_K = c->detect_prob >= 1.0 ? (1ull << 53) : (unsigned long long)floor(c->detect_prob * 9007199254740992.0);
+    const double a = (double)c->map_size / 10.0;  // a = self.map_size/10
+    for (int j = 0; j < c->n_targets; j++) {
+        p->tx0[j] = a * c->cx[j];
+        p->ty0[j] = a * c->cy[j];
+        p->jx2[j] = (a * c->dx[j]) * 2.0;
+        p->jy2[j] = (a * c->dy[j]) * 2.0;
+        if (c->deter[j]) p->deter_mask |= 1u << j;
+    }
+    char *base = (char *)state;
+    p->tgt = (double *)(base + lay.tgt_off);
+    p->agent = (double *)(base + lay.agent_off);
+    p->hdr = (int *)(base + lay.hdr_off);
+    p->mt = (unsigned *)(base + lay.mt_off);
+    p->prob = (float *)(base + lay.prob_off);
+    return CS_OK;
+}
+
+int launched(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+        return CS_E_LAUNCH;
+    }
+    return CS_OK;
+}
+
+inline unsigned env_blocks(const DevParams &p) { return (unsigned)(((size_t)p.B * G + BLOCK - 1) / BLOCK); }
+
+#define CS_DISPATCH_N(n, CALL)                                   \
+    switch (n) {                                                 \
+    case 1: { constexpr int N = 1; CALL; } break;                \
+    case 2: { constexpr int N = 2; CALL; } break;                \
+    case 3: { constexpr int N = 3; CALL; } break;                \
+    case 4: { constexpr int N = 4; CALL; } break;                \
+    case 5: { constexpr int N = 5; CALL; } break;                \
+    case 6: { constexpr int N = 6; CALL; } break;                \
+    case 7: { constexpr int N = 7; CALL; } break;                \
+    default: { constexpr int N = 8; CALL; } break;               \
+    }
+
+}  // namespace
+
+extern "C" {
+
+int cs_abi_version(void) { return CS_ABI_VERSION; }
+const char *cs_last_error(void) { return g_err; }
+
+int cs_state_layout(const cs_config *cfg, cs_layout *out) {
+    int rc = check_config(cfg);
+    if (rc) return rc;
+    if (!out) return fail(CS_E_ARG, "null layout");
+    const size_t B = (size_t)cfg->batch;
+    size_t off = 0;
+    out->tgt_off = off;
+    off = align_up(off + B * G * 2 * sizeof(double), 256);
+    out->agent_off = off;
+    off = align_up(off + B * CS_MAX_AGENTS * 4 * sizeof(double), 256);
+    out->hdr_off = off;
+    off = align_up(off + B * CS_H_WORDS * sizeof(int32_t), 256);
+    out->mt_off = off;
+    off = align_up(off + B * MT_N * sizeof(uint32_t), 256);
+    out->prob_off = off;
+    if (cfg->variant == 1) off = align_up(off + B * (size_t)cfg->map_size * cfg->map_size * sizeof(float), 256);
+    out->total_bytes = off;
+    return CS_OK;
+}
+
+int cs_init(const cs_config *cfg, void *state_dev, void *stream) {
+    DevParams p;
+    int rc = make_params(cfg, state_dev, &p);
+    if (rc) return rc;
+    cs_layout lay;
+    cs_state_layout(cfg, &lay);
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(state_dev, 0, lay.total_bytes, s) != hipSuccess) return fail(CS_E_LAUNCH, "hipMemsetAsync failed");
+    if (cfg->variant == 1) {
+        size_t n4 = (size_t)p.B * p.cells / 4;
+        unsigned blocks = (unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+        hipLaunchKernelGGL(k_fill_prob, dim3(blocks), dim3(256), 0, s, p.prob, n4);
+    }
+    return launched("cs_init");
+}
+
+int cs_seed(const cs_config *cfg, void *state_dev, const uint32_t *seeds_dev, void *stream) {
+    DevParams p;
+    int rc = make_params(cfg, state_dev, &p);
+    if (rc) return rc;
+    if (!seeds_dev) return fail(CS_E_ARG, "null seeds");
+    hipLaunchKernelGGL(k_seed, dim3((p.B + 63) / 64), dim3(64), 0, (hipStream_t)stream, p, seeds_dev);
+    return launched("cs_seed");
+}
+
+int cs_reset(const cs_config *cfg, void *state_dev, const uint8_t *mask_dev, int init, float *obs_dev,
+             float *state_out_dev, void *stream) {
+    DevParams p;
+    int rc = make_params(cfg, state_dev, &p);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    CS_DISPATCH_N(cfg->n_agents,
+                  hipLaunchKernelGGL(k_reset<N>, dim3(env_blocks(p)), dim3(BLOCK), 0, s, p, mask_dev, init, obs_dev,
+                                     state_out_dev));
+    if (cfg->variant == 1) {
+        CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_map<N>, dim3(p.B), dim3(BLOCK), 0, s, p, obs_dev));
+    }
+    return launched("cs_reset");
+}
+
+int cs_step(const cs_config *cfg, void *state_dev, const void *actions_dev, int flags, float *reward_dev,
+            uint8_t *terminated_dev, uint8_t *win_dev, float *obs_dev, float *state_out_dev, void *stream) {
+    DevParams p;
+    int rc = make_params(cfg, state_dev, &p);
+    if (rc) return rc;
+    if (!actions_dev || !reward_dev || !terminated_dev || !win_dev) return fail(CS_E_ARG, "null step buffer");
+    if (cfg->variant == 1 && (flags & CS_AUTO_RESET))
+        return fail(CS_E_ARG, "flight: CS_AUTO_RESET is not fused (reset-time map update); call cs_reset with a mask");
+    hipStream_t s = (hipStream_t)stream;
+    StepIO io{actions_dev, reward_dev, terminated_dev, win_dev, obs_dev, state_out_dev, flags, 1};
+    if (cfg->variant == 0) {
+        CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL((k_step<N, 0>), dim3(env_blocks(p)), dim3(BLOCK), 0, s, p, io));
+    } else {
+        CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL((k_step<N, 1>), dim3(env_blocks(p)), dim3(BLOCK), 0, s, p, io));
+        CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_map<N>, dim3(p.B), dim3(BLOCK), 0, s, p, obs_dev));
+    }
+    return launched("cs_step");
+}
+
+int cs_rollout(const cs_config *cfg, void *state_dev, const void *actions_dev, int T, int flags, float *reward_dev,
+               uint8_t *terminated_dev, uint8_t *win_dev, float *obs_dev, float *state_out_dev, void *stream) {
+    DevParams p;
+    int rc = make_params(cfg, state_dev, &p);
+    if (rc) return rc;
+    if (cfg->variant != 0) return fail(CS_E_CONFIG, "cs_rollout: flight_easy only (the flight map update is its own kernel)");
+    if (T < 1) return fail(CS_E_ARG, "T must be >= 1");
+    if (!actions_dev || !reward_dev || !terminated_dev || !win_dev) return fail(CS_E_ARG, "null rollout buffer");
+    StepIO io{actions_dev, reward_dev, terminated_dev, win_dev, obs_dev, state_out_dev, flags, T};
+    CS_DISPATCH_N(cfg->n_agents,
+                  hipLaunchKernelGGL(k_rollout<N>, dim3(env_blocks(p)), dim3(BLOCK), 0, (hipStream_t)stream, p, io));
+    return launched("cs_rollout");
+}
+
+int cs_emit(const cs_config *cfg, void *state_dev, float *obs_dev, float *state_out_dev, void *stream) {
+    DevParams p;
+    int rc = make_params(cfg, state_dev, &p);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    CS_DISPATCH_N(cfg->n_agents,
+                  hipLaunchKernelGGL(k_emit<N>, dim3(env_blocks(p)), dim3(BLOCK), 0, s, p, obs_dev, state_out_dev));
+    if (cfg->variant == 1 && obs_dev) {
+        CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_map<N>, dim3(p.B), dim3(BLOCK), 0, s, p, obs_dev));
+    }
+    return launched("cs_emit");
+}
+
+int cs_metrics(const cs_config *cfg, void *state_dev, double *out4_dev, void *stream) {
+    DevParams p;
+    int rc = make_params(cfg, state_dev, &p);
+    if (rc) return rc;
+    if (!out4_dev) return fail(CS_E_ARG, "null metrics buffer");
+    hipLaunchKernelGGL(k_metrics, dim3((p.B + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, out4_dev);
+    return launched("cs_metrics");
+}
+
+}  // extern "C"

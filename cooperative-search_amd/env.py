@@ -1,0 +1,403 @@
+"""Host-side mirror of the reference env protocol over the HIP path.
+
+Reference boundary (duck-typed object consumed by common/rollout.py and main.py):
+    Env(args, circle_dict); get_env_info(); reset(init=False); get_obs(); get_state();
+    get_avail_agent_actions(i); step(act_list) -> (reward, terminated, win_flag); .target_find; render(); close()
+
+`BatchedFlightEnv` keeps those names and argument meanings for B environments at once and returns device
+tensors.  `FlightSearchEnvEasy` / `FlightSearchEnv` are B = 1 adapters that return exactly the reference's
+Python types (int / bool / fresh float64 ndarrays) so a rollout.py-shaped loop runs unchanged.
+
+All environment arithmetic happens in csrc/coopsearch.hip behind the C ABI of include/coopsearch.h; torch only
+owns device memory and the stream.  There is no CPU fallback: without a GPU and the built library this raises.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .targets import default_circle_dict
+
+DEFAULT_BASE_SEED = 20240000  # env b of the global batch is seeded base + b
+
+
+def _cfg_from_args(args, circle_dict, batch, variant):
+    cfg = _lib.CsConfig()
+    cfg.variant = variant
+    cfg.n_agents = int(args.n_agents)
+    cfg.n_targets = int(args.target_num)
+    cfg.map_size = int(args.map_size)
+    cfg.view_range = int(args.view_range)
+    cfg.time_limit = int(args.time_limit)
+    cfg.agent_mode = int(args.agent_mode)
+    cfg.target_mode = int(args.target_mode)
+    cfg.velocity = float(args.agent_velocity)
+    cfg.safe_dist = float(args.safe_dist)
+    cfg.detect_prob = float(args.detect_prob)
+    cfg.force_dist = float(args.force_dist)
+    cfg.force_factor = 0.8  # POTENTIAL_FORCE_FACTOR, flight_env_easy.py:65
+    if cfg.target_mode == 0:
+        if len(circle_dict["x"]) < cfg.n_targets:
+            raise Exception("target file has fewer rows than target_num")
+        for j in range(min(cfg.n_targets, _lib.MAX_TARGETS)):
+            cfg.cx[j], cfg.cy[j] = float(circle_dict["x"][j]), float(circle_dict["y"][j])
+            cfg.dx[j], cfg.dy[j] = float(circle_dict["dx"][j]), float(circle_dict["dy"][j])
+            cfg.deter[j] = 1 if circle_dict["deter"][j] == "t" else 0
+    cfg.batch = int(batch)
+    return cfg
+
+
+class BatchedFlightEnv:
+    """B independent flight_easy / flight environments resident in HBM, stepped by HIP kernels.
+
+    args        namespace with the reference's fields (common/arguments.py:27-34, :233-284); `args.env`
+                selects the variant ('flight' -> probability-map env, anything else -> flight_easy)
+    circle_dict dict from load_targets (main.py:19-32); defaults to the shipped flight_targets.txt
+    batch       environments on this device
+    seeds       per-env np.random.seed values (uint32 array-like), default DEFAULT_BASE_SEED + env_offset + b
+    env_offset  global index of env 0 (multi-GPU sharding: results do not depend on how the batch is split)
+    freeze_done terminated envs ignore step() (reward 0, terminated 1); False reproduces the reference, which has
+                no terminal guard
+    auto_reset  terminated envs are reset(init=False) at the start of the next step()
+    """
+
+    def __init__(self, args, circle_dict=None, batch=1, device="cuda", seeds=None, env_offset=0, freeze_done=True,
+                 auto_reset=False, variant=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("BatchedFlightEnv needs a GPU: the HIP path has no CPU fallback")
+        self._L = _lib.load()
+        self.args = args
+        if variant is None:
+            variant = "flight" if getattr(args, "env", "flight_easy") == "flight" else "flight_easy"
+        self.variant = variant
+        self.flight = variant == "flight"
+        self.map_size = int(args.map_size)
+        self.target_num = int(args.target_num)
+        self.target_mode = int(args.target_mode)
+        self.agent_mode = int(args.agent_mode)
+        self.n_agents = int(args.n_agents)
+        self.view_range = args.view_range
+        self.time_limit = int(args.time_limit)
+        self.detect_prob = args.detect_prob
+        self.safe_dist = args.safe_dist
+        self.velocity = args.agent_velocity
+        self.force_dist = args.force_dist
+        self.n_actions = 3
+        self.state_shape = self.n_agents * 4 + self.target_num * 3
+        self.obs_shape = 4  # reported as 4 for flight too (quirk Q8); consumers add map_size**2 when args.conv
+        self.batch = int(batch)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("BatchedFlightEnv: device must be a GPU")
+        # same messages / same moment (construction runs reset) as flight_env_easy.py:136,180
+        if self.target_mode not in (0, 1):
+            raise Exception("No such target mode")
+        if self.agent_mode not in (0, 1, 2, 3):
+            raise Exception("No such agent mode")
+        self.circle_dict = circle_dict if circle_dict is not None else default_circle_dict()
+        self.cfg = _cfg_from_args(args, self.circle_dict, self.batch, 1 if self.flight else 0)
+        self._cfgp = C.byref(self.cfg)
+        lay = _lib.CsLayout()
+        _lib.check(self._L.cs_state_layout(self._cfgp, C.byref(lay)))
+        self.layout = lay
+        B, n, m = self.batch, self.n_agents, self.target_num
+        self.cells = self.map_size * self.map_size
+        self.obs_width = self.cells + 4 if self.flight else 4
+        with torch.cuda.device(self.device):
+            self._blob = torch.empty(lay.total_bytes, dtype=torch.uint8, device=self.device)
+            self._reward = torch.zeros(B, dtype=torch.float32, device=self.device)
+            self._terminated = torch.zeros(B, dtype=torch.uint8, device=self.device)
+            self._win = torch.zeros(B, dtype=torch.uint8, device=self.device)
+            self._obs = torch.zeros(B, n, self.obs_width, dtype=torch.float32, device=self.device)
+            self._state = torch.zeros(B, self.state_shape, dtype=torch.float32, device=self.device)
+            self._avail = torch.ones(B, self.n_actions, dtype=torch.float32, device=self.device)
+            self._metrics = torch.zeros(4, dtype=torch.float64, device=self.device)
+        self.freeze_done = bool(freeze_done)
+        self.auto_reset = bool(auto_reset)
+        if self.freeze_done and self.auto_reset:
+            self.freeze_done = False
+        self.env_offset = int(env_offset)
+        _lib.check(self._L.cs_init(self._cfgp, self._blob.data_ptr(), self._stream()))
+        if seeds is None:
+            seeds = (DEFAULT_BASE_SEED + self.env_offset + np.arange(B, dtype=np.int64)) % (1 << 32)
+        self.seed(seeds)
+        self.reset(init=True)  # FlightSearchEnvEasy.__init__ ends with self.reset(init=True), :68
+
+    # ------------------------------------------------------------------------------------------------ plumbing
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _view(self, off, count, dtype, shape):
+        itemsize = torch.empty((), dtype=dtype).element_size()
+        return self._blob[off:off + count * itemsize].view(dtype).view(*shape)
+
+    def raw(self):
+        """Zero-copy typed views of the state blob (layout: include/coopsearch.h, cs_layout)."""
+        B, lay = self.batch, self.layout
+        d = dict(
+            tgt=self._view(lay.tgt_off, B * 32, torch.float64, (B, 16, 2)),
+            agent=self._view(lay.agent_off, B * 32, torch.float64, (B, 8, 4)),
+            hdr=self._view(lay.hdr_off, B * 16, torch.int32, (B, 16)),
+            mt=self._view(lay.mt_off, B * 624, torch.int32, (B, 624)),
+        )
+        if self.flight:
+            d["prob"] = self._view(lay.prob_off, B * self.cells, torch.float32, (B, self.map_size, self.map_size))
+        return d
+
+    def seed(self, seeds):
+        """np.random.seed(seeds[b]) for env b's private NumPy-compatible stream."""
+        s = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint64) & 0xFFFFFFFF, dtype=np.uint32)
+        if s.shape != (self.batch,):
+            raise ValueError("seeds must have shape (batch,)")
+        t = torch.from_numpy(s.view(np.int32)).to(self.device)
+        _lib.check(self._L.cs_seed(self._cfgp, self._blob.data_ptr(), t.data_ptr(), self._stream()))
+        self._seeds_keepalive = t
+
+    # ------------------------------------------------------------------------------------------- reference API
+    def get_env_info(self):
+        """flight_env_easy.py:71-77 (+ 'batch')."""
+        return {"n_actions": self.n_actions, "state_shape": self.state_shape, "obs_shape": self.obs_shape,
+                "episode_limit": self.time_limit, "batch": self.batch}
+
+    def reset(self, init=False, mask=None):
+        """env.reset(init) for every env (or those with mask[b] != 0).  flight: init=True clears the map."""
+        mptr = None
+        if mask is not None:
+            mask = torch.as_tensor(mask, device=self.device)
+            if mask.dtype != torch.uint8:
+                mask = mask.to(torch.uint8)
+            mask = mask.contiguous()
+            if mask.shape != (self.batch,):
+                raise ValueError("mask must have shape (batch,)")
+            mptr = mask.data_ptr()
+        _lib.check(self._L.cs_reset(self._cfgp, self._blob.data_ptr(), mptr, 1 if init else 0,
+                                    self._obs.data_ptr(), self._state.data_ptr(), self._stream()))
+
+    def _actions(self, actions, lead_shape):
+        if not torch.is_tensor(actions):
+            actions = torch.as_tensor(np.asarray(actions), device=self.device)
+        if actions.device != self.device:
+            actions = actions.to(self.device)
+        if actions.dim() == 0 or actions.shape[-1] != self.n_agents:
+            raise Exception("Act num mismatch agent")  # flight_env_easy.py:256-257
+        if tuple(actions.shape) != tuple(lead_shape) + (self.n_agents,):
+            raise ValueError(f"actions must have shape {tuple(lead_shape) + (self.n_agents,)}")
+        if actions.dtype not in (torch.int32, torch.int64):
+            actions = actions.to(torch.int64)
+        return actions.contiguous()
+
+    def _flags(self, actions):
+        f = 0
+        if self.freeze_done:
+            f |= _lib.FREEZE_DONE
+        if self.auto_reset and not self.flight:
+            f |= _lib.AUTO_RESET
+        if actions.dtype == torch.int64:
+            f |= _lib.ACTIONS_I64
+        return f
+
+    def step(self, actions):
+        """env.step(act_list) for every env: actions [B, n] in {0,1,2} -> (reward[B] f32, terminated[B] bool,
+        win[B] bool).  The returned tensors (and get_obs/get_state) are overwritten by the next step."""
+        a = self._actions(actions, (self.batch,))
+        if self.auto_reset and self.flight:
+            # the reset-time detection pass updates the map before the step's own pass: two launches
+            self.reset(init=False, mask=self._done_mask())
+        _lib.check(self._L.cs_step(self._cfgp, self._blob.data_ptr(), a.data_ptr(), self._flags(a),
+                                   self._reward.data_ptr(), self._terminated.data_ptr(), self._win.data_ptr(),
+                                   self._obs.data_ptr(), self._state.data_ptr(), self._stream()))
+        return self._reward, self._terminated.view(torch.bool), self._win.view(torch.bool)
+
+    def rollout(self, actions, emit=True):
+        """T steps in one launch (flight_easy): actions [T, B, n] -> dict of [T, B, ...] tensors."""
+        if self.flight:
+            raise Exception("rollout: flight_easy only")
+        T = int(actions.shape[0])
+        a = self._actions(actions, (T, self.batch))
+        B, n = self.batch, self.n_agents
+        out = dict(
+            reward=torch.empty(T, B, dtype=torch.float32, device=self.device),
+            terminated=torch.empty(T, B, dtype=torch.uint8, device=self.device),
+            win=torch.empty(T, B, dtype=torch.uint8, device=self.device),
+            obs=torch.empty(T, B, n, 4, dtype=torch.float32, device=self.device) if emit else None,
+            state=torch.empty(T, B, self.state_shape, dtype=torch.float32, device=self.device) if emit else None,
+        )
+        _lib.check(self._L.cs_rollout(self._cfgp, self._blob.data_ptr(), a.data_ptr(), T, self._flags(a),
+                                      out["reward"].data_ptr(), out["terminated"].data_ptr(), out["win"].data_ptr(),
+                                      out["obs"].data_ptr() if emit else None,
+                                      out["state"].data_ptr() if emit else None, self._stream()))
+        if emit:
+            self._obs.copy_(out["obs"][-1])
+            self._state.copy_(out["state"][-1])
+        else:
+            self.refresh()
+        out["terminated"] = out["terminated"].view(torch.bool)
+        out["win"] = out["win"].view(torch.bool)
+        return out
+
+    def refresh(self):
+        """Re-emit get_obs()/get_state() from the device state (after editing raw())."""
+        _lib.check(self._L.cs_emit(self._cfgp, self._blob.data_ptr(), self._obs.data_ptr(), self._state.data_ptr(),
+                                   self._stream()))
+
+    def get_obs(self):
+        """[B, n, 4] (flight: [B, n, map*map + 4], map first) float32 -- live buffer."""
+        return self._obs
+
+    def get_state(self):
+        """[B, 4n + 3m] float32 -- live buffer."""
+        return self._state
+
+    def get_avail_agent_actions(self, agent_id):
+        if agent_id >= self.n_agents:
+            raise Exception("Agent id out of range")  # flight_env_easy.py:185-186
+        return self._avail
+
+    @property
+    def target_find(self):
+        """int32 [B]: running count of found targets (flight_env_easy.py:42)."""
+        return self.raw()["hdr"][:, _lib.H_TARGET_FIND]
+
+    @property
+    def time_step(self):
+        return self.raw()["hdr"][:, _lib.H_TIME_STEP]
+
+    @property
+    def total_reward(self):
+        return self.raw()["hdr"][:, _lib.H_TOTAL_REWARD]
+
+    @property
+    def win_flag(self):
+        return (self.raw()["hdr"][:, _lib.H_FLAGS] & 1).to(torch.bool)
+
+    def _done_mask(self):
+        h = self.raw()["hdr"]
+        return ((h[:, _lib.H_TARGET_FIND] >= self.target_num) | (h[:, _lib.H_TIME_STEP] >= self.time_limit)).to(torch.uint8)
+
+    def metric_partials(self):
+        """float64[4] on device: sum total_reward, sum win, sum target_find, env count (runner.py:86-96)."""
+        self._metrics.zero_()
+        _lib.check(self._L.cs_metrics(self._cfgp, self._blob.data_ptr(), self._metrics.data_ptr(), self._stream()))
+        return self._metrics
+
+    def render(self):
+        pass  # flight_env_easy.py:324-343 is a matplotlib scatter; not on the compute path
+
+    def close(self):
+        pass
+
+
+class _SingleEnvAdapter:
+    """B = 1 adapter with the reference's exact return types (BASELINE config 1 plumbing)."""
+
+    _variant = "flight_easy"
+
+    def __init__(self, args, circle_dict, seed=None, device="cuda"):
+        self.args = args
+        if seed is None:
+            seed = int(np.random.randint(0, 2 ** 31 - 1))  # the reference rides numpy's global stream
+        self._env = BatchedFlightEnv(args, circle_dict, batch=1, device=device, seeds=[seed], freeze_done=False,
+                                     variant=self._variant)
+        e = self._env
+        self.map_size, self.target_num, self.n_agents = e.map_size, e.target_num, e.n_agents
+        self.target_mode, self.agent_mode = e.target_mode, e.agent_mode
+        self.view_range, self.time_limit = e.view_range, e.time_limit
+        self.n_actions, self.state_shape, self.obs_shape = e.n_actions, e.state_shape, e.obs_shape
+        self.circle_dict = e.circle_dict
+
+    def seed(self, s):
+        self._env.seed([int(s)])
+
+    def get_env_info(self):
+        info = self._env.get_env_info()
+        info.pop("batch")
+        return info
+
+    def reset(self, init=False):
+        self._env.reset(init=init)
+
+    def get_avail_agent_actions(self, agent_id):
+        if agent_id >= self.n_agents:
+            raise Exception("Agent id out of range")
+        return np.ones(self.n_actions)
+
+    def get_obs(self):
+        return self._env.get_obs()[0].to(torch.float64).cpu().numpy()
+
+    def get_state(self):
+        return self._env.get_state()[0].to(torch.float64).cpu().numpy()
+
+    def step(self, act_list):
+        if len(act_list) != self.n_agents:
+            raise Exception("Act num mismatch agent")
+        acts = [int(a) for a in act_list]  # python ints, np.int64 or 0-dim torch.LongTensor (agent/agent.py:36,72)
+        for a in acts:
+            if a not in (0, 1, 2, -1, -2, -3):
+                raise IndexError("list index out of range")  # dyaw[act] in the reference
+        acts = [a % 3 for a in acts]
+        r, t, w = self._env.step(torch.tensor([acts], dtype=torch.int32))
+        return int(r.item()), bool(t.item()), bool(w.item())
+
+    # attributes the reference exposes (read by rollout.py:79,190,201 and by debugging code)
+    def _hdr(self):
+        return self._env.raw()["hdr"][0].cpu().numpy()
+
+    @property
+    def target_find(self):
+        return int(self._hdr()[_lib.H_TARGET_FIND])
+
+    @property
+    def time_step(self):
+        return int(self._hdr()[_lib.H_TIME_STEP])
+
+    @property
+    def total_reward(self):
+        return int(self._hdr()[_lib.H_TOTAL_REWARD])
+
+    @property
+    def curr_reward(self):
+        return int(self._hdr()[_lib.H_CURR_REWARD])
+
+    @property
+    def win_flag(self):
+        return bool(self._hdr()[_lib.H_FLAGS] & 1)
+
+    @property
+    def out_flag(self):
+        f = int(self._hdr()[_lib.H_FLAGS]) >> 8
+        return [(f >> i) & 1 for i in range(self.n_agents)]
+
+    @property
+    def agent_pos(self):
+        a = self._env.raw()["agent"][0, :self.n_agents, :2].cpu().numpy()
+        return [[float(x), float(y)] for x, y in a]
+
+    @property
+    def agent_yaw(self):
+        return [float(v) for v in self._env.raw()["agent"][0, :self.n_agents, 2].cpu().numpy()]
+
+    @property
+    def target_pos(self):
+        t = self._env.raw()["tgt"][0, :self.target_num].cpu().numpy()
+        return [[float(x), float(y)] for x, y in t]
+
+    @property
+    def prob_map(self):
+        return self._env.raw()["prob"][0].to(torch.float64).cpu().numpy()
+
+    def render(self):
+        pass
+
+    def close(self):
+        pass
+
+
+class FlightSearchEnvEasy(_SingleEnvAdapter):
+    """Drop-in for /root/reference/env/flight_env_easy.py:14 FlightSearchEnvEasy(args, circle_dict)."""
+    _variant = "flight_easy"
+
+
+class FlightSearchEnv(_SingleEnvAdapter):
+    """Drop-in for /root/reference/env/flight_env.py:14 FlightSearchEnv(args, circle_dict)."""
+    _variant = "flight"

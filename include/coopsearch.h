@@ -1,0 +1,147 @@
+/*
+ * include/coopsearch.h -- C ABI of libcoopsearch_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for ONE path of WZN1ng/Cooperative-Search: the flight_easy / flight environment
+ * reset + step + reward + obs/state emission, batched over B independent environments that live in HBM.
+ * The reference has no FFI: its boundary is a duck-typed Python object.  Every
+ * entry point below names the reference method it replaces (paths relative to the reference repo); the
+ * Python mirror of that object protocol lives in cooperative-search_amd/env.py and binds these symbols
+ * with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain C types only; every *_dev pointer is DEVICE memory owned by the caller (e.g. a torch tensor's
+ *     data_ptr()); `stream` is a hipStream_t passed as void* (NULL = the legacy default stream);
+ *   - nothing allocates, synchronises or copies on the step path; all work is enqueued on `stream`;
+ *   - return value: 0 = OK, negative = CS_E_*; cs_last_error() gives a thread-local message;
+ *   - one environment = 16 lanes of a wavefront: lane t owns target t, the <= 8 agents are replicated
+ *     in every lane's registers.  Hence n_targets <= 16 and n_agents <= 8.
+ *
+ * Numerics contract: agent positions and yaw are fp64 and follow the reference's
+ * float operations one for one (same order, no FMA contraction, correctly rounded sin/cos of the
+ * accumulated yaw); the uniform draws are NumPy's MT19937 stream per env, consumed in the reference's
+ * order; rewards, flags and counts are integers.  Emitted obs/state/reward tensors are fp32.
+ */
+#ifndef COOPSEARCH_H
+#define COOPSEARCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CS_ABI_VERSION 1
+#define CS_MAX_AGENTS 8
+#define CS_MAX_TARGETS 16
+#define CS_MAX_MAP 64
+
+enum { CS_OK = 0, CS_E_CONFIG = -1, CS_E_ARG = -2, CS_E_LAUNCH = -3 };
+
+/* cs_step / cs_rollout flags */
+enum {
+    CS_FREEZE_DONE = 1,  /* an env that was terminated on entry is left untouched: reward 0, terminated 1.
+                            (The reference has no terminal guard, flight_env_easy.py:303-314; leave this
+                            flag clear to reproduce that, as the B = 1 adapter does.) */
+    CS_AUTO_RESET = 2,   /* an env that was terminated on entry is reset(init=False) first, then stepped */
+    CS_ACTIONS_I64 = 4   /* actions_dev holds int64 (torch.long) instead of int32 */
+};
+
+/* Environment constants: common/arguments.py:27-34 (map_size, target_num, target_mode, agent_mode, n_agents,
+ * view_range) and :233-284 (get_flight_args / get_flight_easy_args), plus the parsed target file
+ * (main.py:19-32 load_targets; units of map_size/10). */
+typedef struct cs_config {
+    int32_t variant;      /* 0 = flight_easy (env/flight_env_easy.py), 1 = flight (env/flight_env.py) */
+    int32_t n_agents;     /* 1..CS_MAX_AGENTS */
+    int32_t n_targets;    /* 1..CS_MAX_TARGETS (reference: 15) */
+    int32_t map_size;     /* reference: 50 */
+    int32_t view_range;   /* reference: 7 */
+    int32_t time_limit;   /* reference: 200 */
+    int32_t agent_mode;   /* 0..3, flight_env_easy.py:139-180 */
+    int32_t target_mode;  /* 0 = target file + gaussian jitter, 1 = uniform; flight_env_easy.py:95-136 */
+    double velocity;      /* args.agent_velocity = 1 */
+    double safe_dist;     /* 1 */
+    double detect_prob;   /* 0.9 */
+    double force_dist;    /* 3 */
+    double force_factor;  /* POTENTIAL_FORCE_FACTOR = 0.8, flight_env_easy.py:65 */
+    double cx[CS_MAX_TARGETS], cy[CS_MAX_TARGETS], dx[CS_MAX_TARGETS], dy[CS_MAX_TARGETS];
+    int32_t deter[CS_MAX_TARGETS]; /* 1 = 't' fixed, 0 = 'f' jittered */
+    int64_t batch;        /* B: environments resident on this device */
+} cs_config;
+
+/* Byte offsets of the per-env arrays inside the caller-allocated state blob (all 256-byte aligned). */
+typedef struct cs_layout {
+    size_t total_bytes;
+    size_t tgt_off;    /* double [B][16][2]   target (x, y)                                             */
+    size_t agent_off;  /* double [B][8][4]    agent (x, y, yaw, spare)                                   */
+    size_t hdr_off;    /* int32  [B][16]      CS_H_* words below                                         */
+    size_t mt_off;     /* uint32 [B][624]     MT19937 state, circular (incremental) form + cursor in hdr */
+    size_t prob_off;   /* float  [B][map*map] probability map, first index = x cell (flight only)        */
+} cs_layout;
+
+/* words of the per-env header */
+enum {
+    CS_H_FOUND = 0,     /* bit j = target j found                       (Target.find, flight_env_easy.py:12) */
+    CS_H_NEWLY = 1,     /* targets found by the last detection pass     (tgt_found, flight_env.py:238)       */
+    CS_H_TARGET_FIND = 2, /* env.target_find                             (flight_env_easy.py:42)              */
+    CS_H_FLAGS = 3,     /* bit0 win_flag, bit1 map dirty, bits 8..15 out_flag[i]                             */
+    CS_H_TIME_STEP = 4, /* env.time_step                                                                      */
+    CS_H_TOTAL_REWARD = 5, /* env.total_reward (integer)                                                      */
+    CS_H_MT_POS = 6,    /* cursor into the circular MT19937 state, 0..623                                    */
+    CS_H_EPISODES = 7,  /* resets performed                                                                  */
+    CS_H_WORDS_LO = 8,  /* 32-bit MT outputs consumed since cs_seed (u64, lo/hi)                             */
+    CS_H_WORDS_HI = 9,
+    CS_H_CURR_REWARD = 10, /* env.curr_reward of the last detection pass                                     */
+    CS_H_WORDS = 16
+};
+
+int cs_abi_version(void);
+const char *cs_last_error(void);
+
+/* Fills `out` with the state-blob layout for cfg (cfg->batch envs).  Host only. */
+int cs_state_layout(const cs_config *cfg, cs_layout *out);
+
+/* Zeroes the blob and sets every probability map to 0.5 (FlightSearchEnv.__init__, flight_env.py:53). */
+int cs_init(const cs_config *cfg, void *state_dev, void *stream);
+
+/* np.random.seed(seeds[b]) for env b's private stream (the reference shares one global stream between a
+ * single env and everything else, and never seeds it: SURVEY.md Appendix C Q1). */
+int cs_seed(const cs_config *cfg, void *state_dev, const uint32_t *seeds_dev, void *stream);
+
+/* env.reset(init) -- flight_env_easy.py:79-182, flight_env.py:83-191 -- for every env with mask[b] != 0
+ * (mask_dev NULL = all).  Ends with the reference's reset-time detection pass (and map update for flight).
+ * obs_dev / state_dev_out (either may be NULL) receive get_obs() / get_state() of ALL envs afterwards:
+ *   obs   float [B][n][4]            flight_easy   (get_obs, flight_env_easy.py:218-221)
+ *         float [B][n][map*map + 4]  flight        (get_obs, flight_env.py:223-230: map first, 4 features last)
+ *   state float [B][4n + 3m]                       (get_state, flight_env_easy.py:190-216) */
+int cs_reset(const cs_config *cfg, void *state_dev, const uint8_t *mask_dev, int init,
+             float *obs_dev, float *state_out_dev, void *stream);
+
+/* env.step(act_list) -- flight_env_easy.py:303-314 (_agent_step :255-291, _potential_energy_force :293-301,
+ * _update_obs :223-253), flight_env.py:357-368 (+ _update_prob_map :275-303) -- for every env.
+ *   actions_dev    int32 or int64 [B][n], values 0/1/2
+ *   reward_dev     float [B]   (integer valued)     terminated_dev / win_dev  uint8 [B]
+ *   obs_dev / state_out_dev as in cs_reset (may be NULL) */
+int cs_step(const cs_config *cfg, void *state_dev, const void *actions_dev, int flags,
+            float *reward_dev, uint8_t *terminated_dev, uint8_t *win_dev,
+            float *obs_dev, float *state_out_dev, void *stream);
+
+/* T consecutive env.step calls in ONE launch with the env resident in registers (flight_easy only):
+ * actions [T][B][n]; reward [T][B]; terminated/win [T][B]; obs [T][B][n][4]; state_out [T][B][4n+3m]
+ * (obs/state_out may be NULL).  Same results as T cs_step calls with the same flags. */
+int cs_rollout(const cs_config *cfg, void *state_dev, const void *actions_dev, int T, int flags,
+               float *reward_dev, uint8_t *terminated_dev, uint8_t *win_dev,
+               float *obs_dev, float *state_out_dev, void *stream);
+
+/* get_obs() + get_state() of every env without stepping. */
+int cs_emit(const cs_config *cfg, void *state_dev, float *obs_dev, float *state_out_dev, void *stream);
+
+/* Per-device partial sums of the evaluation metrics of runner.py:86-96 / rollout.py:190-198:
+ * out4_dev[0] += sum total_reward, [1] += sum win_flag, [2] += sum target_find, [3] += number of envs.
+ * (double[4]; the caller zeroes it, then all-gathers / all-reduces the partials over RCCL.) */
+int cs_metrics(const cs_config *cfg, void *state_dev, double *out4_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

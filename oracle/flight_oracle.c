@@ -111,6 +111,38 @@ static int g_exact_pow = 1;
 void orc_set_exact_pow(int on) { g_exact_pow = on; }
 static inline double sq(double v) { return g_exact_pow ? libm_pow(v, 2.0) : v * v; }
 
+/* Trig of the accumulated heading.  Mode 0 (default): libm sin/cos -- what the reference calls, bit-pinned by
+ * the golden traces.  Mode 1: correctly rounded via the double-double table (the arithmetic the HIP kernel
+ * uses; glibc's sin/cos are misrounded by 1 ulp for ~0.2 % of the reachable headings).
+ * Mode 1 with orc_set_exact_pow(0) is the configuration the HIP path must match bit for bit. */
+static int g_trig_mode = 0;
+void orc_set_trig_mode(int mode) { g_trig_mode = mode; }
+static const double k_trig[37][7] = {
+#include "trig_table.inc"
+};
+static void heading_trig(double yaw, double *s, double *c) {
+    if (g_trig_mode == 0) {
+        *s = sin(yaw);
+        *c = cos(yaw);
+        return;
+    }
+    int k = (int)(yaw * 5.729577951308232 + 0.5); /* 18/pi */
+    k = k < 0 ? 0 : (k > 36 ? 36 : k);
+    const double *r = k_trig[k];
+    double t = yaw - r[0];
+    double dh = t - r[1];
+    double bb = dh - t;
+    double err = (t - (dh - bb)) + ((-r[1]) - bb);
+    double dl = err - r[2];
+    if (fabs(dh) > 1e-6) {
+        *s = sin(yaw);
+        *c = cos(yaw);
+        return;
+    }
+    *s = r[3] + ((r[4] + dh * (r[5] - 0.5 * dh * r[3])) + dl * r[5]);
+    *c = r[5] + ((r[6] - dh * (r[3] + 0.5 * dh * r[5])) - dl * r[3]);
+}
+
 struct orc_env {
     orc_config c;
     double ax[ORC_MAX_AGENTS], ay[ORC_MAX_AGENTS];
@@ -310,8 +342,10 @@ static void agent_step(orc_env *e, const int32_t *act) {
         else if (a == 2) yaw += -(M_PI / 18.0);
         if (yaw > 2.0 * M_PI) yaw -= 2.0 * M_PI;
         else if (yaw < 0.0) yaw += 2.0 * M_PI;
-        double x = e->ax[i] + e->c.velocity * cos(yaw);
-        double y = e->ay[i] + e->c.velocity * sin(yaw);
+        double sn, cs;
+        heading_trig(yaw, &sn, &cs);
+        double x = e->ax[i] + e->c.velocity * cs;
+        double y = e->ay[i] + e->c.velocity * sn;
         double fx, fy;
         potential_force(e, i, &fx, &fy);
         x += fx;
@@ -350,8 +384,7 @@ static void agent_feats(const orc_env *e, int i, double *o) {
     const double L = (double)e->c.map_size;
     o[0] = (e->ax[i] - 0.5 * L) / (L / 2.0);
     o[1] = (e->ay[i] - 0.5 * L) / (L / 2.0);
-    o[2] = cos(e->yaw[i]);
-    o[3] = sin(e->yaw[i]);
+    heading_trig(e->yaw[i], &o[3], &o[2]);
 }
 
 /* flight_env_easy.py:218-221 ; flight_env.py:223-230 (map first, 4 features last) */

@@ -59,6 +59,7 @@ void orc_get_state(const orc_env *e, double *out);  /* [4n+3m] */
 /* raw state */
 void orc_get_agents(const orc_env *e, double *pos_xy, double *yaw, int32_t *out_flag);
 void orc_set_agents(orc_env *e, const double *pos_xy, const double *yaw);
+void orc_set_trig_mode(int mode); /* 0 (default): libm sin/cos like the reference; 1: correctly rounded table (HIP-equivalent) */
 void orc_set_exact_pow(int on); /* 1 (default): `**2` = libm pow(x,2.0) like the reference; 0: x*x (timed baseline) */
 void orc_get_targets(const orc_env *e, double *pos_xy, int32_t *found);
 void orc_set_targets(orc_env *e, const double *pos_xy, const int32_t *found);

@@ -36,7 +36,8 @@ def build(force=False):
     """Compile oracle/liboracle_flight.so with gcc (a few hundred ms)."""
     src = os.path.join(_HERE, "flight_oracle.c")
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(
-            os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "flight_oracle.h"))):
+            os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "flight_oracle.h")),
+            os.path.getmtime(os.path.join(_HERE, "trig_table.inc"))):
         subprocess.check_call(["make", "-C", _HERE, "liboracle_flight.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -62,6 +63,7 @@ def lib():
         L.orc_get_agents.argtypes = [vp, f64p, f64p, i32p]
         L.orc_set_agents.argtypes = [vp, f64p, f64p]
         L.orc_set_exact_pow.argtypes = [C.c_int]
+        L.orc_set_trig_mode.argtypes = [C.c_int]
         L.orc_get_targets.argtypes = [vp, f64p, i32p]
         L.orc_set_targets.argtypes = [vp, f64p, i32p]
         L.orc_get_counters.argtypes = [vp, i32p]
@@ -124,6 +126,24 @@ def make_config(variant="flight_easy", n_agents=3, n_targets=15, agent_mode=0, t
 
 def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
+
+
+def set_trig_mode(mode):
+    """0 (default): libm sin/cos, bit-pinned to the reference; 1: correctly rounded table = the HIP kernel's trig."""
+    lib().orc_set_trig_mode(int(mode))
+
+
+class hip_equivalent_arithmetic:
+    """Context manager: oracle in the configuration the HIP path must match bit for bit (CR trig, x*x)."""
+
+    def __enter__(self):
+        set_trig_mode(1)
+        set_exact_pow(False)
+        return self
+
+    def __exit__(self, *exc):
+        set_trig_mode(0)
+        set_exact_pow(True)
 
 
 def set_exact_pow(on):

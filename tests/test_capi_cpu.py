@@ -1,0 +1,102 @@
+"""CPU tests of the boundary: the C-ABI library builds, loads and exports every symbol include/*.h declares,
+the host-only entry points behave (layout, config errors), and the host-side restatements (target loader, env
+constants) match the fixtures.  No compute call is made here (no GPU in the build container)."""
+import ctypes as C
+import os
+import re
+import types
+
+import pytest
+
+import cooperative_search_amd as cs
+from cooperative_search_amd import _lib
+from golden_util import target_table
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    names = []
+    for fn in os.listdir(os.path.join(ROOT, "include")):
+        if fn.endswith(".h"):
+            txt = open(os.path.join(ROOT, "include", fn)).read()
+            txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+            names += re.findall(r"\b(cs_[a-z_0-9]+)\s*\(", txt)
+    return sorted(set(names))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    L = _lib.load()
+    assert os.path.exists(_lib.library_path())
+    syms = declared_symbols()
+    assert set(syms) == set(_lib.EXPORTS), (syms, _lib.EXPORTS)
+    for s in syms:
+        assert hasattr(L, s), s
+    assert L.cs_abi_version() == 1
+
+
+def _cfg(**kw):
+    args = cs.make_env_args(**{k: v for k, v in kw.items() if k in ("env", "n_agents", "agent_mode", "target_mode")})
+    from cooperative_search_amd.env import _cfg_from_args
+    return _cfg_from_args(args, cs.default_circle_dict(), kw.get("batch", 4096), 1 if kw.get("env") == "flight" else 0)
+
+
+def test_state_layout_host_only():
+    L = _lib.load()
+    lay = _lib.CsLayout()
+    cfg = _cfg(n_agents=3, batch=4096)
+    assert L.cs_state_layout(C.byref(cfg), C.byref(lay)) == 0
+    B = 4096
+    assert lay.tgt_off == 0 and lay.agent_off == B * 256 and lay.hdr_off == lay.agent_off + B * 256
+    assert lay.mt_off == lay.hdr_off + B * 64 and lay.total_bytes == lay.mt_off + B * 624 * 4
+    cfg = _cfg(env="flight", n_agents=3, batch=8192)
+    assert L.cs_state_layout(C.byref(cfg), C.byref(lay)) == 0
+    assert lay.total_bytes == lay.prob_off + 8192 * 2500 * 4
+    for off in (lay.tgt_off, lay.agent_off, lay.hdr_off, lay.mt_off, lay.prob_off):
+        assert off % 256 == 0
+
+
+@pytest.mark.parametrize("field,value,msg", [("n_agents", 9, "n_agents"), ("n_targets", 17, "n_targets"),
+                                             ("agent_mode", 4, "No such agent mode"),
+                                             ("target_mode", 2, "No such target mode"), ("batch", 0, "batch")])
+def test_config_errors_are_reported(field, value, msg):
+    L = _lib.load()
+    cfg = _cfg(n_agents=3)
+    setattr(cfg, field, value)
+    lay = _lib.CsLayout()
+    assert L.cs_state_layout(C.byref(cfg), C.byref(lay)) == -1
+    assert msg in L.cs_last_error().decode()
+
+
+def test_load_targets_matches_reference_parse():
+    t = target_table()
+    d = cs.load_targets()
+    assert d == t
+    assert cs.default_circle_dict() == t
+
+
+def test_env_constants_match_reference_setters():
+    a = cs.make_env_args("flight_easy", n_agents=5)
+    assert (a.agent_velocity, a.time_limit, a.safe_dist, a.detect_prob, a.force_dist, a.search_env, a.conv) == \
+        (1, 200, 1, 0.9, 3, True, False)
+    assert (a.map_size, a.target_num, a.view_range, a.n_agents) == (50, 15, 7, 5)
+    f = cs.make_env_args("flight")
+    assert f.conv is True and f.conv_out_dim == 16 and f.wrong_alarm_prob == 0.1
+
+
+def test_env_refuses_to_run_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        cs.BatchedFlightEnv(cs.make_env_args(), batch=4)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "cooperative-search_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, fn)).read()
+                assert "oracle" not in txt.replace("the oracle keeps its own copy", "").replace('"oracle", "trig_table.inc"', ""), \
+                    f"{fn} mentions the oracle"

@@ -1,0 +1,327 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against (a) golden vectors captured from the
+imported reference and (b) the C oracle on identical seeds and actions.
+
+Bars (written here, per the numerics contract in DESIGN.md section 3):
+  * every integer quantity (reward, terminated, win, found flags, target_find, out flags, number of MT words
+    consumed per step) is EXACT against the reference goldens and against the oracle;
+  * agent positions / yaw are BIT-IDENTICAL (atol = 0) to the oracle run in its HIP-equivalent arithmetic
+    (correctly rounded trig, x*x), and within 1e-9 of the reference goldens (libm pow / sin / cos differ by
+    1 ulp in ~0.1 % of evaluations);
+  * target positions within 1e-12 (device log vs glibc log in the polar gaussian);
+  * emitted fp32 obs / state within 1e-6 of the fp64 reference values (north-star tolerance: 1e-5).
+"""
+import numpy as np
+import pytest
+import torch
+
+import cooperative_search_amd as cs
+from cooperative_search_amd import _lib
+from golden_util import load_trace, trace_names
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 1e-6
+
+
+def make_env(meta, batch=1, seeds=None, **kw):
+    args = cs.make_env_args(meta["env"], n_agents=meta["n_agents"], agent_mode=meta["agent_mode"],
+                            target_mode=meta["target_mode"])
+    return cs.BatchedFlightEnv(args, batch=batch, seeds=seeds, **kw)
+
+
+def hdr(env):
+    return env.raw()["hdr"].cpu().numpy()
+
+
+def words(h):
+    return (h[:, _lib.H_WORDS_LO].astype(np.uint32).astype(np.uint64)
+            | (h[:, _lib.H_WORDS_HI].astype(np.uint32).astype(np.uint64) << np.uint64(32)))
+
+
+@pytest.mark.parametrize("name", trace_names())
+def test_hip_replays_reference_golden_trace(name):
+    meta, z = load_trace(name)
+    n, m = meta["n_agents"], 15
+    flight = meta["env"] == "flight"
+    env = make_env(meta, batch=1, seeds=[meta["seed"]], freeze_done=False)
+    for e, ep in enumerate(meta["episodes"]):
+        p = f"e{e}_"
+        env.reset(init=ep["init"])
+        raw = env.raw()
+        tgt = raw["tgt"][0, :m].cpu().numpy()
+        np.testing.assert_allclose(tgt, z[p + "target_pos"], rtol=0, atol=1e-12, err_msg=name + " target_pos")
+        h = hdr(env)[0]
+        assert [(h[_lib.H_FOUND] >> j) & 1 for j in range(m)] == list(z[p + "reset_found"])
+        assert h[_lib.H_TARGET_FIND] == int(z[p + "reset_target_find"])
+        ag = raw["agent"][0, :n].cpu().numpy()
+        np.testing.assert_array_equal(ag[:, :2], z[p + "reset_agent_pos"])
+        np.testing.assert_array_equal(ag[:, 2], z[p + "reset_yaw"])
+        np.testing.assert_allclose(env.get_obs()[0, :, -4:].cpu().numpy(), z[p + "reset_obs"], rtol=0, atol=F32_TOL)
+        np.testing.assert_allclose(env.get_state()[0].cpu().numpy(), z[p + "reset_state"], rtol=0, atol=F32_TOL)
+        if flight:
+            np.testing.assert_allclose(raw["prob"][0].cpu().numpy(), z[p + "reset_prob_map"], rtol=0, atol=F32_TOL)
+            np.testing.assert_allclose(env.get_obs()[0, :, :-4].cpu().numpy().reshape(n, 50, 50),
+                                       np.broadcast_to(z[p + "reset_prob_map"], (n, 50, 50)), rtol=0, atol=F32_TOL)
+        pokes = {}
+        if p + "poke_steps" in z:
+            pokes = {int(t): k for k, t in enumerate(z[p + "poke_steps"])}
+        maps = {}
+        if p + "prob_map_steps" in z:
+            maps = {int(t): z[p + "prob_maps"][k] for k, t in enumerate(z[p + "prob_map_steps"])}
+        acts = z[p + "actions"]
+        w_prev = int(words(hdr(env))[0])
+        for t in range(ep["steps"]):
+            tag = f"{name} {p}step {t}"
+            if t in pokes:
+                k = pokes[t]
+                a = env.raw()["agent"]
+                a[0, :n, 0:2] = torch.from_numpy(z[p + "poke_agent_pos"][k]).to(a.device)
+                a[0, :n, 2] = torch.from_numpy(z[p + "poke_yaw_idx"][k] * (np.pi / 18.0)).to(a.device)
+            r, term, win = env.step(torch.from_numpy(acts[t:t + 1].astype(np.int32)))
+            assert int(r.item()) == int(z[p + "reward"][t]), tag + " reward"
+            assert int(term.item()) == int(z[p + "terminated"][t]), tag + " terminated"
+            assert int(win.item()) == int(z[p + "win"][t]), tag + " win"
+            h = hdr(env)[0]
+            assert h[_lib.H_TARGET_FIND] == int(z[p + "target_find"][t]), tag
+            assert h[_lib.H_TIME_STEP] == int(z[p + "time_step"][t]), tag
+            assert [(h[_lib.H_FOUND] >> j) & 1 for j in range(m)] == list(z[p + "found"][t]), tag + " found"
+            assert [(h[_lib.H_FLAGS] >> (8 + i)) & 1 for i in range(n)] == list(z[p + "out_flag"][t]), tag + " out"
+            w_now = int(words(hdr(env))[0])
+            assert w_now - w_prev == 2 * int(z[p + "n_draws"][t]), tag + " draws consumed"
+            w_prev = w_now
+            ag = env.raw()["agent"][0, :n].cpu().numpy()
+            np.testing.assert_allclose(ag[:, :2], z[p + "agent_pos"][t], rtol=0, atol=1e-9, err_msg=tag + " pos")
+            np.testing.assert_allclose(ag[:, 2], z[p + "yaw"][t], rtol=0, atol=0, err_msg=tag + " yaw")
+            np.testing.assert_allclose(env.get_obs()[0, :, -4:].cpu().numpy(), z[p + "obs"][t], rtol=0, atol=F32_TOL,
+                                       err_msg=tag + " obs")
+            np.testing.assert_allclose(env.get_state()[0].cpu().numpy(), z[p + "state"][t], rtol=0, atol=F32_TOL,
+                                       err_msg=tag + " state")
+            if (t + 1) in maps:
+                np.testing.assert_allclose(env.raw()["prob"][0].cpu().numpy(), maps[t + 1], rtol=0, atol=F32_TOL,
+                                           err_msg=tag + " prob_map")
+                np.testing.assert_array_equal(env.get_obs()[0, 0, :-4].cpu().numpy(),
+                                              env.raw()["prob"][0].cpu().numpy().reshape(-1))
+
+
+def compare_with_oracle(env, ob, B, n, m, tag, check_pos=True):
+    h = hdr(env)
+    raw = env.raw()
+    ag = raw["agent"][:, :n].cpu().numpy()
+    tg = raw["tgt"][:, :m].cpu().numpy()
+    for b in range(B):
+        oe = ob.env(b)
+        c = oe.counters()
+        pos, yaw, out = oe.agents()
+        tp, found = oe.targets()
+        assert h[b, _lib.H_TARGET_FIND] == c["target_find"], f"{tag} env {b} target_find"
+        assert h[b, _lib.H_TIME_STEP] == c["time_step"], f"{tag} env {b} time_step"
+        assert h[b, _lib.H_TOTAL_REWARD] == c["total_reward"], f"{tag} env {b} total_reward"
+        assert (h[b, _lib.H_FLAGS] & 1) == c["win"], f"{tag} env {b} win"
+        assert [(h[b, _lib.H_FOUND] >> j) & 1 for j in range(m)] == list(found), f"{tag} env {b} found"
+        assert [(h[b, _lib.H_FLAGS] >> (8 + i)) & 1 for i in range(n)] == list(out), f"{tag} env {b} out"
+        assert int(words(h)[b]) == oe.words_consumed(), f"{tag} env {b} MT words consumed"
+        if check_pos:
+            np.testing.assert_array_equal(ag[b, :, :2], pos, err_msg=f"{tag} env {b} pos")
+            np.testing.assert_array_equal(ag[b, :, 2], yaw, err_msg=f"{tag} env {b} yaw")
+            np.testing.assert_allclose(tg[b], tp, rtol=0, atol=1e-12, err_msg=f"{tag} env {b} targets")
+
+
+@pytest.mark.parametrize("variant,n,agent_mode,target_mode,B,T", [
+    ("flight_easy", 3, 0, 0, 512, 200),
+    ("flight_easy", 5, 0, 0, 256, 200),
+    ("flight_easy", 3, 3, 0, 128, 120),
+    ("flight_easy", 3, 2, 1, 128, 120),
+    ("flight_easy", 1, 1, 0, 64, 200),
+    ("flight_easy", 8, 0, 0, 64, 100),
+    ("flight_easy", 2, 1, 0, 64, 100),
+])
+def test_batched_step_matches_oracle_bit_exact(variant, n, agent_mode, target_mode, B, T):
+    """Frozen-when-done batch against B oracle envs, every step: outputs exact, raw state bit-identical."""
+    m = 15
+    seeds = (777 + 13 * np.arange(B)).astype(np.uint32)
+    args = cs.make_env_args(variant, n_agents=n, agent_mode=agent_mode, target_mode=target_mode)
+    env = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, freeze_done=True)
+    cfg = orc.make_config(variant=variant, n_agents=n, agent_mode=agent_mode, target_mode=target_mode)
+    rng = np.random.RandomState(n * 100 + agent_mode)
+    with orc.hip_equivalent_arithmetic():
+        ob = orc.OracleBatch(cfg, B, seeds)
+        ob.reset(init=True, threads=8)
+        compare_with_oracle(env, ob, B, n, m, "reset")
+        for t in range(T):
+            a = rng.randint(0, 3, size=(B, n)).astype(np.int32)
+            r, term, win = env.step(torch.from_numpy(a))
+            orr, ot, ow = ob.step(a, freeze_done=True, threads=8)
+            np.testing.assert_array_equal(r.cpu().numpy(), orr, err_msg=f"reward step {t}")
+            np.testing.assert_array_equal(term.cpu().numpy().astype(np.uint8), ot, err_msg=f"terminated step {t}")
+            np.testing.assert_array_equal(win.cpu().numpy().astype(np.uint8), ow, err_msg=f"win step {t}")
+            np.testing.assert_allclose(env.get_obs().cpu().numpy(), ob.obs, rtol=0, atol=F32_TOL)
+            np.testing.assert_allclose(env.get_state().cpu().numpy(), ob.state, rtol=0, atol=F32_TOL)
+            if t % 25 == 24 or t == T - 1:
+                compare_with_oracle(env, ob, B, n, m, f"step {t}")
+
+
+def test_auto_reset_and_unfrozen_modes_match_oracle():
+    B, n, m, T = 128, 5, 15, 420   # > 2 episodes per env
+    seeds = np.arange(B, dtype=np.uint32) + 5
+    args = cs.make_env_args("flight_easy", n_agents=n)
+    cfg = orc.make_config(n_agents=n)
+    for mode in ("auto_reset", "unfrozen"):
+        env = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, freeze_done=False, auto_reset=(mode == "auto_reset"))
+        rng = np.random.RandomState(9)
+        with orc.hip_equivalent_arithmetic():
+            ob = orc.OracleBatch(cfg, B, seeds)
+            ob.reset(init=True, threads=8)
+            for t in range(T if mode == "auto_reset" else 230):
+                a = rng.randint(0, 3, size=(B, n)).astype(np.int64)   # int64 actions path
+                r, term, win = env.step(torch.from_numpy(a))
+                orr, ot, ow = ob.step(a, auto_reset=(mode == "auto_reset"), freeze_done=False, threads=8)
+                np.testing.assert_array_equal(r.cpu().numpy(), orr, err_msg=f"{mode} reward step {t}")
+                np.testing.assert_array_equal(term.cpu().numpy().astype(np.uint8), ot)
+                np.testing.assert_array_equal(win.cpu().numpy().astype(np.uint8), ow)
+            compare_with_oracle(env, ob, B, n, m, mode)
+            if mode == "auto_reset":
+                assert hdr(env)[:, _lib.H_EPISODES].min() >= 3
+
+
+@pytest.mark.parametrize("n,agent_mode,B,T", [(3, 0, 48, 90), (5, 2, 16, 60), (3, 3, 16, 40)])
+def test_flight_prob_map_matches_oracle(n, agent_mode, B, T):
+    m = 15
+    seeds = np.arange(B, dtype=np.uint32) + 31
+    args = cs.make_env_args("flight", n_agents=n, agent_mode=agent_mode)
+    env = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, freeze_done=True)
+    cfg = orc.make_config(variant="flight", n_agents=n, agent_mode=agent_mode)
+    rng = np.random.RandomState(3)
+    with orc.hip_equivalent_arithmetic():
+        ob = orc.OracleBatch(cfg, B, seeds)
+        ob.reset(init=True, threads=8)
+        for t in range(T):
+            a = rng.randint(0, 3, size=(B, n)).astype(np.int32)
+            r, term, win = env.step(torch.from_numpy(a))
+            orr, ot, ow = ob.step(a, freeze_done=True, threads=8)
+            np.testing.assert_array_equal(r.cpu().numpy(), orr, err_msg=f"reward step {t}")
+            np.testing.assert_array_equal(term.cpu().numpy().astype(np.uint8), ot)
+            if t % 10 == 9 or t == T - 1:
+                np.testing.assert_allclose(env.get_obs().cpu().numpy(), ob.obs, rtol=0, atol=F32_TOL,
+                                           err_msg=f"obs (map + feats) step {t}")
+                np.testing.assert_allclose(env.get_state().cpu().numpy(), ob.state, rtol=0, atol=F32_TOL)
+        compare_with_oracle(env, ob, B, n, m, "flight final")
+        # second episode without init: the map persists (quirk Q9)
+        env.reset(init=False)
+        ob.reset(init=False, threads=8)
+        for t in range(15):
+            a = rng.randint(0, 3, size=(B, n)).astype(np.int32)
+            env.step(torch.from_numpy(a))
+            ob.step(a, freeze_done=True, threads=8)
+        np.testing.assert_allclose(env.get_obs().cpu().numpy(), ob.obs, rtol=0, atol=F32_TOL)
+        pm = env.raw()["prob"].cpu().numpy()
+        assert (pm != 0.5).any()
+
+
+def test_rollout_kernel_equals_stepwise():
+    B, n, T = 1024, 3, 200
+    args = cs.make_env_args("flight_easy", n_agents=n)
+    seeds = np.arange(B, dtype=np.uint32) + 99
+    acts = torch.randint(0, 3, (T, B, n), dtype=torch.int32, device="cuda", generator=torch.Generator("cuda").manual_seed(1))
+    for kw in (dict(freeze_done=True), dict(freeze_done=False, auto_reset=True)):
+        e1 = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, **kw)
+        e2 = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, **kw)
+        out = e2.rollout(acts)
+        for t in range(T):
+            r, term, win = e1.step(acts[t])
+            assert torch.equal(r, out["reward"][t]) and torch.equal(term, out["terminated"][t]) and torch.equal(win, out["win"][t])
+            if t % 40 == 0 or t == T - 1:
+                assert torch.equal(e1.get_obs(), out["obs"][t]) and torch.equal(e1.get_state(), out["state"][t])
+        for k in ("tgt", "agent", "hdr", "mt"):
+            assert torch.equal(e1.raw()[k], e2.raw()[k]), k
+
+
+@pytest.mark.parametrize("n,B", [(3, 4096), (5, 16384)])
+def test_full_size_properties_and_shard_invariance(n, B):
+    """BASELINE configs 2/3 at full size: domain invariants + bit-exact shard invariance (rank-local halves with
+    env_offset reproduce the single-device batch)."""
+    T = 200
+    args = cs.make_env_args("flight_easy", n_agents=n)
+    whole = cs.BatchedFlightEnv(args, batch=B)
+    half = B // 2
+    parts = [cs.BatchedFlightEnv(args, batch=half, env_offset=0), cs.BatchedFlightEnv(args, batch=half, env_offset=half)]
+    g = torch.Generator("cuda").manual_seed(7)
+    last_find = torch.zeros(B, dtype=torch.int32, device="cuda")
+    tot = torch.zeros(B, dtype=torch.float64, device="cuda")
+    for t in range(T):
+        a = torch.randint(0, 3, (B, n), dtype=torch.int32, device="cuda", generator=g)
+        r, term, win = whole.step(a)
+        assert torch.equal(r, r.round()) and (r >= -1 - n).all() and (r <= -1 + 10 * 15 + 100).all()
+        tf = whole.target_find
+        assert (tf >= last_find).all() and (tf <= 15).all()
+        last_find = tf.clone()
+        tot += r.double()
+        ag = whole.raw()["agent"][:, :n]
+        assert (ag[:, :, :2] >= 0).all() and (ag[:, :, :2] <= 50).all()
+        assert (ag[:, :, 2] >= 0).all() and (ag[:, :, 2] <= 2 * np.pi).all()
+        assert torch.equal(term, (tf >= 15) | (whole.time_step >= 200))
+        assert torch.equal(win, whole.win_flag) and (~win | (tf == 15)).all()
+        for k, pe in enumerate(parts):
+            rr, tt, ww = pe.step(a[k * half:(k + 1) * half])
+            assert torch.equal(rr, r[k * half:(k + 1) * half]) and torch.equal(tt, term[k * half:(k + 1) * half])
+    assert torch.equal(tot, whole.total_reward.double())
+    for k, pe in enumerate(parts):
+        for key in ("tgt", "agent", "hdr", "mt"):
+            assert torch.equal(pe.raw()[key], whole.raw()[key][k * half:(k + 1) * half]), key
+    assert whole.get_state().abs().max() <= 1.5
+    mp = whole.metric_partials().cpu().numpy()
+    h = hdr(whole)
+    assert mp[3] == B and mp[0] == h[:, _lib.H_TOTAL_REWARD].sum() and mp[2] == h[:, _lib.H_TARGET_FIND].sum()
+    assert mp[1] == (h[:, _lib.H_FLAGS] & 1).sum()
+    # statistical pin shipped by the reference (result/flight_easy_Seed0_random_{3,5}a15t(AM0TM0)/average_res_529.npy,
+    # BASELINE.md section 1): % of targets found after 200 random steps, 84.87 (3 agents) / 95.80 (5 agents)
+    found_pct = 100.0 * whole.target_find.double().mean().item() / 15.0
+    assert abs(found_pct - {3: 84.87, 5: 95.80}[n]) < 3.0, found_pct
+
+
+def test_flight_full_size_smoke_properties():
+    """BASELINE config 4 (flight, 3 agents, B = 8192): map values stay in [0, 1], untouched cells stay 0.5,
+    the obs rows replicate the map, reward bounds hold."""
+    B, n = 8192, 3
+    env = cs.BatchedFlightEnv(cs.make_env_args("flight", n_agents=n), batch=B)
+    g = torch.Generator("cuda").manual_seed(11)
+    for t in range(30):
+        a = torch.randint(0, 3, (B, n), dtype=torch.int32, device="cuda", generator=g)
+        r, term, win = env.step(a)
+    pm = env.raw()["prob"]
+    assert (pm >= 0).all() and (pm <= 1).all()
+    assert (pm[:, :, 45:] == 0.5).float().mean() > 0.5   # far corner strip is rarely visited in 30 steps from y = 0
+    obs = env.get_obs()
+    for i in range(n):
+        assert torch.equal(obs[:, i, :2500], pm.reshape(B, 2500))
+    assert torch.equal(obs[:, :, 2500:], env.get_state()[:, :4 * n].reshape(B, n, 4))
+
+
+def test_b1_adapter_runs_a_rollout_shaped_loop():
+    """BASELINE config 1: the reference-typed B = 1 adapter driven like common/rollout.py:43-76."""
+    meta, z = load_trace("easy_n3_am0_s0_a1")
+    args = cs.make_env_args("flight_easy", n_agents=3)
+    env = cs.FlightSearchEnvEasy(args, cs.load_targets(), seed=meta["seed"])
+    info = env.get_env_info()
+    assert info == {"n_actions": 3, "state_shape": 57, "obs_shape": 4, "episode_limit": 200}
+    env.seed(meta["seed"])
+    env.reset()
+    terminated, step, episode_reward = False, 0, 0
+    while not terminated and step < info["episode_limit"]:
+        obs, state = env.get_obs(), env.get_state()
+        assert obs.dtype == np.float64 and obs.shape == (3, 4) and state.shape == (57,)
+        acts = []
+        for agent_id in range(3):
+            avail = env.get_avail_agent_actions(agent_id)
+            assert avail.tolist() == [1.0, 1.0, 1.0]
+            acts.append(torch.tensor(int(z["e0_actions"][step][agent_id])))   # 0-dim LongTensor like torch.argmax
+        reward, terminated, info_win = env.step(acts)
+        assert isinstance(reward, int) and isinstance(terminated, bool) and isinstance(info_win, bool)
+        assert reward == int(z["e0_reward"][step])
+        episode_reward += reward
+        step += 1
+    assert (step, episode_reward, env.target_find) == (200, -470, 8)
+    with pytest.raises(Exception, match="Act num mismatch agent"):
+        env.step([0, 1])
+    with pytest.raises(Exception, match="Agent id out of range"):
+        env.get_avail_agent_actions(3)
