@@ -45,6 +45,7 @@ def test_hip_replays_reference_golden_trace(name):
     n, m = meta["n_agents"], 15
     flight = meta["env"] == "flight"
     env = make_env(meta, batch=1, seeds=[meta["seed"]], freeze_done=False)
+    env.seed([meta["seed"]])   # golden protocol: the ctor's reset ate RNG; np.random.seed(seed) comes after it
     for e, ep in enumerate(meta["episodes"]):
         p = f"e{e}_"
         env.reset(init=ep["init"])
@@ -142,6 +143,8 @@ def test_batched_step_matches_oracle_bit_exact(variant, n, agent_mode, target_mo
     seeds = (777 + 13 * np.arange(B)).astype(np.uint32)
     args = cs.make_env_args(variant, n_agents=n, agent_mode=agent_mode, target_mode=target_mode)
     env = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, freeze_done=True)
+    env.seed(seeds)
+    env.reset(init=True)
     cfg = orc.make_config(variant=variant, n_agents=n, agent_mode=agent_mode, target_mode=target_mode)
     rng = np.random.RandomState(n * 100 + agent_mode)
     with orc.hip_equivalent_arithmetic():
@@ -168,6 +171,8 @@ def test_auto_reset_and_unfrozen_modes_match_oracle():
     cfg = orc.make_config(n_agents=n)
     for mode in ("auto_reset", "unfrozen"):
         env = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, freeze_done=False, auto_reset=(mode == "auto_reset"))
+        env.seed(seeds)
+        env.reset(init=True)
         rng = np.random.RandomState(9)
         with orc.hip_equivalent_arithmetic():
             ob = orc.OracleBatch(cfg, B, seeds)
@@ -190,6 +195,8 @@ def test_flight_prob_map_matches_oracle(n, agent_mode, B, T):
     seeds = np.arange(B, dtype=np.uint32) + 31
     args = cs.make_env_args("flight", n_agents=n, agent_mode=agent_mode)
     env = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, freeze_done=True)
+    env.seed(seeds)
+    env.reset(init=True)
     cfg = orc.make_config(variant="flight", n_agents=n, agent_mode=agent_mode)
     rng = np.random.RandomState(3)
     with orc.hip_equivalent_arithmetic():
