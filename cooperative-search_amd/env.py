@@ -209,31 +209,40 @@ class BatchedFlightEnv:
                                    self._obs.data_ptr(), self._state.data_ptr(), self._stream()))
         return self._reward, self._terminated.view(torch.bool), self._win.view(torch.bool)
 
-    def rollout(self, actions, emit=True):
-        """T steps in one launch (flight_easy): actions [T, B, n] -> dict of [T, B, ...] tensors."""
+    def rollout(self, actions, emit=True, out=None, update_views=True):
+        """T steps in one launch (flight_easy): actions [T, B, n] -> dict of [T, B, ...] tensors.
+        `out` reuses caller buffers (keys reward/terminated/win/obs/state); update_views=False skips refreshing
+        the live get_obs()/get_state() buffers afterwards (they then lag until the next step/refresh)."""
         if self.flight:
             raise Exception("rollout: flight_easy only")
         T = int(actions.shape[0])
         a = self._actions(actions, (T, self.batch))
         B, n = self.batch, self.n_agents
-        out = dict(
-            reward=torch.empty(T, B, dtype=torch.float32, device=self.device),
-            terminated=torch.empty(T, B, dtype=torch.uint8, device=self.device),
-            win=torch.empty(T, B, dtype=torch.uint8, device=self.device),
-            obs=torch.empty(T, B, n, 4, dtype=torch.float32, device=self.device) if emit else None,
-            state=torch.empty(T, B, self.state_shape, dtype=torch.float32, device=self.device) if emit else None,
-        )
+        if out is None:
+            out = dict(
+                reward=torch.empty(T, B, dtype=torch.float32, device=self.device),
+                terminated=torch.empty(T, B, dtype=torch.uint8, device=self.device),
+                win=torch.empty(T, B, dtype=torch.uint8, device=self.device),
+                obs=torch.empty(T, B, n, 4, dtype=torch.float32, device=self.device) if emit else None,
+                state=torch.empty(T, B, self.state_shape, dtype=torch.float32, device=self.device) if emit else None,
+            )
+        else:
+            emit = out.get("obs") is not None and out.get("state") is not None
+            out = dict(out)
+        term = out["terminated"].view(torch.uint8)
+        win = out["win"].view(torch.uint8)
         _lib.check(self._L.cs_rollout(self._cfgp, self._blob.data_ptr(), a.data_ptr(), T, self._flags(a),
-                                      out["reward"].data_ptr(), out["terminated"].data_ptr(), out["win"].data_ptr(),
+                                      out["reward"].data_ptr(), term.data_ptr(), win.data_ptr(),
                                       out["obs"].data_ptr() if emit else None,
                                       out["state"].data_ptr() if emit else None, self._stream()))
-        if emit:
-            self._obs.copy_(out["obs"][-1])
-            self._state.copy_(out["state"][-1])
-        else:
-            self.refresh()
-        out["terminated"] = out["terminated"].view(torch.bool)
-        out["win"] = out["win"].view(torch.bool)
+        if update_views:
+            if emit:
+                self._obs.copy_(out["obs"][-1])
+                self._state.copy_(out["state"][-1])
+            else:
+                self.refresh()
+        out["terminated"] = term.view(torch.bool)
+        out["win"] = win.view(torch.bool)
         return out
 
     def refresh(self):
