@@ -29,7 +29,7 @@ constexpr int BLOCK = 256;   // 4 wavefronts, 16 environments
 constexpr int MT_N = 624;
 constexpr int MT_M = 397;
 constexpr int TRIG_ROWS = 37, TRIG_COLS = 7;
-constexpr int FLAG_WIN = 1, FLAG_DIRTY = 2;
+constexpr int FLAG_WIN = 1, FLAG_DIRTY = 2, FLAG_RESET_PASS = 4;
 
 // {A_hi, A_lo, A_lo2, S_hi, S_lo, C_hi, C_lo} for A = k*pi/18 (gen_trig_table.py)
 __device__ const double g_trig[TRIG_ROWS][TRIG_COLS] = {
@@ -38,7 +38,7 @@ __device__ const double g_trig[TRIG_ROWS][TRIG_COLS] = {
 
 struct DevParams {
     int B, n_targets, map_size, cells, time_limit, agent_mode, target_mode, variant;
-    double velocity, force_k, force_d2, view_r2, L, q;
+    double velocity, force_k, force_d2, view_r2, L, q, mid, inv_half;
     unsigned long long detect_K;  // U <= detect_prob  <=>  53-bit integer draw <= floor(detect_prob * 2^53)
     double tx0[CS_MAX_TARGETS], ty0[CS_MAX_TARGETS], jx2[CS_MAX_TARGETS], jy2[CS_MAX_TARGETS];
     unsigned deter_mask;
@@ -125,13 +125,17 @@ __device__ __forceinline__ void trig_heading(const double *T, double yaw, double
     double bb = dh - t;
     double err = (t - (dh - bb)) + ((-r[1]) - bb);  // TwoSum tail
     double dl = err - r[2];
-    if (fabs(dh) > 1e-6) {  // off-grid heading injected through the raw state: generic path
-        s = sin(yaw);
-        c = cos(yaw);
-        return;
-    }
     s = r[3] + ((r[4] + dh * (r[5] - 0.5 * dh * r[3])) + dl * r[5]);
     c = r[5] + ((r[6] - dh * (r[3] + 0.5 * dh * r[5])) - dl * r[3]);
+    if (fabs(dh) > 1e-6) {
+        // off-grid heading (only reachable by editing the raw state; |dh| <= pi/36): angle-addition about the
+        // nearest grid heading with Taylor series in dh, ~1 ulp
+        const double d2 = dh * dh;
+        const double sd = dh * (1.0 + d2 * (-1.0 / 6 + d2 * (1.0 / 120 + d2 * (-1.0 / 5040 + d2 * (1.0 / 362880)))));
+        const double cd = 1.0 + d2 * (-0.5 + d2 * (1.0 / 24 + d2 * (-1.0 / 720 + d2 * (1.0 / 40320 + d2 * (-1.0 / 3628800)))));
+        s = r[3] * cd + r[5] * sd;
+        c = r[5] * cd - r[3] * sd;
+    }
 }
 
 __device__ __forceinline__ void load_trig_to_lds(double *T) {
@@ -146,10 +150,30 @@ template <int N>
 struct Env {
     double ax[N], ay[N], yaw[N], cs[N], sn[N];  // cs/sn: cos/sin of the CURRENT yaw (what get_obs emits)
     double tx, ty;                               // this lane's target
-    unsigned found, newly;                       // bit masks over targets
+    float ntx, nty;                              // its normalised coordinates as get_state emits them
+    unsigned found, newly, newly_reset;          // bit masks over targets
     int target_find, flags, time_step, total_reward, mt_pos, episodes, curr_reward;
     unsigned long long words;
 };
+
+template <int N>
+__device__ __forceinline__ void norm_target(const DevParams &p, Env<N> &e) {
+    // (t - 0.5*map_size)/(map_size/2), flight_env_easy.py:211; fp32 output, so the fp64 quotient is replaced by a
+    // product with the reciprocal (differs from the quotient's fp32 rounding in ~1e-9 of cases, tolerance 1e-6)
+    e.ntx = (float)((e.tx - p.mid) * p.inv_half);
+    e.nty = (float)((e.ty - p.mid) * p.inv_half);
+}
+
+// The group's window into the circular MT19937 state: lane l holds words pos+l and pos+397+l.
+struct MtWin {
+    unsigned cur, far;
+};
+__device__ __forceinline__ MtWin mt_prefetch(const unsigned *mt, int pos, int l) {
+    MtWin w;
+    w.cur = mt[wrap624(pos + l)];
+    w.far = mt[wrap624(wrap624(pos + MT_M) + l)];
+    return w;
+}
 
 template <int N>
 __device__ __forceinline__ void env_trig(const double *T, Env<N> &e) {
@@ -171,6 +195,7 @@ __device__ __forceinline__ void env_load(const DevParams &p, int b, int t, Env<N
     e.episodes = h1.w;
     e.words = (unsigned long long)(unsigned)h2.x | ((unsigned long long)(unsigned)h2.y << 32);
     e.curr_reward = h2.z;
+    e.newly_reset = (unsigned)h2.w;
     const double4 *a4 = reinterpret_cast<const double4 *>(p.agent + (size_t)b * CS_MAX_AGENTS * 4);
 #pragma unroll
     for (int i = 0; i < N; i++) {
@@ -185,6 +210,7 @@ __device__ __forceinline__ void env_load(const DevParams &p, int b, int t, Env<N
     double2 tt = t2[t];
     e.tx = tt.x;
     e.ty = tt.y;
+    norm_target(p, e);
 }
 
 template <int N>
@@ -193,7 +219,8 @@ __device__ __forceinline__ void env_store(const DevParams &p, int b, int t, cons
         int4 *h4 = reinterpret_cast<int4 *>(p.hdr + (size_t)b * CS_H_WORDS);
         h4[0] = make_int4((int)e.found, (int)e.newly, e.target_find, e.flags);
         h4[1] = make_int4(e.time_step, e.total_reward, e.mt_pos, e.episodes);
-        h4[2] = make_int4((int)(unsigned)(e.words & 0xffffffffull), (int)(unsigned)(e.words >> 32), e.curr_reward, 0);
+        h4[2] = make_int4((int)(unsigned)(e.words & 0xffffffffull), (int)(unsigned)(e.words >> 32), e.curr_reward,
+                          (int)e.newly_reset);
     }
     double4 *a4 = reinterpret_cast<double4 *>(p.agent + (size_t)b * CS_MAX_AGENTS * 4);
 #pragma unroll
@@ -207,10 +234,19 @@ __device__ __forceinline__ void env_store(const DevParams &p, int b, int t, cons
 
 // ---------------------------------------------------------------------------------------------------------
 // Detection pass + reward: flight_env_easy.py:223-253 (_update_obs), flight_env.py:232-266.
-// Returns curr_reward.  gshift = 16 * (group index inside the wavefront).
+// Returns curr_reward.  gshift = 16 * (group index inside the wavefront); win = the group's prefetched window
+// at e.mt_pos.
+//
+// One np.random.rand() is consumed per in-range (agent, target) pair, found or not (quirk Q4), in agent-major
+// order: a wavefront ballot gives the in-range mask, a prefix popcount of the group's 16-bit slice gives each
+// pair its rank r, i.e. stream words pos+2r and pos+2r+1.  Circular MT19937: word k is rebuilt from words k,
+// k+1 and k+397 (== k-227), so the <= 2*n*m <= 226 words of one pass (n <= 7; n = 8 draws in two halves on the
+// slow path) can all be rebuilt from the state as it stood before the pass.  Lane l rebuilds word l of the
+// window once; ranks 0..6 are served by two wave shuffles each, and the consumed prefix is committed with one
+// coalesced store.  Ranks >= 7 (more than 7 pairs in range at once) take the direct-load path.
 // ---------------------------------------------------------------------------------------------------------
 template <int N>
-__device__ __forceinline__ int detect_pass(const DevParams &p, int b, int t, int gshift, Env<N> &e) {
+__device__ __forceinline__ int detect_pass(const DevParams &p, int b, int t, int gshift, Env<N> &e, MtWin win) {
     const bool is_tgt = t < p.n_targets;
     unsigned *mt = p.mt + (size_t)b * MT_N;
     bool inr[N];
@@ -225,42 +261,54 @@ __device__ __forceinline__ int detect_pass(const DevParams &p, int b, int t, int
         rank[i] = base + __popc(gm & below);  // agent-major order of the reference's double loop
         base += __popc(gm);
     }
-    // one np.random.rand() per in-range pair (found or not: quirk Q4).  Circular MT: word k is rebuilt from
-    // words k, k+1 and k+397 == k-227, so up to 227 consecutive words can be regenerated independently from
-    // the state as it stood before the pass: all loads first, all stores after.  n*16*2 words fit that window
-    // for n <= 7; n = 8 draws in two agent-halves.
-    constexpr int PHASES = (N * G * 2 > 226) ? 2 : 1;
-    constexpr int PER = (N + PHASES - 1) / PHASES;
+    // window words 0..14 rebuilt in lanes 0..14
+    const unsigned nxt = (unsigned)__shfl((int)win.cur, t + 1, G);
+    const unsigned nw = mt_mix(win.cur, nxt, win.far);
+    const unsigned tw = mt_temper(nw);
     bool hit = false;
 #pragma unroll
-    for (int ph = 0; ph < PHASES; ph++) {
-        unsigned w[PER][5];
+    for (int i = 0; i < N; i++) {
+        const int src = rank[i] < 7 ? 2 * rank[i] : 0;
+        const unsigned wa = (unsigned)__shfl((int)tw, src, G);
+        const unsigned wb = (unsigned)__shfl((int)tw, src + 1, G);
+        const unsigned long long u = ((unsigned long long)(wa >> 5) << 26) | (unsigned long long)(wb >> 6);
+        hit = hit || (inr[i] && rank[i] < 7 && u <= p.detect_K);  // prob <= self.detect_prob, exact in integers
+    }
+    const int fast_words = base < 7 ? 2 * base : 14;
+    if (t < fast_words) mt[wrap624(e.mt_pos + t)] = nw;
+    if (base > 7) {  // rare: direct loads for the ranks the window does not cover
+        constexpr int PHASES = (N * G * 2 > 226) ? 2 : 1;
+        constexpr int PER = (N + PHASES - 1) / PHASES;
 #pragma unroll
-        for (int k = 0; k < PER; k++) {
-            const int i = ph * PER + k;
-            if (i < N && inr[i]) {
-                int i0 = wrap624(e.mt_pos + 2 * rank[i]);
-                int i1 = wrap624(i0 + 1), i2 = wrap624(i0 + 2);
-                w[k][0] = mt[i0];
-                w[k][1] = mt[i1];
-                w[k][2] = mt[i2];
-                w[k][3] = mt[wrap624(i0 + MT_M)];
-                w[k][4] = mt[wrap624(i1 + MT_M)];
+        for (int ph = 0; ph < PHASES; ph++) {
+            unsigned w[PER][5];
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const int i = ph * PER + k;
+                if (i < N && inr[i] && rank[i] >= 7) {
+                    int i0 = wrap624(e.mt_pos + 2 * rank[i]);
+                    int i1 = wrap624(i0 + 1), i2 = wrap624(i0 + 2);
+                    w[k][0] = mt[i0];
+                    w[k][1] = mt[i1];
+                    w[k][2] = mt[i2];
+                    w[k][3] = mt[wrap624(i0 + MT_M)];
+                    w[k][4] = mt[wrap624(i1 + MT_M)];
+                }
             }
-        }
 #pragma unroll
-        for (int k = 0; k < PER; k++) {
-            const int i = ph * PER + k;
-            if (i < N && inr[i]) {
-                int i0 = wrap624(e.mt_pos + 2 * rank[i]);
-                int i1 = wrap624(i0 + 1);
-                unsigned n0 = mt_mix(w[k][0], w[k][1], w[k][3]);
-                unsigned n1 = mt_mix(w[k][1], w[k][2], w[k][4]);
-                mt[i0] = n0;
-                mt[i1] = n1;
-                unsigned long long u =
-                    ((unsigned long long)(mt_temper(n0) >> 5) << 26) | (unsigned long long)(mt_temper(n1) >> 6);
-                hit = hit || (u <= p.detect_K);  // prob <= self.detect_prob, evaluated exactly in integers
+            for (int k = 0; k < PER; k++) {
+                const int i = ph * PER + k;
+                if (i < N && inr[i] && rank[i] >= 7) {
+                    int i0 = wrap624(e.mt_pos + 2 * rank[i]);
+                    int i1 = wrap624(i0 + 1);
+                    unsigned n0 = mt_mix(w[k][0], w[k][1], w[k][3]);
+                    unsigned n1 = mt_mix(w[k][1], w[k][2], w[k][4]);
+                    mt[i0] = n0;
+                    mt[i1] = n1;
+                    unsigned long long u =
+                        ((unsigned long long)(mt_temper(n0) >> 5) << 26) | (unsigned long long)(mt_temper(n1) >> 6);
+                    hit = hit || (u <= p.detect_K);
+                }
             }
         }
     }
@@ -287,25 +335,34 @@ __device__ __forceinline__ int detect_pass(const DevParams &p, int b, int t, int
 
 // ---------------------------------------------------------------------------------------------------------
 // Kinematics: flight_env_easy.py:255-301 (_agent_step + _potential_energy_force), flight_env.py:305-355.
-// Sequential over agents (quirk Q7); every lane of the group computes the same values.
+// The reference is sequential over agents (quirk Q7: agent i is repelled from the already-moved agents j < i),
+// but only the force and the wall test carry that dependency.  Phase 1 therefore computes, for all agents at
+// once and branch-free (instruction-level parallelism instead of 2n dependent chains), the new heading, its
+// sin/cos, the unforced move, and the sin/cos of the reflected heading a wall hit would select.  Phase 2 is the
+// short sequential part: force (a rare branch with the two fp64 divisions), wall test, selects.  Every lane of
+// the group computes the same values.  Operation order per coordinate is the reference's: (x + v*cos) + f_x.
 // ---------------------------------------------------------------------------------------------------------
 template <int N, int VARIANT>
 __device__ __forceinline__ void kinematics(const DevParams &p, const double *T, const int (&act)[N], Env<N> &e) {
     const double PI = 3.141592653589793, TWO_PI = 2.0 * 3.141592653589793, THREE_PI = 3.0 * 3.141592653589793;
     const double DYAW = 3.141592653589793 / 18.0;
-    unsigned out = 0;
+    double yw[N], s1[N], c1[N], yr[N], s2[N], c2[N], xt[N], yt[N];
 #pragma unroll
     for (int i = 0; i < N; i++) {
         double yaw = e.yaw[i];
-        if (act[i] == 1) yaw += DYAW;
-        else if (act[i] == 2) yaw += -DYAW;
-        if (yaw > TWO_PI) yaw -= TWO_PI;
-        else if (yaw < 0.0) yaw += TWO_PI;
-        double s, c;
-        trig_heading(T, yaw, s, c);
+        yaw = act[i] == 1 ? yaw + DYAW : (act[i] == 2 ? yaw + -DYAW : yaw);  // dyaw = [0, pi/18, -pi/18][act]
+        yaw = yaw > TWO_PI ? yaw - TWO_PI : (yaw < 0.0 ? yaw + TWO_PI : yaw);
+        yw[i] = yaw;
+        trig_heading(T, yaw, s1[i], c1[i]);
+        yr[i] = (yaw <= PI) ? PI - yaw : THREE_PI - yaw;
+        trig_heading(T, yr[i], s2[i], c2[i]);
+        xt[i] = e.ax[i] + p.velocity * c1[i];
+        yt[i] = e.ay[i] + p.velocity * s1[i];
+    }
+    unsigned out = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
         const double x0 = e.ax[i], y0 = e.ay[i];
-        double x = x0 + p.velocity * c;
-        double y = y0 + p.velocity * s;
         double fx = 0.0, fy = 0.0;
 #pragma unroll
         for (int j = 0; j < N; j++) {
@@ -318,22 +375,16 @@ __device__ __forceinline__ void kinematics(const DevParams &p, const double *T, 
                 fy += p.force_k * (y0 - ya) / den;
             }
         }
-        x += fx;
-        y += fy;
-        bool hit = VARIANT == 1 ? (x < 0.0 || x >= p.L || y < 0.0 || y >= p.L)   // flight_env.py:328
-                                : (x < 0.0 || x > p.L || y < 0.0 || y > p.L);    // flight_env_easy.py:278
-        if (hit) {
-            x = fmin(fmax(x, 0.0), p.L);
-            y = fmin(fmax(y, 0.0), p.L);
-            yaw = (yaw <= PI) ? PI - yaw : THREE_PI - yaw;
-            trig_heading(T, yaw, s, c);
-            out |= 1u << i;
-        }
-        e.ax[i] = x;
-        e.ay[i] = y;
-        e.yaw[i] = yaw;
-        e.cs[i] = c;
-        e.sn[i] = s;
+        double x = xt[i] + fx;
+        double y = yt[i] + fy;
+        const bool hit = VARIANT == 1 ? (x < 0.0 || x >= p.L || y < 0.0 || y >= p.L)   // flight_env.py:328
+                                      : (x < 0.0 || x > p.L || y < 0.0 || y > p.L);    // flight_env_easy.py:278
+        e.ax[i] = hit ? fmin(fmax(x, 0.0), p.L) : x;
+        e.ay[i] = hit ? fmin(fmax(y, 0.0), p.L) : y;
+        e.yaw[i] = hit ? yr[i] : yw[i];
+        e.cs[i] = hit ? c2[i] : c1[i];
+        e.sn[i] = hit ? s2[i] : s1[i];
+        out |= hit ? (1u << i) : 0u;
     }
     e.flags = (e.flags & ~0xff00) | (int)(out << 8);
 }
@@ -389,6 +440,7 @@ __device__ __forceinline__ void env_reset(const DevParams &p, const double *T, i
     e.words = g.words;
     e.tx = mx;
     e.ty = my;
+    norm_target(p, e);
     e.found = 0;
     e.newly = 0;
     e.target_find = 0;
@@ -409,7 +461,7 @@ __device__ __forceinline__ void env_reset(const DevParams &p, const double *T, i
         e.yaw[i] = yaw;
         trig_heading(T, yaw, e.sn[i], e.cs[i]);
     }
-    detect_pass<N>(p, b, t, gshift, e);
+    detect_pass<N>(p, b, t, gshift, e, mt_prefetch(g.mt, e.mt_pos, t));
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -418,14 +470,13 @@ __device__ __forceinline__ void env_reset(const DevParams &p, const double *T, i
 // ---------------------------------------------------------------------------------------------------------
 template <int N>
 __device__ __forceinline__ void emit(const DevParams &p, int t, const Env<N> &e, float *obs_row, float *state_row) {
-    const double half = p.L / 2.0, mid = 0.5 * p.L;
     const int obs_w = p.variant == 1 ? p.cells + 4 : 4;
     const int feat_off = p.variant == 1 ? p.cells : 0;
 #pragma unroll
     for (int i = 0; i < N; i++) {
         if (t == i) {
-            float4 f = make_float4((float)((e.ax[i] - mid) / half), (float)((e.ay[i] - mid) / half), (float)e.cs[i],
-                                   (float)e.sn[i]);
+            float4 f = make_float4((float)((e.ax[i] - p.mid) * p.inv_half), (float)((e.ay[i] - p.mid) * p.inv_half),
+                                   (float)e.cs[i], (float)e.sn[i]);
             if (obs_row) *reinterpret_cast<float4 *>(obs_row + (size_t)i * obs_w + feat_off) = f;
             if (state_row) {
                 state_row[4 * i + 0] = f.x;
@@ -437,8 +488,8 @@ __device__ __forceinline__ void emit(const DevParams &p, int t, const Env<N> &e,
     }
     if (state_row && t < p.n_targets) {
         float *s = state_row + 4 * N + 3 * t;
-        s[0] = (float)((e.tx - mid) / half);
-        s[1] = (float)((e.ty - mid) / half);
+        s[0] = e.ntx;
+        s[1] = e.nty;
         s[2] = ((e.found >> t) & 1u) ? 1.0f : 0.0f;
     }
 }
@@ -464,23 +515,28 @@ __device__ __forceinline__ void load_actions(const StepIO &io, size_t row, int (
     }
 }
 
-// One env.step for the group's env, state in registers.  Returns through io slot `slot` (= t*B + b).
+// One env.step for the group's env, state in registers.  Results go to io slot `slot` (= step*B + b).
+// `act` are this step's actions (already loaded), `win` the MT window at e.mt_pos (already prefetched).
 template <int N, int VARIANT>
 __device__ __forceinline__ void step_once(const DevParams &p, const double *T, const StepIO &io, int b, int t,
-                                          int gshift, size_t slot, Env<N> &e) {
+                                          int gshift, size_t slot, const int (&act)[N], MtWin win, Env<N> &e) {
     bool done = e.target_find >= p.n_targets || e.time_step >= p.time_limit;
     int reward = 0;
     bool term = true;
+    e.flags &= ~(FLAG_DIRTY | FLAG_RESET_PASS);  // pending-map-update flags describe THIS launch only
     if (done && (io.flags & CS_AUTO_RESET)) {
         env_reset<N>(p, T, b, t, gshift, 0, e);
+        if (VARIANT == 1) {  // flight: the map kernel must replay the reset-time update before this step's
+            e.newly_reset = e.newly;
+            e.flags |= FLAG_RESET_PASS;
+        }
         env_store<N>(p, b, t, e, true);  // targets changed
+        win = mt_prefetch(p.mt + (size_t)b * MT_N, e.mt_pos, t);
         done = false;
     }
     if (!(done && (io.flags & CS_FREEZE_DONE))) {
-        int act[N];
-        load_actions<N>(io, slot, act);
         kinematics<N, VARIANT>(p, T, act, e);
-        reward = detect_pass<N>(p, b, t, gshift, e);
+        reward = detect_pass<N>(p, b, t, gshift, e, win);
         e.total_reward += reward;
         e.time_step += 1;
         term = e.target_find >= p.n_targets || e.time_step >= p.time_limit;
@@ -500,29 +556,52 @@ __device__ __forceinline__ void step_once(const DevParams &p, const double *T, c
 template <int N, int VARIANT>
 __global__ __launch_bounds__(BLOCK) void k_step(DevParams p, StepIO io) {
     __shared__ double T[TRIG_ROWS * TRIG_COLS];
-    load_trig_to_lds(T);
     const int gid = blockIdx.x * BLOCK + threadIdx.x;
     const int b = gid / G, t = gid % G;
-    if (b >= p.B) return;
-    const int gshift = (int)(threadIdx.x & 63) & ~15;
+    const bool live = b < p.B;
+    // issue every independent global load before the barrier that publishes the trig table
     Env<N> e;
-    env_load<N>(p, b, t, e);
-    step_once<N, VARIANT>(p, T, io, b, t, gshift, (size_t)b, e);
+    int act[N];
+    if (live) {
+        env_load<N>(p, b, t, e);
+        load_actions<N>(io, (size_t)b, act);
+    }
+    load_trig_to_lds(T);
+    if (!live) return;
+    const int gshift = (int)(threadIdx.x & 63) & ~15;
+    MtWin win = mt_prefetch(p.mt + (size_t)b * MT_N, e.mt_pos, t);
+    step_once<N, VARIANT>(p, T, io, b, t, gshift, (size_t)b, act, win, e);
     env_store<N>(p, b, t, e, false);
 }
 
-// T steps per launch, env resident in registers between steps (flight_easy).
+// T steps per launch, env resident in registers between steps (flight_easy).  The next step's actions and MT
+// window are requested before the current step's arithmetic so their latency hides behind it.
 template <int N>
 __global__ __launch_bounds__(BLOCK) void k_rollout(DevParams p, StepIO io) {
     __shared__ double T[TRIG_ROWS * TRIG_COLS];
-    load_trig_to_lds(T);
     const int gid = blockIdx.x * BLOCK + threadIdx.x;
     const int b = gid / G, t = gid % G;
-    if (b >= p.B) return;
-    const int gshift = (int)(threadIdx.x & 63) & ~15;
+    const bool live = b < p.B;
     Env<N> e;
-    env_load<N>(p, b, t, e);
-    for (int s = 0; s < io.T; s++) step_once<N, 0>(p, T, io, b, t, gshift, (size_t)s * p.B + b, e);
+    int act[N];
+    if (live) {
+        env_load<N>(p, b, t, e);
+        load_actions<N>(io, (size_t)b, act);
+    }
+    load_trig_to_lds(T);
+    if (!live) return;
+    const int gshift = (int)(threadIdx.x & 63) & ~15;
+    const unsigned *mt = p.mt + (size_t)b * MT_N;
+    MtWin win = mt_prefetch(mt, e.mt_pos, t);
+    for (int s = 0; s < io.T; s++) {
+        int act_next[N];
+        const int sn = s + 1 < io.T ? s + 1 : s;
+        load_actions<N>(io, (size_t)sn * p.B + b, act_next);
+        step_once<N, 0>(p, T, io, b, t, gshift, (size_t)s * p.B + b, act, win, e);
+        win = mt_prefetch(mt, e.mt_pos, t);
+#pragma unroll
+        for (int i = 0; i < N; i++) act[i] = act_next[i];
+    }
     env_store<N>(p, b, t, e, false);
 }
 
@@ -541,6 +620,10 @@ __global__ __launch_bounds__(BLOCK) void k_reset(DevParams p, const uint8_t *mas
         env_store<N>(p, b, t, e, true);
     } else {
         env_trig<N>(T, e);
+        if (e.flags & (FLAG_DIRTY | FLAG_RESET_PASS)) {
+            e.flags &= ~(FLAG_DIRTY | FLAG_RESET_PASS);
+            env_store<N>(p, b, t, e, false);
+        }
     }
     const size_t obs_w = (size_t)N * (p.variant == 1 ? p.cells + 4 : 4);
     const size_t st_w = (size_t)(4 * N + 3 * p.n_targets);
@@ -566,83 +649,186 @@ __global__ __launch_bounds__(BLOCK) void k_emit(DevParams p, float *obs, float *
 // flight: probability-map update (flight_env.py:275-303) fused with the map part of get_obs (:223-230).
 // One workgroup per env streams the 10 KB map once: float4 per lane, update the cells whose corners fall in a
 // sensor disc (only when the env ran a detection pass since the last call), write the map back only where it
-// changed, and write the n copies that get_obs emits.
+// changed, and write the n copies that get_obs emits.  An env that was auto-reset inside k_step carries two
+// pending passes (reset-time pass at the start positions, then the step's pass); both are applied, in order,
+// in the same sweep.
+//
+// Corner test `(x-ax)**2 + (y-ay)**2 < view_range**2` (strict, flight_env.py:300): decided in fp32 when the
+// fp32 distance is clear of the threshold by more than its error bound, in exact fp64 otherwise.
 // ---------------------------------------------------------------------------------------------------------
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// Per-pass data of one env in LDS.
+struct MapPassLds {
+    unsigned long long rowbits[CS_MAX_MAP + 2];  // bit Y of rowbits[X]: lattice point (X, Y) strictly inside a disc
+    int cells[CS_MAX_TARGETS];                   // flat cell index of each newly found target, -1 otherwise
+    int any_found;
+};
+
+// The reference's corner test, exactly: (x-ax)**2 + (y-ay)**2 < view_range**2 (flight_env.py:299-300), with dx2 =
+// (x-ax)*(x-ax) hoisted (same fp64 value).
+__device__ __forceinline__ bool corner_exact(double dx2, int yi, double ay, double r2) {
+    const double dy = (double)yi - ay;
+    return dx2 + dy * dy < r2;
+}
+
+// Lattice bitmap of one pass, built by ONE wavefront: lane X owns lattice row X (0..map_size).  For a fixed row
+// the exact predicate is monotone in |Y - ay| (fp64 rounding is monotone), so each agent covers a contiguous
+// interval [lo, hi] of columns: an fp32 sqrt gives the estimate (error << 1) and the three lattice columns around
+// each end are settled with the exact fp64 comparison.
 template <int N>
-__global__ __launch_bounds__(BLOCK) void k_map(DevParams p, float *obs) {
-    __shared__ int s_cell[CS_MAX_TARGETS];
-    __shared__ int s_dirty;
-    const int b = blockIdx.x;
-    int *hdr = p.hdr + (size_t)b * CS_H_WORDS;
-    const int flags = hdr[CS_H_FLAGS];
-    const unsigned newly = (unsigned)hdr[CS_H_NEWLY];
-    const bool dirty = flags & FLAG_DIRTY;
-    double ax[N], ay[N];
-    const double4 *a4 = reinterpret_cast<const double4 *>(p.agent + (size_t)b * CS_MAX_AGENTS * 4);
+__device__ __forceinline__ void build_rowbits(const DevParams &p, const double (&ax)[N], const double (&ay)[N], int lane,
+                                              unsigned long long *rowbits) {
+    unsigned long long bits = 0;
+    const int X = lane;
+    if (X <= p.map_size) {
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-        double4 a = a4[i];
-        ax[i] = a.x;
-        ay[i] = a.y;
-    }
-    if (threadIdx.x < CS_MAX_TARGETS) {
-        int cell = -1;
-        if (dirty && ((newly >> threadIdx.x) & 1u)) {
-            const double *tg = p.tgt + ((size_t)b * G + threadIdx.x) * 2;
-            int ix = (int)tg[0], iy = (int)tg[1];  // int(): truncation toward zero
-            ix = ix < p.map_size - 1 ? ix : p.map_size - 1;
-            iy = iy < p.map_size - 1 ? iy : p.map_size - 1;
-            cell = (ix >= 0 && iy >= 0) ? ix * p.map_size + iy : -1;
+        for (int a = 0; a < N; a++) {
+            const double dxd = (double)X - ax[a];
+            const double dx2 = dxd * dxd;
+            const float w2 = (float)(p.view_r2 - dx2);
+            if (w2 > -0.01f) {
+                const float w = sqrtf(fmaxf(w2, 0.0f));
+                const float ayf = (float)ay[a];
+                const int y0 = (int)ceilf(ayf - w), y1 = (int)floorf(ayf + w);
+                // first column of [y0-1, y0+1] and last column of [y1-1, y1+1] that pass the exact test
+                const bool l0 = corner_exact(dx2, y0 - 1, ay[a], p.view_r2), l1 = corner_exact(dx2, y0, ay[a], p.view_r2),
+                           l2 = corner_exact(dx2, y0 + 1, ay[a], p.view_r2);
+                const bool h0 = corner_exact(dx2, y1 + 1, ay[a], p.view_r2), h1 = corner_exact(dx2, y1, ay[a], p.view_r2),
+                           h2 = corner_exact(dx2, y1 - 1, ay[a], p.view_r2);
+                int lo = l0 ? y0 - 1 : (l1 ? y0 : y0 + 1);
+                int hi = h0 ? y1 + 1 : (h1 ? y1 : y1 - 1);
+                const bool any = (l0 | l1 | l2) & (h0 | h1 | h2);
+                lo = lo < 0 ? 0 : lo;
+                hi = hi > p.map_size ? p.map_size : hi;
+                if (any && lo <= hi) {
+                    const unsigned long long upto_hi = hi >= 63 ? ~0ull : ((1ull << (hi + 1)) - 1ull);
+                    bits |= upto_hi & ~((1ull << lo) - 1ull);
+                }
+            }
         }
-        s_cell[threadIdx.x] = cell;
+        rowbits[X] = bits;
     }
-    __syncthreads();
+}
+
+// flight: probability-map update (flight_env.py:275-303) fused with the map part of get_obs (:223-230).
+// Each workgroup streams its share of one env's 10 KB map once: float4 per lane, update the cells with a corner
+// in a sensor disc (only when the env ran a detection pass in the preceding k_step / k_reset), write the map back
+// only where it changed, and write the n copies that get_obs emits (write-once stream: non-temporal stores).
+// An env that was auto-reset inside k_step carries two pending passes (reset-time pass at the start positions,
+// then the step's pass); both are applied, in order, in the same sweep.
+//
+// Launch: grid (B, ceil(chunks / MAP_BLOCK)), MAP_BLOCK threads: several small workgroups per env so that a CU
+// holds many of them and one workgroup's load latency overlaps another's arithmetic and stores.  The pending-
+// update flags are written only by k_step / k_reset (set or cleared on every launch), never here, so the
+// workgroups of one env need no ordering; `apply` = 0 makes this a pure get_obs sweep (cs_emit).
+constexpr int MAP_BLOCK = 320;
+
+template <int N>
+__global__ __launch_bounds__(MAP_BLOCK) void k_map(DevParams p, float *obs, int apply) {
+    __shared__ MapPassLds s_pass[2];  // [0] reset-time pass at the start positions, [1] the step's pass
+    const int b = blockIdx.x;
+    const int *hdr = p.hdr + (size_t)b * CS_H_WORDS;
+    const int flags = apply ? hdr[CS_H_FLAGS] : 0;
+    const bool dirty = flags & FLAG_DIRTY;
+    const bool reset_pass = flags & FLAG_RESET_PASS;
+    if (!dirty && !reset_pass && !obs) return;
     float4 *m4 = reinterpret_cast<float4 *>(p.prob + (size_t)b * p.cells);
+    const int nchunks = p.cells / 4;
+    // the map load does not depend on anything below: issue it first
+    const int c_first = blockIdx.y * MAP_BLOCK + threadIdx.x;
+    float4 v_first = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c_first < nchunks) v_first = m4[c_first];
+
+    if (dirty || reset_pass) {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (wave < 2 && (wave == 0 ? dirty : reset_pass)) {  // wave 0: the step's pass, wave 1: the reset-time pass
+            const int k = 1 - wave;
+            double ax[N], ay[N];
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                if (k == 1) {
+                    const double4 a = reinterpret_cast<const double4 *>(p.agent + (size_t)b * CS_MAX_AGENTS * 4)[i];
+                    ax[i] = a.x;
+                    ay[i] = a.y;
+                } else {
+                    const double s = N != 1 ? (double)(i * p.map_size) / (double)(N - 1) : p.L / 2.0;  // flight_env.py:148-187
+                    switch (p.agent_mode) {
+                    case 0: ax[i] = s; ay[i] = 0.0; break;
+                    case 1: ax[i] = s; ay[i] = p.L / 2.0; break;
+                    case 2: ax[i] = 0.0; ay[i] = s; break;
+                    default: ax[i] = p.L; ay[i] = s; break;
+                    }
+                }
+            }
+            build_rowbits<N>(p, ax, ay, lane, s_pass[k].rowbits);
+            if (lane == 63) s_pass[k].rowbits[CS_MAX_MAP + 1] = 0;  // row map_size + 1 is read by wrapping chunks
+            if (lane < CS_MAX_TARGETS) {  // cells of the newly found targets
+                const unsigned newly = (unsigned)hdr[k == 0 ? CS_H_NEWLY_RESET : CS_H_NEWLY];
+                int cell = -1;
+                if ((newly >> lane) & 1u) {
+                    const double *tg = p.tgt + ((size_t)b * G + lane) * 2;
+                    int ix = (int)tg[0], iy = (int)tg[1];  // int(): truncation toward zero, flight_env.py:279
+                    ix = ix < p.map_size - 1 ? ix : p.map_size - 1;
+                    iy = iy < p.map_size - 1 ? iy : p.map_size - 1;
+                    cell = (ix >= 0 && iy >= 0) ? ix * p.map_size + iy : -1;
+                }
+                s_pass[k].cells[lane] = cell;
+                if (lane == 0) s_pass[k].any_found = newly != 0;
+            }
+        }
+    }
+    __syncthreads();  // uniform: dirty / reset_pass are per-workgroup values
     const size_t row_w = (size_t)p.cells + 4;
-    const double reach = sqrt(p.view_r2) + 1.0;
-    for (int c = threadIdx.x; c < p.cells / 4; c += BLOCK) {
-        float4 v = m4[c];
-        if (dirty) {
+    const float qf = (float)p.q;
+    const float inv_map = 1.0f / (float)p.map_size;
+    for (int c = c_first; c < nchunks; c += gridDim.y * MAP_BLOCK) {
+        float4 v = c == c_first ? v_first : m4[c];
+        if (dirty || reset_pass) {
             float pv[4] = {v.x, v.y, v.z, v.w};
-            bool changed = false;
+            const int cell0 = 4 * c;
+            const int ci = (int)(((float)cell0 + 0.5f) * inv_map);  // exact for cell0 < 4096
+            const int cj0 = cell0 - ci * p.map_size;
+            unsigned any = 0;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int cell = 4 * c + k;
-                const int ci = cell / p.map_size, cj = cell - ci * p.map_size;
-                bool near = false;
-#pragma unroll
-                for (int a = 0; a < N; a++)
-                    near = near || (fabs((double)ci + 0.5 - ax[a]) < reach && fabs((double)cj + 0.5 - ay[a]) < reach);
-                if (!near) continue;
-                int cnt = 0;
+            for (int k = 0; k < 2; k++) {
+                if (k == 0 ? !reset_pass : !dirty) continue;
+                const MapPassLds &m = s_pass[k];
+                const unsigned long long r0 = m.rowbits[ci], r1 = m.rowbits[ci + 1];
+                const unsigned long long r2 = m.rowbits[ci + 2 <= CS_MAX_MAP + 1 ? ci + 2 : CS_MAX_MAP + 1];
+                unsigned cnts = 0;
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    const double x = (double)(ci + (q & 1)), y = (double)(cj + (q >> 1));
-                    bool in = false;
-#pragma unroll
-                    for (int a = 0; a < N; a++) in = in || ((x - ax[a]) * (x - ax[a]) + (y - ay[a]) * (y - ay[a]) < p.view_r2);
-                    cnt += in ? 1 : 0;
+                    const bool wrap = cj0 + q >= p.map_size;  // chunk straddles two rows when map_size % 4 != 0
+                    const int yi = wrap ? cj0 + q - p.map_size : cj0 + q;
+                    const unsigned long long ra = wrap ? r1 : r0, rb = wrap ? r2 : r1;
+                    const int cnt = __popc((unsigned)((ra >> yi) & 3ull)) + __popc((unsigned)((rb >> yi) & 3ull));
+                    // percent*(1-detect_prob)*p / ((1-detect_prob)*p + (1-p)), flight_env.py:292
+                    const float upd = ((float)cnt * 0.25f) * qf * pv[q] / (qf * pv[q] + (1.0f - pv[q]));
+                    pv[q] = cnt ? upd : pv[q];
+                    cnts |= (unsigned)cnt << (4 * q);
                 }
-                if (cnt == 0) continue;
-                bool is_found_cell = false;
-                for (int j = 0; j < p.n_targets; j++) is_found_cell = is_found_cell || (s_cell[j] == cell);
-                double pr = (double)pv[k];
-                double nv = is_found_cell ? 1.0 : ((double)cnt / 4.0) * p.q * pr / (p.q * pr + (1.0 - pr));
-                pv[k] = (float)nv;
-                changed = true;
+                if (m.any_found && cnts) {  // a newly found target's cell, if in view, is set to 1 (:288-289)
+                    for (int j = 0; j < p.n_targets; j++) {
+                        const int d = m.cells[j] - cell0;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) pv[q] = (d == q && ((cnts >> (4 * q)) & 0xfu)) ? 1.0f : pv[q];
+                    }
+                }
+                any |= cnts;
             }
-            if (changed) {
+            if (any) {
                 v = make_float4(pv[0], pv[1], pv[2], pv[3]);
                 m4[c] = v;
             }
         }
         if (obs) {
+            const v4f nv = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int a = 0; a < N; a++)
-                reinterpret_cast<float4 *>(obs + ((size_t)b * N + a) * row_w)[c] = v;
+            for (int a = 0; a < N; a++)  // write-once stream: keep it out of the caches
+                __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(obs + ((size_t)b * N + a) * row_w) + c);
         }
     }
-    if (dirty && threadIdx.x == 0) hdr[CS_H_FLAGS] = flags & ~FLAG_DIRTY;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -712,6 +898,7 @@ int check_config(const cs_config *c) {
     if (c->n_targets < 1 || c->n_targets > CS_MAX_TARGETS) return fail(CS_E_CONFIG, "n_targets must be 1..16");
     if (c->map_size < 2 || c->map_size > CS_MAX_MAP) return fail(CS_E_CONFIG, "map_size must be 2..64");
     if (c->variant == 1 && (c->map_size * c->map_size) % 4 != 0) return fail(CS_E_CONFIG, "flight needs map_size^2 % 4 == 0");
+    if (c->variant == 1 && c->map_size > 62) return fail(CS_E_CONFIG, "flight needs map_size <= 62 (one u64 per lattice row)");
     if (c->agent_mode < 0 || c->agent_mode > 3) return fail(CS_E_CONFIG, "No such agent mode");
     if (c->target_mode < 0 || c->target_mode > 1) return fail(CS_E_CONFIG, "No such target mode");
     if (c->time_limit < 1) return fail(CS_E_CONFIG, "time_limit must be positive");
@@ -740,6 +927,8 @@ int make_params(const cs_config *c, void *state, DevParams *p) {
     p->force_d2 = c->force_dist * c->force_dist;
     p->view_r2 = (double)(c->view_range * c->view_range);
     p->L = (double)c->map_size;
+    p->mid = 0.5 * p->L;
+    p->inv_half = 1.0 / (p->L / 2.0);
     p->q = 1.0 - c->detect_prob;
     p->detect_K = c->detect_prob >= 1.0 ? (1ull << 53) : (unsigned long long)floor(c->detect_prob * 9007199254740992.0);
     const double a = (double)c->map_size / 10.0;  // a = self.map_size/10
@@ -767,6 +956,8 @@ int launched(const char *what) {
     }
     return CS_OK;
 }
+
+inline dim3 map_grid(const DevParams &p) { return dim3((unsigned)p.B, (unsigned)((p.cells / 4 + MAP_BLOCK - 1) / MAP_BLOCK)); }
 
 inline unsigned env_blocks(const DevParams &p) { return (unsigned)(((size_t)p.B * G + BLOCK - 1) / BLOCK); }
 
@@ -844,7 +1035,7 @@ int cs_reset(const cs_config *cfg, void *state_dev, const uint8_t *mask_dev, int
                   hipLaunchKernelGGL(k_reset<N>, dim3(env_blocks(p)), dim3(BLOCK), 0, s, p, mask_dev, init, obs_dev,
                                      state_out_dev));
     if (cfg->variant == 1) {
-        CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_map<N>, dim3(p.B), dim3(BLOCK), 0, s, p, obs_dev));
+        CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_map<N>, map_grid(p), dim3(MAP_BLOCK), 0, s, p, obs_dev, 1));
     }
     return launched("cs_reset");
 }
@@ -855,15 +1046,13 @@ int cs_step(const cs_config *cfg, void *state_dev, const void *actions_dev, int 
     int rc = make_params(cfg, state_dev, &p);
     if (rc) return rc;
     if (!actions_dev || !reward_dev || !terminated_dev || !win_dev) return fail(CS_E_ARG, "null step buffer");
-    if (cfg->variant == 1 && (flags & CS_AUTO_RESET))
-        return fail(CS_E_ARG, "flight: CS_AUTO_RESET is not fused (reset-time map update); call cs_reset with a mask");
     hipStream_t s = (hipStream_t)stream;
     StepIO io{actions_dev, reward_dev, terminated_dev, win_dev, obs_dev, state_out_dev, flags, 1};
     if (cfg->variant == 0) {
         CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL((k_step<N, 0>), dim3(env_blocks(p)), dim3(BLOCK), 0, s, p, io));
     } else {
         CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL((k_step<N, 1>), dim3(env_blocks(p)), dim3(BLOCK), 0, s, p, io));
-        CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_map<N>, dim3(p.B), dim3(BLOCK), 0, s, p, obs_dev));
+        CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_map<N>, map_grid(p), dim3(MAP_BLOCK), 0, s, p, obs_dev, 1));
     }
     return launched("cs_step");
 }
@@ -890,7 +1079,7 @@ int cs_emit(const cs_config *cfg, void *state_dev, float *obs_dev, float *state_
     CS_DISPATCH_N(cfg->n_agents,
                   hipLaunchKernelGGL(k_emit<N>, dim3(env_blocks(p)), dim3(BLOCK), 0, s, p, obs_dev, state_out_dev));
     if (cfg->variant == 1 && obs_dev) {
-        CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_map<N>, dim3(p.B), dim3(BLOCK), 0, s, p, obs_dev));
+        CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_map<N>, map_grid(p), dim3(MAP_BLOCK), 0, s, p, obs_dev, 0));
     }
     return launched("cs_emit");
 }

@@ -191,7 +191,7 @@ class BatchedFlightEnv:
         f = 0
         if self.freeze_done:
             f |= _lib.FREEZE_DONE
-        if self.auto_reset and not self.flight:
+        if self.auto_reset:
             f |= _lib.AUTO_RESET
         if actions.dtype == torch.int64:
             f |= _lib.ACTIONS_I64
@@ -201,9 +201,6 @@ class BatchedFlightEnv:
         """env.step(act_list) for every env: actions [B, n] in {0,1,2} -> (reward[B] f32, terminated[B] bool,
         win[B] bool).  The returned tensors (and get_obs/get_state) are overwritten by the next step."""
         a = self._actions(actions, (self.batch,))
-        if self.auto_reset and self.flight:
-            # the reset-time detection pass updates the map before the step's own pass: two launches
-            self.reset(init=False, mask=self._done_mask())
         _lib.check(self._L.cs_step(self._cfgp, self._blob.data_ptr(), a.data_ptr(), self._flags(a),
                                    self._reward.data_ptr(), self._terminated.data_ptr(), self._win.data_ptr(),
                                    self._obs.data_ptr(), self._state.data_ptr(), self._stream()))

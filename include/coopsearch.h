@@ -84,7 +84,8 @@ enum {
     CS_H_FOUND = 0,     /* bit j = target j found                       (Target.find, flight_env_easy.py:12) */
     CS_H_NEWLY = 1,     /* targets found by the last detection pass     (tgt_found, flight_env.py:238)       */
     CS_H_TARGET_FIND = 2, /* env.target_find                             (flight_env_easy.py:42)              */
-    CS_H_FLAGS = 3,     /* bit0 win_flag, bit1 map dirty, bits 8..15 out_flag[i]                             */
+    CS_H_FLAGS = 3,     /* bit0 win_flag, bit1 map update pending, bit2 reset-time map update pending,
+                           bits 8..15 out_flag[i]                                                            */
     CS_H_TIME_STEP = 4, /* env.time_step                                                                      */
     CS_H_TOTAL_REWARD = 5, /* env.total_reward (integer)                                                      */
     CS_H_MT_POS = 6,    /* cursor into the circular MT19937 state, 0..623                                    */
@@ -92,6 +93,7 @@ enum {
     CS_H_WORDS_LO = 8,  /* 32-bit MT outputs consumed since cs_seed (u64, lo/hi)                             */
     CS_H_WORDS_HI = 9,
     CS_H_CURR_REWARD = 10, /* env.curr_reward of the last detection pass                                     */
+    CS_H_NEWLY_RESET = 11, /* flight: targets found by the reset-time pass of a fused auto-reset              */
     CS_H_WORDS = 16
 };
 

@@ -225,6 +225,35 @@ def test_flight_prob_map_matches_oracle(n, agent_mode, B, T):
         assert (pm != 0.5).any()
 
 
+@pytest.mark.parametrize("n,agent_mode", [(3, 0), (3, 3), (5, 1)])
+def test_flight_fused_auto_reset_matches_oracle(n, agent_mode):
+    """flight + CS_AUTO_RESET: the reset-time map update (start positions) and the step's update are applied in
+    one k_map sweep; short episodes (time_limit 25) force several resets per env."""
+    B, T, m = 24, 110, 15
+    seeds = np.arange(B, dtype=np.uint32) + 77
+    args = cs.make_env_args("flight", n_agents=n, agent_mode=agent_mode)
+    args.time_limit = 25
+    env = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, freeze_done=False, auto_reset=True)
+    env.seed(seeds)
+    env.reset(init=True)
+    cfg = orc.make_config(variant="flight", n_agents=n, agent_mode=agent_mode, time_limit=25)
+    rng = np.random.RandomState(17)
+    with orc.hip_equivalent_arithmetic():
+        ob = orc.OracleBatch(cfg, B, seeds)
+        ob.reset(init=True, threads=8)
+        for t in range(T):
+            a = rng.randint(0, 3, size=(B, n)).astype(np.int32)
+            r, term, win = env.step(torch.from_numpy(a))
+            orr, ot, ow = ob.step(a, auto_reset=True, freeze_done=False, threads=8)
+            np.testing.assert_array_equal(r.cpu().numpy(), orr, err_msg=f"reward step {t}")
+            np.testing.assert_array_equal(term.cpu().numpy().astype(np.uint8), ot)
+            if t % 7 == 6 or t == T - 1:
+                np.testing.assert_allclose(env.get_obs().cpu().numpy(), ob.obs, rtol=0, atol=F32_TOL,
+                                           err_msg=f"obs (map + feats) step {t}")
+        compare_with_oracle(env, ob, B, n, m, "flight auto-reset")
+        assert hdr(env)[:, _lib.H_EPISODES].min() >= 4
+
+
 def test_rollout_kernel_equals_stepwise():
     B, n, T = 1024, 3, 200
     args = cs.make_env_args("flight_easy", n_agents=n)
