@@ -67,51 +67,50 @@ __device__ __forceinline__ unsigned mt_temper(unsigned y) {
 }
 __device__ __forceinline__ int wrap624(int v) { return v >= MT_N ? v - MT_N : v; }  // v < 2*624
 
-// Sequential consumer used by reset (polar gaussians need a data-dependent number of words).  The 16 lanes of
-// the group generate 64 candidate words at once (4 per lane, one memory round trip), all lanes consume them
-// in lock-step through a wave shuffle, and only the consumed prefix is committed back to the state.
-struct SeqGen {
-    unsigned *mt;
-    int pos, l16, wave_base, c;
-    unsigned long long words;
-    unsigned nw[4], tw[4];
+// Reset draws its random numbers 16 "attempts" at a time: lane l of the group rebuilds the four stream words
+// pos+4l .. pos+4l+3 (one memory round trip for the whole group; 64 words < 227, so they are independent of each
+// other) and turns them into the two uniforms one polar-gaussian attempt (or one uniform target) consumes.  Only
+// the prefix of the batch that the reference's sequential algorithm would have consumed is committed.
+struct AttemptBatch {
+    unsigned nw[4];
+    double u1, u2;  // np.random.rand() #2l and #2l+1 of the batch
 
-    __device__ __forceinline__ void fill() {
+    __device__ __forceinline__ void generate(const unsigned *mt, int pos, int l) {
+        const int i0 = wrap624(pos + 4 * l);
+        unsigned cur[5], far[4];
+#pragma unroll
+        for (int q = 0; q < 5; q++) cur[q] = mt[wrap624(i0 + q)];
+#pragma unroll
+        for (int q = 0; q < 4; q++) far[q] = mt[wrap624(wrap624(i0 + MT_M) + q)];
+        unsigned tw[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            int i0 = wrap624(pos + l16 + 16 * q);
-            unsigned a = mt[i0], b = mt[wrap624(i0 + 1)], f = mt[wrap624(i0 + MT_M)];
-            nw[q] = mt_mix(a, b, f);
+            nw[q] = mt_mix(cur[q], cur[q + 1], far[q]);
             tw[q] = mt_temper(nw[q]);
         }
-        c = 0;
+        // numpy random_sample: 53-bit double from two words
+        u1 = ((double)(tw[0] >> 5) * 67108864.0 + (double)(tw[1] >> 6)) / 9007199254740992.0;
+        u2 = ((double)(tw[2] >> 5) * 67108864.0 + (double)(tw[3] >> 6)) / 9007199254740992.0;
     }
-    __device__ __forceinline__ void commit(int cnt) {
+    // write back the first `words` words of the batch
+    __device__ __forceinline__ void commit(unsigned *mt, int pos, int l, int words) const {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            int j = l16 + 16 * q;
-            if (j < cnt) mt[wrap624(pos + j)] = nw[q];
-        }
-        pos = wrap624(pos + cnt);
-        words += (unsigned long long)cnt;
-    }
-    __device__ __forceinline__ unsigned next() {
-        if (c == 64) {
-            commit(64);
-            fill();
-        }
-        int q = c >> 4;
-        unsigned v = q == 0 ? tw[0] : (q == 1 ? tw[1] : (q == 2 ? tw[2] : tw[3]));
-        unsigned r = (unsigned)__shfl((int)v, wave_base + (c & 15), 64);
-        c++;
-        return r;
-    }
-    // numpy random_sample: 53-bit double from two words
-    __device__ __forceinline__ double rand() {
-        unsigned a = next() >> 5, b = next() >> 6;
-        return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+        for (int q = 0; q < 4; q++)
+            if (4 * l + q < words) mt[wrap624(wrap624(pos + 4 * l) + q)] = nw[q];
     }
 };
+
+// index of the k-th (0-based) set bit of a 16-bit mask, 16 if there is none
+__device__ __forceinline__ int kth_set_bit16(unsigned mask, int k) {
+    int sel = 16, c = 0;
+#pragma unroll
+    for (int l = 0; l < 16; l++) {
+        const bool bit = (mask >> l) & 1u;
+        sel = (bit && c == k) ? l : sel;
+        c += bit ? 1 : 0;
+    }
+    return sel;
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // Correctly rounded sin/cos of an accumulated heading (see gen_trig_table.py).  T points at the LDS copy.
@@ -400,44 +399,63 @@ __device__ __forceinline__ void env_reset(const DevParams &p, const double *T, i
         float4 *m4 = reinterpret_cast<float4 *>(p.prob + (size_t)b * p.cells);
         for (int c = t; c < p.cells / 4; c += G) m4[c] = make_float4(0.5f, 0.5f, 0.5f, 0.5f);
     }
-    SeqGen g;
-    g.mt = p.mt + (size_t)b * MT_N;
-    g.pos = e.mt_pos;
-    g.l16 = t;
-    g.wave_base = (int)(threadIdx.x & 63) & ~15;
-    g.words = e.words;
-    g.fill();
+    unsigned *mt = p.mt + (size_t)b * MT_N;
+    const unsigned tmask = p.n_targets >= 32 ? ~0u : ((1u << p.n_targets) - 1u);
     double mx = 0.0, my = 0.0;
-    for (int j = 0; j < p.n_targets; j++) {
-        double x, y;
-        if (p.target_mode == 0) {
-            x = p.tx0[j];
-            y = p.ty0[j];
-            if (!((p.deter_mask >> j) & 1u)) {
-                // two np.random.randn(): legacy polar method, second value of the pair comes out first
-                double x1, x2, r2;
-                do {
-                    x1 = 2.0 * g.rand() - 1.0;
-                    x2 = 2.0 * g.rand() - 1.0;
-                    r2 = x1 * x1 + x2 * x2;
-                } while (r2 >= 1.0 || r2 == 0.0);
-                double f = sqrt(-2.0 * log(r2) / r2);
-                double g1 = f * x2, g2 = f * x1;
-                x += p.jx2[j] * (g1 - 0.5);  // dx*2*(randn-0.5)
-                y += p.jy2[j] * (g2 - 0.5);
+    if (p.target_mode == 0) {
+        // x = a*cx (+ dx*2*(randn-0.5) for the 'f' rows), flight_env_easy.py:95-113.  np.random.randn is the legacy
+        // polar method: attempts (x1, x2) are drawn until 0 < r2 < 1; the pair's SECOND value f*x2 is returned
+        // first, f*x1 is cached for the next call -- so the j-th accepted attempt serves the j-th 'f' target.
+        double jx = 0.0, jy = 0.0;
+#pragma unroll
+        for (int j = 0; j < CS_MAX_TARGETS; j++) {  // per-lane pick from the kernel-argument tables (selects, no scratch)
+            mx = j == t ? p.tx0[j] : mx;
+            my = j == t ? p.ty0[j] : my;
+            jx = j == t ? p.jx2[j] : jx;
+            jy = j == t ? p.jy2[j] : jy;
+        }
+        const unsigned fmask = ~p.deter_mask & tmask;        // jittered targets
+        const int need_total = __popc(fmask);
+        const bool mine = (fmask >> t) & 1u;
+        const int my_rank = __popc(fmask & ((1u << t) - 1u));  // which accepted attempt is mine
+        int taken = 0;
+        while (taken < need_total) {  // group-uniform; one batch suffices ~99 % of the time for 9 jittered targets
+            AttemptBatch ab;
+            ab.generate(mt, e.mt_pos, t);
+            const double x1 = 2.0 * ab.u1 - 1.0, x2 = 2.0 * ab.u2 - 1.0;
+            const double r2 = x1 * x1 + x2 * x2;
+            const bool accept = !(r2 >= 1.0 || r2 == 0.0);
+            const double f = sqrt(-2.0 * log(accept ? r2 : 0.5) / (accept ? r2 : 0.5));
+            const double g1 = f * x2, g2 = f * x1;
+            const unsigned amask = (unsigned)((__ballot(accept) >> gshift) & 0xffffull);
+            const int have = __popc(amask);
+            const int want = need_total - taken;
+            const int k = my_rank - taken;                                  // my index within this batch's accepts
+            const int sel = kth_set_bit16(amask, (k >= 0 && k < 16) ? k : 0);
+            const double s1 = __shfl(g1, sel & 15, G), s2 = __shfl(g2, sel & 15, G);
+            if (mine && k >= 0 && k < have && k < want) {
+                mx += jx * (s1 - 0.5);  // dx*2*(randn-0.5)
+                my += jy * (s2 - 0.5);
             }
-        } else {
-            x = p.L * g.rand();
-            y = p.L * g.rand();
+            // words consumed: up to and including the attempt that supplied the last needed pair, else the batch
+            const int last = have >= want ? kth_set_bit16(amask, want - 1) : 15;
+            const int words = 4 * (last + 1);
+            ab.commit(mt, e.mt_pos, t, words);
+            e.mt_pos = wrap624(e.mt_pos + words);
+            e.words += (unsigned long long)words;
+            taken += have < want ? have : want;
         }
-        if (j == t) {
-            mx = x;
-            my = y;
-        }
+    } else {
+        // x, y = map_size*np.random.rand() per target, flight_env_easy.py:122-127
+        AttemptBatch ab;
+        ab.generate(mt, e.mt_pos, t);
+        mx = p.L * ab.u1;
+        my = p.L * ab.u2;
+        const int words = 4 * p.n_targets;
+        ab.commit(mt, e.mt_pos, t, words);
+        e.mt_pos = wrap624(e.mt_pos + words);
+        e.words += (unsigned long long)words;
     }
-    g.commit(g.c);
-    e.mt_pos = g.pos;
-    e.words = g.words;
     e.tx = mx;
     e.ty = my;
     norm_target(p, e);
@@ -461,7 +479,7 @@ __device__ __forceinline__ void env_reset(const DevParams &p, const double *T, i
         e.yaw[i] = yaw;
         trig_heading(T, yaw, e.sn[i], e.cs[i]);
     }
-    detect_pass<N>(p, b, t, gshift, e, mt_prefetch(g.mt, e.mt_pos, t));
+    detect_pass<N>(p, b, t, gshift, e, mt_prefetch(mt, e.mt_pos, t));
 }
 
 // ---------------------------------------------------------------------------------------------------------
