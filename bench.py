@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="override envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--kernel", default="auto", choices=["auto", "group", "lane"],
+                    help="flight_easy kernel: 16 lanes per env, one lane per env, or by batch size")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -137,7 +139,7 @@ def main():
     S = largest_divisor_leq(K, 100)  # steps per graph replay / per rollout launch
 
     env = cs.BatchedFlightEnv(cs.make_env_args(env_name, n_agents=n), batch=B, device=dev, env_offset=rank * B,
-                              freeze_done=False, auto_reset=True)
+                              freeze_done=False, auto_reset=True, kernel=a.kernel)
     g = torch.Generator(device=dev).manual_seed(1 + rank)
     acts = torch.randint(0, 3, (S, B, n), dtype=torch.int32, device=dev, generator=g)
 
@@ -215,7 +217,10 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get(f"{a.workload}:{mode}")
+        lane = env_name == "flight_easy" and (a.kernel == "lane" or (a.kernel == "auto" and B >= 32768))
         kernel = {"rollout": f"k_rollout<{n}>", "step": f"k_step<{n},{1 if env_name == 'flight' else 0}>"}[mode]
+        if lane:
+            kernel = f"k_rollout_lane<{n}>"
         if env_name == "flight":
             kernel += f" + k_map<{n}>"
         line = {
@@ -224,7 +229,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{env_name}, {n} agents, {m} targets, batch={B} envs per GPU, agent_mode=0, "
                                    f"target_mode=0 ({a.workload})", "mode": mode, "steps_per_launch": steps_per_launch,
-                       "auto_reset": True, "emits": "obs+state every step", "hip_graph": mode == "step" and not a.no_graph},
+                       "auto_reset": True, "emits": "obs+state every step", "kernel": a.kernel, "hip_graph": mode == "step" and not a.no_graph},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": kernel,
                          "algorithmic_bytes_per_env_step": alg, "avg_launch_us": launch_s * 1e6,

@@ -9,6 +9,7 @@ from .targets import load_targets, DEFAULT_TARGETS_FILE, default_circle_dict  # 
 from .args import get_flight_easy_args, get_flight_args, make_env_args  # noqa: F401
 from .env import BatchedFlightEnv, FlightSearchEnvEasy, FlightSearchEnv  # noqa: F401
 from . import _lib as lib  # noqa: F401
+from . import dist  # noqa: F401
 
 __all__ = ["BatchedFlightEnv", "FlightSearchEnvEasy", "FlightSearchEnv", "load_targets", "default_circle_dict",
            "get_flight_easy_args", "get_flight_args", "make_env_args", "lib"]

@@ -341,8 +341,8 @@ __device__ __forceinline__ int detect_pass(const DevParams &p, int b, int t, int
 // short sequential part: force (a rare branch with the two fp64 divisions), wall test, selects.  Every lane of
 // the group computes the same values.  Operation order per coordinate is the reference's: (x + v*cos) + f_x.
 // ---------------------------------------------------------------------------------------------------------
-template <int N, int VARIANT>
-__device__ __forceinline__ void kinematics(const DevParams &p, const double *T, const int (&act)[N], Env<N> &e) {
+template <int N, int VARIANT, class EnvT>
+__device__ __forceinline__ void kinematics(const DevParams &p, const double *T, const int (&act)[N], EnvT &e) {
     const double PI = 3.141592653589793, TWO_PI = 2.0 * 3.141592653589793, THREE_PI = 3.0 * 3.141592653589793;
     const double DYAW = 3.141592653589793 / 18.0;
     double yw[N], s1[N], c1[N], yr[N], s2[N], c2[N], xt[N], yt[N];
@@ -553,7 +553,7 @@ __device__ __forceinline__ void step_once(const DevParams &p, const double *T, c
         done = false;
     }
     if (!(done && (io.flags & CS_FREEZE_DONE))) {
-        kinematics<N, VARIANT>(p, T, act, e);
+        kinematics<N, VARIANT, Env<N>>(p, T, act, e);
         reward = detect_pass<N>(p, b, t, gshift, e, win);
         e.total_reward += reward;
         e.time_step += 1;
@@ -622,6 +622,264 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(DevParams p, StepIO io) {
     }
     env_store<N>(p, b, t, e, false);
 }
+
+// =========================================================================================================
+// Lane-per-env path (flight_easy): one environment per LANE, 64 per wavefront.
+//
+// The 16-lane-group kernels above minimise the latency of one step when the batch is small (every SIMD gets a
+// wave even at B = 4096) but replicate the kinematics 16 times.  For larger batches this path does each env's
+// arithmetic exactly once: agents AND the 16 targets live in the lane's registers, the n*m sensor tests are a
+// per-lane loop with full instruction-level parallelism, the in-range pairs are a per-lane bitmask consumed in
+// agent-major order, and get_state rows are staged through a per-wave LDS tile so the 64 rows leave as one
+// contiguous, coalesced block.  Resets (rare, data-dependent length) are done wave-cooperatively by borrowing
+// lanes 0..15 as the group of the code above.  Results are bit-identical to the group kernels (same per-env
+// arithmetic, same MT19937 word order); tests/test_gpu_parity.py runs both.
+// =========================================================================================================
+template <int N>
+struct EnvL {
+    double ax[N], ay[N], yaw[N], cs[N], sn[N];
+    double tx[CS_MAX_TARGETS], ty[CS_MAX_TARGETS];
+    unsigned found, newly, newly_reset;
+    int target_find, flags, time_step, total_reward, mt_pos, episodes, curr_reward;
+    unsigned long long words;
+};
+
+template <int N>
+__device__ __forceinline__ void envl_load(const DevParams &p, int b, const double *T, EnvL<N> &e) {
+    const int4 *h4 = reinterpret_cast<const int4 *>(p.hdr + (size_t)b * CS_H_WORDS);
+    int4 h0 = h4[0], h1 = h4[1], h2 = h4[2];
+    e.found = (unsigned)h0.x;
+    e.newly = (unsigned)h0.y;
+    e.target_find = h0.z;
+    e.flags = h0.w;
+    e.time_step = h1.x;
+    e.total_reward = h1.y;
+    e.mt_pos = h1.z;
+    e.episodes = h1.w;
+    e.words = (unsigned long long)(unsigned)h2.x | ((unsigned long long)(unsigned)h2.y << 32);
+    e.curr_reward = h2.z;
+    e.newly_reset = (unsigned)h2.w;
+    const double4 *a4 = reinterpret_cast<const double4 *>(p.agent + (size_t)b * CS_MAX_AGENTS * 4);
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        double4 a = a4[i];
+        e.ax[i] = a.x;
+        e.ay[i] = a.y;
+        e.yaw[i] = a.z;
+    }
+    const double2 *t2 = reinterpret_cast<const double2 *>(p.tgt + (size_t)b * G * 2);
+#pragma unroll
+    for (int j = 0; j < CS_MAX_TARGETS; j++) {
+        double2 tt = t2[j];
+        e.tx[j] = tt.x;
+        e.ty[j] = tt.y;
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) trig_heading(T, e.yaw[i], e.sn[i], e.cs[i]);
+}
+
+template <int N>
+__device__ __forceinline__ void envl_store(const DevParams &p, int b, const EnvL<N> &e) {
+    int4 *h4 = reinterpret_cast<int4 *>(p.hdr + (size_t)b * CS_H_WORDS);
+    h4[0] = make_int4((int)e.found, (int)e.newly, e.target_find, e.flags);
+    h4[1] = make_int4(e.time_step, e.total_reward, e.mt_pos, e.episodes);
+    h4[2] = make_int4((int)(unsigned)(e.words & 0xffffffffull), (int)(unsigned)(e.words >> 32), e.curr_reward,
+                      (int)e.newly_reset);
+    double4 *a4 = reinterpret_cast<double4 *>(p.agent + (size_t)b * CS_MAX_AGENTS * 4);
+#pragma unroll
+    for (int i = 0; i < N; i++) a4[i] = make_double4(e.ax[i], e.ay[i], e.yaw[i], 0.0);
+}
+
+// Detection pass + reward for one lane's env (same contract as detect_pass).  The in-range pairs form a bitmask
+// with bit 16*i + j for (agent i, target j): popping its set bits low-to-high IS the reference's agent-major
+// order.  Draws are served four at a time from a per-lane window of the circular MT19937 state.
+template <int N>
+__device__ __forceinline__ int detect_lane(const DevParams &p, unsigned *mt, EnvL<N> &e) {
+    const unsigned tmask = p.n_targets >= 16 ? 0xffffu : ((1u << p.n_targets) - 1u);
+    unsigned long long lo = 0, hi = 0;  // agents 0..3 / 4..7
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        unsigned m = 0;
+#pragma unroll
+        for (int j = 0; j < CS_MAX_TARGETS; j++) {
+            const double ddx = e.tx[j] - e.ax[i], ddy = e.ty[j] - e.ay[i];
+            m |= (ddx * ddx + ddy * ddy <= p.view_r2 ? 1u : 0u) << j;  // (t_x-x)**2 + (t_y-y)**2 <= view_range**2
+        }
+        m &= tmask;
+        if (i < 4) lo |= (unsigned long long)m << (16 * i);
+        else hi |= (unsigned long long)m << (16 * (i - 4));
+    }
+    const int total = __popcll(lo) + (N > 4 ? __popcll(hi) : 0);
+    unsigned hitmask = 0;
+    int pos = e.mt_pos;
+    for (int r0 = 0; r0 < total; r0 += 4) {  // one np.random.rand() per in-range pair, found or not (quirk Q4)
+        unsigned cur[9], far[8];
+#pragma unroll
+        for (int q = 0; q < 9; q++) cur[q] = mt[wrap624(pos + q)];
+        const int fpos = wrap624(pos + MT_M);
+#pragma unroll
+        for (int q = 0; q < 8; q++) far[q] = mt[wrap624(fpos + q)];
+        const int take = total - r0 < 4 ? total - r0 : 4;
+        unsigned tw[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const unsigned nw = mt_mix(cur[q], cur[q + 1], far[q]);
+            tw[q] = mt_temper(nw);
+            if (q < 2 * take) mt[wrap624(pos + q)] = nw;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (k < take) {
+                int bit;
+                if (N <= 4 || lo) {
+                    bit = __ffsll((long long)lo) - 1;
+                    lo &= lo - 1;
+                } else {
+                    bit = __ffsll((long long)hi) - 1;
+                    hi &= hi - 1;
+                }
+                const unsigned long long u = ((unsigned long long)(tw[2 * k] >> 5) << 26) | (unsigned long long)(tw[2 * k + 1] >> 6);
+                hitmask |= (u <= p.detect_K ? 1u : 0u) << (bit & 15);  // prob <= self.detect_prob, exact in integers
+            }
+        }
+        pos = wrap624(pos + 2 * take);
+    }
+    e.mt_pos = pos;
+    e.words += (unsigned long long)(2 * total);
+    const unsigned newly = hitmask & ~e.found;
+    const int cnt = __popc(newly);
+    int r = -1;     // MOVE_COST
+    r += 10 * cnt;  // FIND_ONE_TGT
+    e.found |= newly;
+    e.newly = newly;
+    e.target_find += cnt;
+    if (cnt > 0 && e.target_find == p.n_targets && !(e.flags & FLAG_WIN)) {
+        r += 100;  // FIND_ALL_TGT
+        e.flags |= FLAG_WIN;
+    }
+    r -= __popc(((unsigned)e.flags >> 8) & 0xffu);  // OUT_PUNISH
+    e.curr_reward = r;
+    e.flags |= FLAG_DIRTY;
+    return r;
+}
+
+// Rows of the per-wave staging tile: [64 lanes][W floats], W = 4n + 3m (odd for m = 15: conflict-free columns).
+template <int N>
+__device__ __forceinline__ void tile_write_targets(const DevParams &p, float *row, const EnvL<N> &e) {
+#pragma unroll
+    for (int j = 0; j < CS_MAX_TARGETS; j++) {
+        if (j < p.n_targets) {
+            row[4 * N + 3 * j + 0] = (float)((e.tx[j] - p.mid) * p.inv_half);
+            row[4 * N + 3 * j + 1] = (float)((e.ty[j] - p.mid) * p.inv_half);
+        }
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(BLOCK) void k_rollout_lane(DevParams p, StepIO io) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *T = reinterpret_cast<double *>(smem);                                   // trig table (2072 B)
+    const int W = 4 * N + 3 * p.n_targets;
+    float *tiles = reinterpret_cast<float *>(smem + ((TRIG_ROWS * TRIG_COLS * 8 + 15) / 16) * 16);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *tile = tiles + (size_t)wave * 64 * W;
+    float *row = tile + (size_t)lane * W;
+    const int b = blockIdx.x * BLOCK + threadIdx.x;
+    const int b0 = b - lane;  // first env of this wavefront
+    const bool live = b < p.B;
+    load_trig_to_lds(T);
+    if (b0 >= p.B) return;  // whole wavefront out of range
+    EnvL<N> e;
+    int act[N];
+    unsigned *mt = p.mt + (size_t)(live ? b : 0) * MT_N;
+    if (live) {
+        envl_load<N>(p, b, T, e);
+        load_actions<N>(io, (size_t)b, act);
+        tile_write_targets<N>(p, row, e);
+    }
+    const bool full_wave = b0 + 64 <= p.B;
+    for (int s = 0; s < io.T; s++) {
+        const size_t slot = (size_t)s * p.B + (live ? b : 0);
+        int act_next[N];
+        if (live) load_actions<N>(io, (size_t)(s + 1 < io.T ? s + 1 : s) * p.B + b, act_next);
+        bool done = live && (e.target_find >= p.n_targets || e.time_step >= p.time_limit);
+        // ---- auto-reset: wave-cooperative, lanes 0..15 act as the group of the resetting env -----------------
+        unsigned long long need = __ballot(done && (io.flags & CS_AUTO_RESET));
+        if (need) {
+            if ((need >> lane) & 1ull) envl_store<N>(p, b, e);  // publish cursor / counters for the helper group
+            while (need) {
+                const int src = __ffsll((long long)need) - 1;
+                need &= need - 1;
+                const int br = b0 + src;
+                if (lane < G) {
+                    Env<N> g;
+                    env_load<N>(p, br, lane, g);
+                    env_reset<N>(p, T, br, lane, 0, 0, g);
+                    env_store<N>(p, br, lane, g, true);
+                }
+            }
+            if (done && (io.flags & CS_AUTO_RESET)) {
+                envl_load<N>(p, b, T, e);
+                tile_write_targets<N>(p, row, e);
+                done = false;
+            }
+        }
+        int reward = 0;
+        bool term = true;
+        if (live) {
+            e.flags &= ~(FLAG_DIRTY | FLAG_RESET_PASS);
+            if (!(done && (io.flags & CS_FREEZE_DONE))) {
+                kinematics<N, 0, EnvL<N>>(p, T, act, e);
+                reward = detect_lane<N>(p, mt, e);
+                e.total_reward += reward;
+                e.time_step += 1;
+                term = e.target_find >= p.n_targets || e.time_step >= p.time_limit;
+            }
+            io.reward[slot] = (float)reward;
+            io.terminated[slot] = term ? 1 : 0;
+            io.win[slot] = (e.flags & FLAG_WIN) ? 1 : 0;
+            float4 f[N];
+#pragma unroll
+            for (int i = 0; i < N; i++)
+                f[i] = make_float4((float)((e.ax[i] - p.mid) * p.inv_half), (float)((e.ay[i] - p.mid) * p.inv_half),
+                                   (float)e.cs[i], (float)e.sn[i]);
+            if (io.obs) {
+                float4 *o = reinterpret_cast<float4 *>(io.obs) + slot * N;
+#pragma unroll
+                for (int i = 0; i < N; i++) o[i] = f[i];
+            }
+            if (io.state) {
+#pragma unroll
+                for (int i = 0; i < N; i++) {
+                    row[4 * i + 0] = f[i].x;
+                    row[4 * i + 1] = f[i].y;
+                    row[4 * i + 2] = f[i].z;
+                    row[4 * i + 3] = f[i].w;
+                }
+#pragma unroll
+                for (int j = 0; j < CS_MAX_TARGETS; j++)
+                    if (j < p.n_targets) row[4 * N + 3 * j + 2] = ((e.found >> j) & 1u) ? 1.0f : 0.0f;
+            }
+        }
+        if (io.state) {
+            // the wave's 64 rows are contiguous in get_state's [B][W] layout: copy the tile out as one block
+            float *dst = io.state + ((size_t)s * p.B + b0) * W;
+            const bool vec = full_wave && ((reinterpret_cast<size_t>(dst) & 15) == 0) && ((64 * W) % 4 == 0);
+            if (vec) {
+                const float4 *src4 = reinterpret_cast<const float4 *>(tile);
+                float4 *dst4 = reinterpret_cast<float4 *>(dst);
+                for (int k = lane; k < 16 * W; k += 64) dst4[k] = src4[k];
+            } else {
+                const int rows = p.B - b0 < 64 ? p.B - b0 : 64;
+                for (int k = lane; k < rows * W; k += 64) dst[k] = tile[k];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < N; i++) act[i] = act_next[i];
+    }
+    if (live) envl_store<N>(p, b, e);
+}
+
 
 template <int N>
 __global__ __launch_bounds__(BLOCK) void k_reset(DevParams p, const uint8_t *mask, int init, float *obs, float *state) {
@@ -977,6 +1235,19 @@ int launched(const char *what) {
 
 inline dim3 map_grid(const DevParams &p) { return dim3((unsigned)p.B, (unsigned)((p.cells / 4 + MAP_BLOCK - 1) / MAP_BLOCK)); }
 
+inline unsigned lane_blocks(const DevParams &p) { return (unsigned)(((size_t)p.B + BLOCK - 1) / BLOCK); }
+inline size_t lane_smem(const cs_config *c) {
+    const size_t W = 4 * (size_t)c->n_agents + 3 * (size_t)c->n_targets;
+    return ((TRIG_ROWS * TRIG_COLS * 8 + 15) / 16) * 16 + (BLOCK / 64) * 64 * W * sizeof(float);
+}
+// Kernel choice for flight_easy: one env per 16-lane group (lowest latency, fills the chip from B = 4096) or one
+// env per lane (no replicated arithmetic; wins once the batch gives every SIMD a wavefront anyway).
+inline bool use_lane_kernel(const cs_config *c, int flags) {
+    if (flags & CS_KERNEL_LANE) return true;
+    if (flags & CS_KERNEL_GROUP) return false;
+    return c->batch >= 32768;
+}
+
 inline unsigned env_blocks(const DevParams &p) { return (unsigned)(((size_t)p.B * G + BLOCK - 1) / BLOCK); }
 
 #define CS_DISPATCH_N(n, CALL)                                   \
@@ -1066,7 +1337,10 @@ int cs_step(const cs_config *cfg, void *state_dev, const void *actions_dev, int 
     if (!actions_dev || !reward_dev || !terminated_dev || !win_dev) return fail(CS_E_ARG, "null step buffer");
     hipStream_t s = (hipStream_t)stream;
     StepIO io{actions_dev, reward_dev, terminated_dev, win_dev, obs_dev, state_out_dev, flags, 1};
-    if (cfg->variant == 0) {
+    if (cfg->variant == 0 && use_lane_kernel(cfg, flags)) {
+        CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_rollout_lane<N>, dim3(lane_blocks(p)), dim3(BLOCK),
+                                                        lane_smem(cfg), s, p, io));
+    } else if (cfg->variant == 0) {
         CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL((k_step<N, 0>), dim3(env_blocks(p)), dim3(BLOCK), 0, s, p, io));
     } else {
         CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL((k_step<N, 1>), dim3(env_blocks(p)), dim3(BLOCK), 0, s, p, io));
@@ -1084,8 +1358,13 @@ int cs_rollout(const cs_config *cfg, void *state_dev, const void *actions_dev, i
     if (T < 1) return fail(CS_E_ARG, "T must be >= 1");
     if (!actions_dev || !reward_dev || !terminated_dev || !win_dev) return fail(CS_E_ARG, "null rollout buffer");
     StepIO io{actions_dev, reward_dev, terminated_dev, win_dev, obs_dev, state_out_dev, flags, T};
-    CS_DISPATCH_N(cfg->n_agents,
-                  hipLaunchKernelGGL(k_rollout<N>, dim3(env_blocks(p)), dim3(BLOCK), 0, (hipStream_t)stream, p, io));
+    if (use_lane_kernel(cfg, flags)) {
+        CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_rollout_lane<N>, dim3(lane_blocks(p)), dim3(BLOCK),
+                                                        lane_smem(cfg), (hipStream_t)stream, p, io));
+    } else {
+        CS_DISPATCH_N(cfg->n_agents,
+                      hipLaunchKernelGGL(k_rollout<N>, dim3(env_blocks(p)), dim3(BLOCK), 0, (hipStream_t)stream, p, io));
+    }
     return launched("cs_rollout");
 }
 

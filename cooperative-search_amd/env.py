@@ -60,10 +60,13 @@ class BatchedFlightEnv:
     freeze_done terminated envs ignore step() (reward 0, terminated 1); False reproduces the reference, which has
                 no terminal guard
     auto_reset  terminated envs are reset(init=False) at the start of the next step()
+    kernel      flight_easy only: "group" (16 lanes per env: lowest step latency, fills the chip from B = 4096),
+                "lane" (one env per lane: no replicated arithmetic, for large batches) or "auto" (lane from
+                B >= 32768).  Both produce bit-identical results.
     """
 
     def __init__(self, args, circle_dict=None, batch=1, device="cuda", seeds=None, env_offset=0, freeze_done=True,
-                 auto_reset=False, variant=None):
+                 auto_reset=False, variant=None, kernel="auto"):
         if not torch.cuda.is_available():
             raise RuntimeError("BatchedFlightEnv needs a GPU: the HIP path has no CPU fallback")
         self._L = _lib.load()
@@ -113,6 +116,9 @@ class BatchedFlightEnv:
             self._state = torch.zeros(B, self.state_shape, dtype=torch.float32, device=self.device)
             self._avail = torch.ones(B, self.n_actions, dtype=torch.float32, device=self.device)
             self._metrics = torch.zeros(4, dtype=torch.float64, device=self.device)
+        if kernel not in ("auto", "group", "lane"):
+            raise ValueError("kernel must be 'auto', 'group' or 'lane'")
+        self.kernel = kernel
         self.freeze_done = bool(freeze_done)
         self.auto_reset = bool(auto_reset)
         if self.freeze_done and self.auto_reset:
@@ -195,6 +201,10 @@ class BatchedFlightEnv:
             f |= _lib.AUTO_RESET
         if actions.dtype == torch.int64:
             f |= _lib.ACTIONS_I64
+        if self.kernel == "group":
+            f |= _lib.KERNEL_GROUP
+        elif self.kernel == "lane":
+            f |= _lib.KERNEL_LANE
         return f
 
     def step(self, actions):

@@ -44,7 +44,9 @@ enum {
                             (The reference has no terminal guard, flight_env_easy.py:303-314; leave this
                             flag clear to reproduce that, as the B = 1 adapter does.) */
     CS_AUTO_RESET = 2,   /* an env that was terminated on entry is reset(init=False) first, then stepped */
-    CS_ACTIONS_I64 = 4   /* actions_dev holds int64 (torch.long) instead of int32 */
+    CS_ACTIONS_I64 = 4,  /* actions_dev holds int64 (torch.long) instead of int32 */
+    CS_KERNEL_GROUP = 8, /* flight_easy: force the 16-lanes-per-env kernels (default for batch < 32768) */
+    CS_KERNEL_LANE = 16  /* flight_easy: force the lane-per-env kernel   (default for batch >= 32768); same results */
 };
 
 /* Environment constants: common/arguments.py:27-34 (map_size, target_num, target_mode, agent_mode, n_agents,
