@@ -65,6 +65,11 @@ __device__ __forceinline__ unsigned mt_temper(unsigned y) {
     y ^= (y >> 18);
     return y;
 }
+// Ends a rarely-taken branch that issued vector memory operations: with nothing left in flight on that arm, the
+// compiler's wait-count bookkeeping at the join is exactly the common path's (otherwise it drains everything --
+// including the step's own stores -- before the next use of any loaded value).
+__device__ __forceinline__ void drain_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }  // vmcnt(0), gfx9 encoding
+
 __device__ __forceinline__ int wrap624(int v) { return v >= MT_N ? v - MT_N : v; }  // v < 2*624
 
 // Reset draws its random numbers 16 "attempts" at a time: lane l of the group rebuilds the four stream words
@@ -310,6 +315,7 @@ __device__ __forceinline__ int detect_pass(const DevParams &p, int b, int t, int
                 }
             }
         }
+        drain_vmem();
     }
     e.mt_pos = wrap624(e.mt_pos + 2 * base);
     e.words += (unsigned long long)(2 * base);
@@ -383,6 +389,62 @@ __device__ __forceinline__ void kinematics(const DevParams &p, const double *T, 
         e.yaw[i] = hit ? yr[i] : yw[i];
         e.cs[i] = hit ? c2[i] : c1[i];
         e.sn[i] = hit ? s2[i] : s1[i];
+        out |= hit ? (1u << i) : 0u;
+    }
+    e.flags = (e.flags & ~0xff00) | (int)(out << 8);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Group version of phase 1: the 2n heading evaluations of a step (new heading and its wall reflection, per agent)
+// are spread over the group's lanes -- lane 2i takes agent i's heading, lane 2i+1 its reflection -- and the
+// sin/cos pairs are broadcast with wave shuffles, instead of every lane evaluating all 2n (2n <= 16 = lanes).
+// Phase 2 is the same sequential code as in kinematics().
+// ---------------------------------------------------------------------------------------------------------
+template <int N, int VARIANT>
+__device__ __forceinline__ void kinematics_group(const DevParams &p, const double *T, const int (&act)[N], int t,
+                                                 Env<N> &e) {
+    const double PI = 3.141592653589793, TWO_PI = 2.0 * 3.141592653589793, THREE_PI = 3.0 * 3.141592653589793;
+    const double DYAW = 3.141592653589793 / 18.0;
+    double yw[N], yr[N];
+    double mine = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        double yaw = e.yaw[i];
+        yaw = act[i] == 1 ? yaw + DYAW : (act[i] == 2 ? yaw + -DYAW : yaw);  // dyaw = [0, pi/18, -pi/18][act]
+        yaw = yaw > TWO_PI ? yaw - TWO_PI : (yaw < 0.0 ? yaw + TWO_PI : yaw);
+        yw[i] = yaw;
+        yr[i] = (yaw <= PI) ? PI - yaw : THREE_PI - yaw;
+        mine = t == 2 * i ? yw[i] : (t == 2 * i + 1 ? yr[i] : mine);
+    }
+    double ms, mc;
+    trig_heading(T, mine, ms, mc);
+    unsigned out = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const double s1 = __shfl(ms, 2 * i, G), c1 = __shfl(mc, 2 * i, G);
+        const double s2 = __shfl(ms, 2 * i + 1, G), c2 = __shfl(mc, 2 * i + 1, G);
+        const double x0 = e.ax[i], y0 = e.ay[i];
+        double fx = 0.0, fy = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            if (j == i) continue;
+            double xa = e.ax[j], ya = e.ay[j];  // already moved if j < i
+            double d2 = (xa - x0) * (xa - x0) + (ya - y0) * (ya - y0);
+            if (d2 < p.force_d2 && (xa != x0 || ya != y0)) {
+                double den = (x0 - xa) * (x0 - xa) + (y0 - ya) * (y0 - ya);
+                fx += p.force_k * (x0 - xa) / den;
+                fy += p.force_k * (y0 - ya) / den;
+            }
+        }
+        double x = (x0 + p.velocity * c1) + fx;
+        double y = (y0 + p.velocity * s1) + fy;
+        const bool hit = VARIANT == 1 ? (x < 0.0 || x >= p.L || y < 0.0 || y >= p.L)   // flight_env.py:328
+                                      : (x < 0.0 || x > p.L || y < 0.0 || y > p.L);    // flight_env_easy.py:278
+        e.ax[i] = hit ? fmin(fmax(x, 0.0), p.L) : x;
+        e.ay[i] = hit ? fmin(fmax(y, 0.0), p.L) : y;
+        e.yaw[i] = hit ? yr[i] : yw[i];
+        e.cs[i] = hit ? c2 : c1;
+        e.sn[i] = hit ? s2 : s1;
         out |= hit ? (1u << i) : 0u;
     }
     e.flags = (e.flags & ~0xff00) | (int)(out << 8);
@@ -512,6 +574,18 @@ __device__ __forceinline__ void emit(const DevParams &p, int t, const Env<N> &e,
     }
 }
 
+// Per-wavefront LDS staging tile for the group kernels: the 4 envs of a wavefront deposit their get_state rows,
+// obs features and step outputs here, then all 64 lanes write them out as contiguous dwords.  Every global store
+// of a step is thereby unconditional and sits in one straight-line block, so the compiler's vmcnt bookkeeping is
+// exact and a prefetched load is never waited for together with the step's own stores.
+constexpr int TILE_W = 4 * CS_MAX_AGENTS + 3 * CS_MAX_TARGETS;  // widest get_state row (80 floats)
+struct WaveTile {
+    float row[4][TILE_W];
+    float reward[4];
+    int term[4], win[4];
+    int pad[4];
+};
+
 struct StepIO {
     const void *actions;  // [T][B][N] int32 / int64
     float *reward;        // [T][B]
@@ -520,62 +594,116 @@ struct StepIO {
     int flags, T;
 };
 
+// int32 actions, or the low dword of little-endian int64 actions (values 0..2): one branch-free strided read
 template <int N>
 __device__ __forceinline__ void load_actions(const StepIO &io, size_t row, int (&act)[N]) {
-    if (io.flags & CS_ACTIONS_I64) {
-        const long long *a = reinterpret_cast<const long long *>(io.actions) + row * N;
+    const int stride = (io.flags & CS_ACTIONS_I64) ? 2 : 1;
+    const int *a = reinterpret_cast<const int *>(io.actions) + row * N * stride;
 #pragma unroll
-        for (int i = 0; i < N; i++) act[i] = (int)a[i];
-    } else {
-        const int *a = reinterpret_cast<const int *>(io.actions) + row * N;
-#pragma unroll
-        for (int i = 0; i < N; i++) act[i] = a[i];
-    }
+    for (int i = 0; i < N; i++) act[i] = a[i * stride];
 }
 
-// One env.step for the group's env, state in registers.  Results go to io slot `slot` (= step*B + b).
-// `act` are this step's actions (already loaded), `win` the MT window at e.mt_pos (already prefetched).
+// Wave-level write-out of one step (see WaveTile).  slot0 = output slot of the wavefront's first env, nvalid =
+// number of its envs that exist (1..4).  Called by all 64 lanes.
+template <int N>
+__device__ __forceinline__ void emit_wave(const DevParams &p, const StepIO &io, WaveTile &tile, int lane, int t, int grp,
+                                          bool live, const Env<N> &e, int reward, bool term, size_t slot0, int nvalid) {
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < N; i++)
+            if (t == i)
+                *reinterpret_cast<float4 *>(&tile.row[grp][4 * i]) =
+                    make_float4((float)((e.ax[i] - p.mid) * p.inv_half), (float)((e.ay[i] - p.mid) * p.inv_half),
+                                (float)e.cs[i], (float)e.sn[i]);
+        if (t < p.n_targets) {
+            tile.row[grp][4 * N + 3 * t + 0] = e.ntx;
+            tile.row[grp][4 * N + 3 * t + 1] = e.nty;
+            tile.row[grp][4 * N + 3 * t + 2] = ((e.found >> t) & 1u) ? 1.0f : 0.0f;
+        }
+        if (t == 0) {
+            tile.reward[grp] = (float)reward;
+            tile.term[grp] = term ? 1 : 0;
+            tile.win[grp] = (e.flags & FLAG_WIN) ? 1 : 0;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int W = 4 * N + 3 * p.n_targets;
+    {   // reward / terminated / win: lane -> env (lane & 3), duplicates write the same value
+        const int r = (lane & 3) < nvalid ? (lane & 3) : nvalid - 1;
+        io.reward[slot0 + r] = tile.reward[r];
+        io.terminated[slot0 + r] = (uint8_t)tile.term[r];
+        io.win[slot0 + r] = (uint8_t)tile.win[r];
+    }
+    if (io.obs) {  // one float4 per (env, agent)
+        const int l = lane < nvalid * N ? lane : nvalid * N - 1;
+        const int r = l / N, i = l - r * N;
+        const size_t obs_w = p.variant == 1 ? (size_t)p.cells + 4 : 4;
+        const size_t off = ((slot0 + r) * N + i) * obs_w + (p.variant == 1 ? p.cells : 0);
+        *reinterpret_cast<float4 *>(io.obs + off) = *reinterpret_cast<const float4 *>(&tile.row[r][4 * i]);
+    }
+    if (io.state) {  // the nvalid rows are contiguous in get_state's [B][W] layout
+        const int total = nvalid * W;
+        const float inv_w = 1.0f / (float)W;
+        float *dst = io.state + slot0 * W;
+        constexpr int K = (4 * (4 * N + 3 * CS_MAX_TARGETS) + 63) / 64;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            int idx = lane + 64 * k;
+            idx = idx < total ? idx : total - 1;
+            const int r = (int)(((float)idx + 0.5f) * inv_w);
+            dst[idx] = tile.row[r][idx - r * W];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();  // the tile is rewritten by the next step
+}
+
+// One env.step for the group's env, state in registers.  `act` are this step's actions, `win` the MT window at
+// e.mt_pos (both already loaded); called by all 64 lanes of the wavefront (`live` = the lane's env exists).
 template <int N, int VARIANT>
-__device__ __forceinline__ void step_once(const DevParams &p, const double *T, const StepIO &io, int b, int t,
-                                          int gshift, size_t slot, const int (&act)[N], MtWin win, Env<N> &e) {
-    bool done = e.target_find >= p.n_targets || e.time_step >= p.time_limit;
+__device__ __forceinline__ void step_once(const DevParams &p, const double *T, const StepIO &io, WaveTile &tile, int b,
+                                          int lane, size_t slot0, int nvalid, bool live, const int (&act)[N],
+                                          MtWin &win, bool prefetch_next, Env<N> &e) {
+    const int t = lane & (G - 1), grp = lane >> 4, gshift = lane & ~(G - 1);
     int reward = 0;
     bool term = true;
-    e.flags &= ~(FLAG_DIRTY | FLAG_RESET_PASS);  // pending-map-update flags describe THIS launch only
-    if (done && (io.flags & CS_AUTO_RESET)) {
-        env_reset<N>(p, T, b, t, gshift, 0, e);
-        if (VARIANT == 1) {  // flight: the map kernel must replay the reset-time update before this step's
-            e.newly_reset = e.newly;
-            e.flags |= FLAG_RESET_PASS;
+    if (live) {
+        bool done = e.target_find >= p.n_targets || e.time_step >= p.time_limit;
+        e.flags &= ~(FLAG_DIRTY | FLAG_RESET_PASS);  // pending-map-update flags describe THIS launch only
+        if (done && (io.flags & CS_AUTO_RESET)) {
+            env_reset<N>(p, T, b, t, gshift, 0, e);
+            if (VARIANT == 1) {  // flight: the map kernel must replay the reset-time update before this step's
+                e.newly_reset = e.newly;
+                e.flags |= FLAG_RESET_PASS;
+            }
+            env_store<N>(p, b, t, e, true);  // targets changed
+            win = mt_prefetch(p.mt + (size_t)b * MT_N, e.mt_pos, t);
+            drain_vmem();
+            done = false;
         }
-        env_store<N>(p, b, t, e, true);  // targets changed
-        win = mt_prefetch(p.mt + (size_t)b * MT_N, e.mt_pos, t);
-        done = false;
+        if (!(done && (io.flags & CS_FREEZE_DONE))) {
+            kinematics_group<N, VARIANT>(p, T, act, t, e);
+            reward = detect_pass<N>(p, b, t, gshift, e, win);
+            e.total_reward += reward;
+            e.time_step += 1;
+            term = e.target_find >= p.n_targets || e.time_step >= p.time_limit;
+        } else {
+            env_trig<N>(T, e);  // frozen env: re-emit the unchanged observation
+        }
+        // the next step's window does not overlap the words just committed: request it before this step's stores
+        if (prefetch_next) win = mt_prefetch(p.mt + (size_t)b * MT_N, e.mt_pos, t);
     }
-    if (!(done && (io.flags & CS_FREEZE_DONE))) {
-        kinematics<N, VARIANT, Env<N>>(p, T, act, e);
-        reward = detect_pass<N>(p, b, t, gshift, e, win);
-        e.total_reward += reward;
-        e.time_step += 1;
-        term = e.target_find >= p.n_targets || e.time_step >= p.time_limit;
-    } else {
-        env_trig<N>(T, e);  // frozen env: re-emit the unchanged observation
-    }
-    if (t == 0) {
-        io.reward[slot] = (float)reward;
-        io.terminated[slot] = term ? 1 : 0;
-        io.win[slot] = (e.flags & FLAG_WIN) ? 1 : 0;
-    }
-    const size_t obs_w = (size_t)N * (p.variant == 1 ? p.cells + 4 : 4);
-    const size_t st_w = (size_t)(4 * N + 3 * p.n_targets);
-    emit<N>(p, t, e, io.obs ? io.obs + slot * obs_w : nullptr, io.state ? io.state + slot * st_w : nullptr);
+    emit_wave<N>(p, io, tile, lane, t, grp, live, e, reward, term, slot0, nvalid);
 }
 
 template <int N, int VARIANT>
 __global__ __launch_bounds__(BLOCK) void k_step(DevParams p, StepIO io) {
     __shared__ double T[TRIG_ROWS * TRIG_COLS];
+    __shared__ WaveTile tiles[BLOCK / 64];
     const int gid = blockIdx.x * BLOCK + threadIdx.x;
     const int b = gid / G, t = gid % G;
+    const int lane = threadIdx.x & 63;
     const bool live = b < p.B;
     // issue every independent global load before the barrier that publishes the trig table
     Env<N> e;
@@ -585,20 +713,24 @@ __global__ __launch_bounds__(BLOCK) void k_step(DevParams p, StepIO io) {
         load_actions<N>(io, (size_t)b, act);
     }
     load_trig_to_lds(T);
-    if (!live) return;
-    const int gshift = (int)(threadIdx.x & 63) & ~15;
-    MtWin win = mt_prefetch(p.mt + (size_t)b * MT_N, e.mt_pos, t);
-    step_once<N, VARIANT>(p, T, io, b, t, gshift, (size_t)b, act, win, e);
-    env_store<N>(p, b, t, e, false);
+    const int wave_b0 = (blockIdx.x * BLOCK + (threadIdx.x & ~63)) / G;
+    if (wave_b0 >= p.B) return;
+    const int nvalid = p.B - wave_b0 < 4 ? p.B - wave_b0 : 4;
+    MtWin win = {0u, 0u};
+    if (live) win = mt_prefetch(p.mt + (size_t)b * MT_N, e.mt_pos, t);
+    step_once<N, VARIANT>(p, T, io, tiles[threadIdx.x >> 6], b, lane, (size_t)wave_b0, nvalid, live, act, win, false, e);
+    if (live) env_store<N>(p, b, t, e, false);
 }
 
 // T steps per launch, env resident in registers between steps (flight_easy).  The next step's actions and MT
-// window are requested before the current step's arithmetic so their latency hides behind it.
+// window are requested before the current step's stores so their latency hides behind the arithmetic.
 template <int N>
 __global__ __launch_bounds__(BLOCK) void k_rollout(DevParams p, StepIO io) {
     __shared__ double T[TRIG_ROWS * TRIG_COLS];
+    __shared__ WaveTile tiles[BLOCK / 64];
     const int gid = blockIdx.x * BLOCK + threadIdx.x;
     const int b = gid / G, t = gid % G;
+    const int lane = threadIdx.x & 63;
     const bool live = b < p.B;
     Env<N> e;
     int act[N];
@@ -607,20 +739,21 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(DevParams p, StepIO io) {
         load_actions<N>(io, (size_t)b, act);
     }
     load_trig_to_lds(T);
-    if (!live) return;
-    const int gshift = (int)(threadIdx.x & 63) & ~15;
-    const unsigned *mt = p.mt + (size_t)b * MT_N;
-    MtWin win = mt_prefetch(mt, e.mt_pos, t);
+    const int wave_b0 = (blockIdx.x * BLOCK + (threadIdx.x & ~63)) / G;
+    if (wave_b0 >= p.B) return;
+    const int nvalid = p.B - wave_b0 < 4 ? p.B - wave_b0 : 4;
+    WaveTile &tile = tiles[threadIdx.x >> 6];
+    MtWin win = {0u, 0u};
+    if (live) win = mt_prefetch(p.mt + (size_t)b * MT_N, e.mt_pos, t);
     for (int s = 0; s < io.T; s++) {
         int act_next[N];
         const int sn = s + 1 < io.T ? s + 1 : s;
-        load_actions<N>(io, (size_t)sn * p.B + b, act_next);
-        step_once<N, 0>(p, T, io, b, t, gshift, (size_t)s * p.B + b, act, win, e);
-        win = mt_prefetch(mt, e.mt_pos, t);
+        load_actions<N>(io, (size_t)sn * p.B + (live ? b : 0), act_next);
+        step_once<N, 0>(p, T, io, tile, b, lane, (size_t)s * p.B + wave_b0, nvalid, live, act, win, s + 1 < io.T, e);
 #pragma unroll
         for (int i = 0; i < N; i++) act[i] = act_next[i];
     }
-    env_store<N>(p, b, t, e, false);
+    if (live) env_store<N>(p, b, t, e, false);
 }
 
 // =========================================================================================================
