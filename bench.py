@@ -48,9 +48,11 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E
 def algorithmic_bytes_per_env_step(env, n, m, mode):
     """SURVEY.md section 8(d).  flight_easy, one launch per step: 61n + 22m + 22 (535 B at 3a15t, 657 B at 5a15t);
     fused T-step rollout (state resident in registers): 36n + 12m + 6 (294 B / 366 B);
-    flight: obs n*(2500+4)*4 + state 4*(4n+3m) + map read + map write (full-map streaming model) + rest."""
+    flight: obs n*(2500+4)*4 + state 4*(4n+3m) + ONE read of the 10 000-byte map + the flight_easy remainder
+    (40 535 B at 3a15t).  This is the model that matches k_map: it writes the map back only where a cell changed
+    (data dependent, not counted); SURVEY's full-map streaming model (+10 000 B write-back) would be 50 535 B."""
     if env == "flight":
-        return n * 2504 * 4 + 4 * (4 * n + 3 * m) + 10000 + 10000 + (61 * n + 22 * m + 22 - 16 * n - 4 * (4 * n + 3 * m))
+        return n * 2504 * 4 + 4 * (4 * n + 3 * m) + 10000 + (61 * n + 22 * m + 22 - 16 * n - 4 * (4 * n + 3 * m))
     if mode == "rollout":
         return 36 * n + 12 * m + 6
     return 61 * n + 22 * m + 22
@@ -216,7 +218,9 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(f"{a.workload}:{mode}")
+            traffic = (json.load(open(tpath)).get(f"{a.workload}:{mode}") or {}).get("per_launch_bytes")
+            if a.batch or a.kernel != "auto":
+                traffic = None  # the committed PMC passes were taken on the default batch / kernel
         lane = env_name == "flight_easy" and (a.kernel == "lane" or (a.kernel == "auto" and B >= 32768))
         kernel = {"rollout": f"k_rollout<{n}>", "step": f"k_step<{n},{1 if env_name == 'flight' else 0}>"}[mode]
         if lane:
