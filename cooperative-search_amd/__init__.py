@@ -10,6 +10,7 @@ from .args import get_flight_easy_args, get_flight_args, make_env_args  # noqa: 
 from .env import BatchedFlightEnv, FlightSearchEnvEasy, FlightSearchEnv  # noqa: F401
 from . import _lib as lib  # noqa: F401
 from . import dist  # noqa: F401
+from .collector import EpisodeCollector, evaluate, collect_experiment_data, random_policy  # noqa: F401
 
 __all__ = ["BatchedFlightEnv", "FlightSearchEnvEasy", "FlightSearchEnv", "load_targets", "default_circle_dict",
            "get_flight_easy_args", "get_flight_args", "make_env_args", "lib"]

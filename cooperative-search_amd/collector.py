@@ -1,0 +1,129 @@
+"""Batched episode collection and evaluation: the callers of the env path.
+
+`EpisodeCollector.generate_episodes` is the batched counterpart of `RolloutWorker.generate_episode`
+(/root/reference/common/rollout.py:22-140): same 11 keys, same padding semantics (after an episode terminates its
+remaining time steps are all-zero with padded = 1 and terminated = 1, rollout.py:105-116), one leading batch
+dimension of B episodes instead of 1.  `evaluate` is `Runner.evaluate` (runner.py:86-96) and
+`collect_experiment_data` the found-fraction curve of runner.py:139-171 / rollout.py:143-204, both reduced over
+ranks with the all-gather of dist.py.
+
+The env arithmetic stays in the HIP kernels; this module only moves tensors (torch ops on the device).
+"""
+import torch
+
+from . import dist as _dist
+
+
+class EpisodeCollector:
+    def __init__(self, env):
+        self.env = env
+
+    def generate_episodes(self, policy=None, actions=None, init=False):
+        """One episode per env.  Either `actions` (open-loop table, int [T, B, n]; flight_easy runs it as ONE fused
+        rollout launch) or `policy(obs[B,n,obs], state[B,S], last_onehot[B,n,A], t) -> int actions [B, n]`.
+        Returns (episode dict of float32 [B, T, ...] tensors, episode_reward[B], win_tag[B] bool, targets_find[B])."""
+        env = self.env
+        B, n, T, A = env.batch, env.n_agents, env.time_limit, env.n_actions
+        dev = env.device
+        saved = (env.freeze_done, env.auto_reset)
+        env.freeze_done, env.auto_reset = True, False  # finished envs must stay put; their steps become padding
+        try:
+            env.reset(init=init)  # rollout.py:26
+            obs_w, S = env.obs_width, env.state_shape
+            o = torch.empty(T + 1, B, n, obs_w, dtype=torch.float32, device=dev)
+            s = torch.empty(T + 1, B, S, dtype=torch.float32, device=dev)
+            u = torch.empty(T, B, n, dtype=torch.int64, device=dev)
+            r = torch.empty(T, B, dtype=torch.float32, device=dev)
+            term = torch.empty(T, B, dtype=torch.bool, device=dev)
+            o[0].copy_(env.get_obs())
+            s[0].copy_(env.get_state())
+            if actions is not None and not env.flight:
+                acts = torch.as_tensor(actions, device=dev)
+                out = env.rollout(acts)
+                o[1:].copy_(out["obs"])
+                s[1:].copy_(out["state"])
+                u.copy_(acts.to(torch.int64))
+                r.copy_(out["reward"])
+                term.copy_(out["terminated"])
+            else:
+                last = torch.zeros(B, n, A, dtype=torch.float32, device=dev)
+                for t in range(T):
+                    a = actions[t] if actions is not None else policy(o[t], s[t], last, t)
+                    a = torch.as_tensor(a, device=dev).to(torch.int64)
+                    rr, tt, _ = env.step(a)
+                    u[t].copy_(a)
+                    r[t].copy_(rr)
+                    term[t].copy_(tt)
+                    o[t + 1].copy_(env.get_obs())
+                    s[t + 1].copy_(env.get_state())
+                    last = torch.nn.functional.one_hot(a, A).to(torch.float32)
+            # a step is real if the env had not terminated before it
+            done_before = torch.zeros(T, B, dtype=torch.bool, device=dev)
+            done_before[1:] = term[:-1]
+            real = ~done_before  # [T, B]
+            rf = real.to(torch.float32)
+
+            def bt(x):  # [T, B, ...] -> [B, T, ...]
+                return x.transpose(0, 1).contiguous()
+
+            m4 = rf[:, :, None, None]
+            onehot = torch.nn.functional.one_hot(u, A).to(torch.float32)
+            ones = torch.ones(T, B, n, A, dtype=torch.float32, device=dev)
+            episode = dict(
+                o=bt(o[:-1] * m4), s=bt(s[:-1] * rf[:, :, None]), u=bt((u.to(torch.float32) * rf[:, :, None])[..., None]),
+                r=bt((r * rf)[..., None]), avail_u=bt(ones * m4), o_next=bt(o[1:] * m4), s_next=bt(s[1:] * rf[:, :, None]),
+                avail_u_next=bt(ones * m4), u_onehot=bt(onehot * m4), padded=bt((1.0 - rf)[..., None]),
+                terminated=bt(torch.where(real, term.to(torch.float32), torch.ones_like(rf))[..., None]))
+            episode_reward = env.total_reward.to(torch.float32).clone()
+            win_tag = env.win_flag.clone()  # terminated and win_flag (rollout.py:64): a win always terminates
+            targets_find = env.target_find.clone()
+            return episode, episode_reward, win_tag, targets_find
+        finally:
+            env.freeze_done, env.auto_reset = saved
+
+
+def _run_episodes(env, policy, init):
+    """One batch of episodes with frozen termination; yields (t, target_find) after every step."""
+    B, n, T, A = env.batch, env.n_agents, env.time_limit, env.n_actions
+    saved = (env.freeze_done, env.auto_reset)
+    env.freeze_done, env.auto_reset = True, False
+    try:
+        env.reset(init=init)
+        last = torch.zeros(B, n, A, dtype=torch.float32, device=env.device)
+        for t in range(T):
+            a = torch.as_tensor(policy(env.get_obs(), env.get_state(), last, t), device=env.device).to(torch.int64)
+            env.step(a)
+            last = torch.nn.functional.one_hot(a, A).to(torch.float32)
+            yield t, env.target_find
+    finally:
+        env.freeze_done, env.auto_reset = saved
+
+
+def random_policy(generator=None):
+    """The reference's alg='random' (agent/agent.py:34-36): uniform over the available actions."""
+    def policy(obs, state, last, t):
+        return torch.randint(0, 3, obs.shape[:2], device=obs.device, generator=generator)
+    return policy
+
+
+def evaluate(env, policy, batches=1):
+    """Runner.evaluate (runner.py:86-96): mean win_tag, episode_reward, targets_find over batches * B * world
+    evaluation episodes (reset() without init, like generate_episode).  One all-gather per call."""
+    part = torch.zeros(4, dtype=torch.float64, device=env.device)
+    for _ in range(batches):
+        for _t, _tf in _run_episodes(env, policy, init=False):
+            pass
+        part += env.metric_partials()
+    m = _dist.reduce_metrics(part)
+    return m["win_rate"], m["episode_reward"], m["targets_find"]
+
+
+def collect_experiment_data(env, policy, batches=1):
+    """runner.py:139-171: percent of targets found by step t (float64[episode_limit]), reset(init=True) per
+    episode as generate_replay does, averaged over batches * B * world episodes."""
+    curve = _dist.FoundCurve(env.time_limit, env.target_num, env.device)
+    for _ in range(batches):
+        for t, tf in _run_episodes(env, policy, init=True):
+            curve.add_step(t, tf)
+        curve.end_episodes(env.batch)
+    return curve.result()

@@ -217,6 +217,61 @@ def wall_script(n, T):
     return a
 
 
+def capture_episode(name, env_name, n, agent_mode, seed, aseed):
+    """Golden episode dict from the reference's own RolloutWorker.generate_episode (common/rollout.py:22-140),
+    driven by a stub Agents object that replays a pre-drawn action table (so the env is the only consumer of
+    numpy's global stream, as in the seeding protocol above)."""
+    Easy, Flight, load_targets = import_reference()
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        from common.rollout import RolloutWorker
+    finally:
+        os.chdir(cwd)
+    import io, contextlib
+    flight = env_name == "flight"
+    circle = load_targets(os.path.join(REF, "flight_targets.txt"))
+    args = make_args(env_name, n, agent_mode)
+    with contextlib.redirect_stdout(io.StringIO()):
+        env = (Flight if flight else Easy)(args, circle)
+    info = env.get_env_info()
+    args.n_actions, args.state_shape, args.obs_shape = info["n_actions"], info["state_shape"], info["obs_shape"]
+    args.episode_limit = info["episode_limit"]
+    args.epsilon, args.anneal_epsilon, args.min_epsilon, args.epsilon_anneal_scale = 0.0, 0.0, 0.0, "step"
+    args.alg, args.evaluate_epoch = "scripted", 20
+    actions = np.random.RandomState(aseed).randint(0, 3, size=(args.episode_limit, n)).astype(np.int32)
+
+    class StubPolicy:
+        def init_hidden(self, k):
+            pass
+
+    class StubAgents:
+        def __init__(self):
+            self.policy = StubPolicy()
+            self.calls = 0
+
+        def choose_action(self, obs, last_action, agent_num, avail_actions, epsilon, evaluate=False):
+            t, self.calls = self.calls // n, self.calls + 1
+            return int(actions[t][agent_num])
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        worker = RolloutWorker(env, StubAgents(), args)
+    np.random.seed(seed)
+    episode, episode_reward, win_tag, targets_find = worker.generate_episode(1, evaluate=True)
+    out = {k: np.asarray(v) for k, v in episode.items()}
+    out["actions_table"] = actions
+    out["meta"] = np.array(json.dumps(dict(name=name, env=env_name, n_agents=n, agent_mode=agent_mode, seed=seed,
+                                           aseed=aseed, episode_reward=int(episode_reward), win_tag=bool(win_tag),
+                                           targets_find=int(targets_find),
+                                           steps=int((out["padded"][0, :, 0] == 0).sum()))))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: reward={episode_reward} win={win_tag} found={targets_find} "
+          f"steps={(out['padded'][0, :, 0] == 0).sum()} shapes=" +
+          ",".join(f"{k}{tuple(v.shape)}" for k, v in out.items() if k not in ("meta", "actions_table")),
+          f"-> {os.path.getsize(path)/1024:.0f} KiB")
+
+
 def dump_target_table():
     """The dict the reference's load_targets (main.py:19-32) parses out of flight_targets.txt."""
     _, _, load_targets = import_reference()
@@ -270,6 +325,14 @@ def main():
     metas.append(run_trace("flight_n5_am2_s8_a9", "flight", 5, 2, 8, 9, [EP(True, 50, False)], map_every=25))
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump(metas, f, indent=1)
+    capture_all_episodes()
+
+
+def capture_all_episodes():
+    # episode dicts of common/rollout.py (the "next" row f1 of SURVEY.md section 8)
+    capture_episode("episode_easy_n3_am0_s0_a1", "flight_easy", 3, 0, 0, 1)      # 200 steps, time-limit termination
+    capture_episode("episode_easy_n5_am0_s0_a1", "flight_easy", 5, 0, 0, 1)      # 76 steps, win + zero padding
+    capture_episode("episode_flight_n3_am3_s3_a2", "flight", 3, 3, 3, 2)         # conv obs (2504 wide)
 
 
 if __name__ == "__main__":
