@@ -103,48 +103,14 @@ def cpu_baseline(env_name, n, batch, budget_s=12.0):
                       f"obs+state emitted, {dt:.1f} s wall", "single_thread_value": single}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20000)
-    ap.add_argument("--warmup", type=int, default=2000)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--mode", default=None, choices=["step", "rollout"])
-    ap.add_argument("--batch", type=int, default=None, help="override envs per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--kernel", default="auto", choices=["auto", "group", "lane"],
-                    help="flight_easy kernel: 16 lanes per env, one lane per env, or by batch size")
-    a = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
-
-    import cooperative_search_amd as cs
-
-    wl = dict(WORKLOADS[a.workload])
-    if a.batch:
-        wl["batch"] = a.batch
-    env_name, n, B, m = wl["env"], wl["n_agents"], wl["batch"], 15
-    mode = a.mode or ("rollout" if env_name == "flight_easy" else "step")
-    if env_name == "flight" and mode == "rollout":
-        raise SystemExit("rollout mode is flight_easy only")
-    K, W = a.steps, a.warmup
+def measure(cs, dev, env_name, n, B, mode, K, W, kernel, rank=0, no_graph=False, barrier=lambda: None):
+    """Times K steps of one workload on `dev`; returns (seconds wall, event ms, env, S)."""
+    m = 15
     S = largest_divisor_leq(K, 100)  # steps per graph replay / per rollout launch
-
     env = cs.BatchedFlightEnv(cs.make_env_args(env_name, n_agents=n), batch=B, device=dev, env_offset=rank * B,
-                              freeze_done=False, auto_reset=True, kernel=a.kernel)
+                              freeze_done=False, auto_reset=True, kernel=kernel)
     g = torch.Generator(device=dev).manual_seed(1 + rank)
     acts = torch.randint(0, 3, (S, B, n), dtype=torch.int32, device=dev, generator=g)
-
     if mode == "rollout":
         out = dict(
             reward=torch.empty(S, B, dtype=torch.float32, device=dev),
@@ -159,7 +125,7 @@ def main():
         def chunk_eager():
             for s in range(S):
                 env.step(acts[s])
-        if a.no_graph:
+        if no_graph:
             chunk = chunk_eager
         else:
             side = torch.cuda.Stream(device=dev)
@@ -174,11 +140,6 @@ def main():
 
             def chunk():
                 graph.replay()
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
     for _ in range(max(1, math.ceil(W / S))):
         chunk()
     torch.cuda.synchronize(dev)
@@ -194,15 +155,80 @@ def main():
     barrier()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
-    ev_ms = ev0.elapsed_time(ev1)
+    return dt, ev0.elapsed_time(ev1), env, S
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+
+def side_measurement(cs, dev, label, env_name, n, B, mode, K, W, kernel):
+    """Compact entry for the `also` object: other workloads measured in the same run (N = 1 only)."""
+    dt, ev_ms, env, S = measure(cs, dev, env_name, n, B, mode, K, W, kernel)
+    launches = K // S if mode == "rollout" else K
+    alg = algorithmic_bytes_per_env_step(env_name, n, 15, mode)
+    achieved = alg * B * (S if mode == "rollout" else 1) / ((ev_ms / 1e3) / launches) / 1e9
+    del env
+    torch.cuda.empty_cache()
+    return {"workload": label, "mode": mode, "kernel": kernel, "value": B * K / dt, "unit": "env-steps/s",
+            "ms_per_step": dt * 1e3 / K, "algorithmic_bytes_per_env_step": alg,
+            "roofline_achieved_GBps": achieved, "roofline_frac": achieved / HBM_PEAK_GBPS}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--warmup", type=int, default=2000)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default=None, choices=["step", "rollout"])
+    ap.add_argument("--batch", type=int, default=None, help="override envs per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads reported under 'also'")
+    ap.add_argument("--kernel", default="auto", choices=["auto", "group", "lane"],
+                    help="flight_easy kernel: 16 lanes per env, one lane per env, or by batch size")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    # BENCH_SHARE_GPU=1 (tests only): all ranks use cuda:0 and the gloo backend, to exercise the N > 1 control flow on
+    # a one-GPU box.  The real multi-GPU run is one process per GPU over RCCL (backend "nccl").
+    share = os.environ.get("BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if world > 1:
+        import torch.distributed as dist
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+
+    import cooperative_search_amd as cs
+
+    wl = dict(WORKLOADS[a.workload])
+    if a.batch:
+        wl["batch"] = a.batch
+    env_name, n, B, m = wl["env"], wl["n_agents"], wl["batch"], 15
+    mode = a.mode or ("rollout" if env_name == "flight_easy" else "step")
+    if env_name == "flight" and mode == "rollout":
+        raise SystemExit("rollout mode is flight_easy only")
+    K, W = a.steps, a.warmup
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    dt, ev_ms, env, S = measure(cs, dev, env_name, n, B, mode, K, W, a.kernel, rank=rank, no_graph=a.no_graph,
+                                barrier=barrier)
+    cdev = torch.device("cpu") if share else dev  # gloo collectives on host tensors in the shared-GPU test mode
+    tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt_max = float(tmax.item())
 
     # evaluation-metric reduction (runner.py:86-96): the path's only collective, outside the timed region
-    part = env.metric_partials().clone()
+    part = env.metric_partials().clone().to(cdev)
     if world > 1:
         gathered = [torch.zeros_like(part) for _ in range(world)]
         dist.all_gather(gathered, part)
@@ -243,6 +269,18 @@ def main():
         }
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(env_name, n, B)
+        if world == 1 and not a.no_also and a.workload == "c2" and not a.batch:
+            del env
+            torch.cuda.empty_cache()
+            line["also"] = [
+                side_measurement(cs, dev, "c2 flight_easy 3a15t B=4096, one launch per step (hipGraph)", "flight_easy", 3,
+                                 4096, "step", 10000, 1000, "auto"),
+                side_measurement(cs, dev, "c3 flight_easy 5a15t B=16384", "flight_easy", 5, 16384, "rollout", 2000, 200, "auto"),
+                side_measurement(cs, dev, "c4 flight 3a15t B=8192 (k_step + k_map per step)", "flight", 3, 8192, "step",
+                                 2000, 200, "auto"),
+                side_measurement(cs, dev, "flight_easy 3a15t B=262144 (lane-per-env kernel; batch sweep asymptote)",
+                                 "flight_easy", 3, 262144, "rollout", 400, 100, "lane"),
+            ]
         print(json.dumps(line))
     if world > 1:
         dist.barrier()
