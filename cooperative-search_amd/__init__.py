@@ -6,10 +6,12 @@ include/coopsearch.h.  Nothing here falls back to a CPU implementation: importin
 constructing an environment without the built HIP library and a GPU raises.
 """
 from .targets import load_targets, DEFAULT_TARGETS_FILE, default_circle_dict  # noqa: F401
-from .args import get_flight_easy_args, get_flight_args, make_env_args  # noqa: F401
+from .args import get_flight_easy_args, get_flight_args, make_env_args, apply_env_info  # noqa: F401
 from .env import BatchedFlightEnv, FlightSearchEnvEasy, FlightSearchEnv  # noqa: F401
 from . import _lib as lib  # noqa: F401
 from . import dist  # noqa: F401
+from .replay import DeviceReplayBuffer  # noqa: F401
+from .agents import AgentRNN, BatchedAgents, rnn_input_shape  # noqa: F401
 from .collector import EpisodeCollector, evaluate, collect_experiment_data, random_policy  # noqa: F401
 
 __all__ = ["BatchedFlightEnv", "FlightSearchEnvEasy", "FlightSearchEnv", "load_targets", "default_circle_dict",

@@ -1,0 +1,97 @@
+"""Batched action selection: the caller of the env path.
+
+The reference picks actions one agent at a time with batch 1 and a host->device copy per call
+(/root/reference/agent/agent.py:33-75); once the env is batched that loop is the bottleneck.  `BatchedAgents` runs ONE
+forward of the shared recurrent Q-network over all B*n (env, agent) rows and does the epsilon-greedy choice on the
+device.  `AgentRNN` has the reference architecture and parameter names (network/base_net.py:5-46: [conv ->] fc1 ->
+GRUCell -> fc2), so the reference's `*_rnn_net_params.pkl` state_dicts load unchanged.  Stock torch modules: nothing
+custom is needed on ROCm for a 64-wide GRU.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class AgentRNN(nn.Module):
+    def __init__(self, input_shape, args):
+        super().__init__()
+        self.args = args
+        self.input_shape = input_shape
+        if args.conv:
+            self.conv_size = int((args.map_size - args.kernel_size_1) / args.stride_1 + 1)
+            self.conv = nn.Sequential(nn.Conv2d(1, args.dim_1, args.kernel_size_1, args.stride_1), nn.ReLU(),
+                                      nn.Conv2d(args.dim_1, args.dim_2, args.kernel_size_2, args.stride_2, args.padding_2),
+                                      nn.ReLU())
+            self.linear = nn.Linear(args.dim_2 * self.conv_size ** 2, args.conv_out_dim)
+        self.fc1 = nn.Linear(input_shape, args.rnn_hidden_dim)
+        self.rnn = nn.GRUCell(args.rnn_hidden_dim, args.rnn_hidden_dim)
+        self.fc2 = nn.Sequential(nn.Linear(args.rnn_hidden_dim, args.rnn_hidden_dim), nn.ReLU(),
+                                 nn.Linear(args.rnn_hidden_dim, args.n_actions))
+
+    def forward(self, obs, hidden_state):
+        if self.args.conv:
+            cells = self.args.map_size ** 2
+            prob = obs[:, :cells].reshape(-1, 1, self.args.map_size, self.args.map_size)
+            feat = self.linear(self.conv(prob).reshape(-1, self.args.dim_2 * self.conv_size ** 2))
+            obs = torch.cat([feat, obs[:, cells:]], 1)
+        x = F.relu(self.fc1(obs))
+        h = self.rnn(x, hidden_state.reshape(-1, self.args.rnn_hidden_dim))
+        return self.fc2(h), h
+
+
+def rnn_input_shape(args):
+    """policy/qmix.py:19-25: obs_shape (+ n_actions if last_action) (+ n_agents if reuse_network) (+ conv_out_dim)."""
+    shape = args.obs_shape
+    if getattr(args, "last_action", True):
+        shape += args.n_actions
+    if getattr(args, "reuse_network", True):
+        shape += args.n_agents
+    if getattr(args, "conv", False):
+        shape += args.conv_out_dim
+    return shape
+
+
+class BatchedAgents:
+    """choose_action for every (env, agent) at once.  policy(obs, state, last_onehot, t) signature of collector.py."""
+
+    def __init__(self, args, batch, device="cuda", net=None):
+        self.args, self.batch, self.device = args, int(batch), torch.device(device)
+        self.n_agents, self.n_actions = args.n_agents, args.n_actions
+        self.net = (net or AgentRNN(rnn_input_shape(args), args)).to(self.device)
+        self.agent_ids = torch.eye(self.n_agents, device=self.device).expand(self.batch, -1, -1)
+        self.init_hidden()
+
+    def init_hidden(self):
+        self.hidden = torch.zeros(self.batch * self.n_agents, self.args.rnn_hidden_dim, device=self.device)
+
+    @torch.no_grad()
+    def choose_action(self, obs, last_onehot, avail=None, epsilon=0.0, evaluate=False, generator=None):
+        """obs [B, n, obs_w], last_onehot [B, n, A] -> int64 actions [B, n] (agent/agent.py:33-75 semantics:
+        inputs = obs ++ last_action ++ agent_id; q masked to -inf where unavailable; greedy when evaluating or with
+        probability 1 - epsilon, otherwise uniform over the available actions)."""
+        B, n, A = self.batch, self.n_agents, self.n_actions
+        parts = [obs]
+        if getattr(self.args, "last_action", True):
+            parts.append(last_onehot)
+        if getattr(self.args, "reuse_network", True):
+            parts.append(self.agent_ids)
+        x = torch.cat(parts, dim=2).reshape(B * n, -1)
+        q, self.hidden = self.net(x, self.hidden)
+        q = q.reshape(B, n, A)
+        if avail is not None:
+            q = q.masked_fill(avail.reshape(-1, 1, A).expand(B, n, A) == 0 if avail.dim() == 2 else avail == 0, float("-inf"))
+        greedy = q.argmax(dim=2)
+        if evaluate or epsilon <= 0.0:
+            return greedy
+        explore = torch.rand(B, n, device=self.device, generator=generator) < epsilon
+        probs = torch.ones(B, n, A, device=self.device) if avail is None else (
+            avail.reshape(-1, 1, A).expand(B, n, A) if avail.dim() == 2 else avail).to(torch.float32)
+        rand_a = torch.multinomial(probs.reshape(B * n, A), 1, generator=generator).reshape(B, n)
+        return torch.where(explore, rand_a, greedy)
+
+    def policy(self, epsilon=0.0, evaluate=True, generator=None):
+        def fn(obs, state, last_onehot, t):
+            if t == 0:
+                self.init_hidden()
+            return self.choose_action(obs, last_onehot, None, epsilon, evaluate, generator)
+        return fn

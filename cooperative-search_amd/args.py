@@ -41,3 +41,17 @@ def make_env_args(env="flight_easy", n_agents=3, agent_mode=0, target_mode=0, ma
     args = types.SimpleNamespace(env=env, map_size=map_size, target_num=target_num, target_mode=target_mode,
                                  agent_mode=agent_mode, n_agents=n_agents, view_range=view_range)
     return get_flight_args(args) if env == "flight" else get_flight_easy_args(args)
+
+
+def apply_env_info(args, env):
+    """main.py:113-118: copy get_env_info() into the namespace; plus the algorithm-side fields the agent network and the
+    replay buffer read (common/arguments.py:37-39 last_action / reuse_network, get_mixer_args :58 rnn_hidden_dim)."""
+    info = env.get_env_info()
+    args.n_actions = info["n_actions"]
+    args.state_shape = info["state_shape"]
+    args.obs_shape = info["obs_shape"]
+    args.episode_limit = info["episode_limit"]
+    for k, v in (("last_action", True), ("reuse_network", True), ("rnn_hidden_dim", 64)):
+        if not hasattr(args, k):
+            setattr(args, k, v)
+    return args

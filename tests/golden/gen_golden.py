@@ -328,6 +328,75 @@ def main():
     capture_all_episodes()
 
 
+def capture_replay_indices():
+    """FIFO storage-index rule and sampling helpers of the reference ReplayBuffer (common/replay_buffer.py:84-101,
+    70-82): a sequence of store sizes -> the indices it hands out."""
+    import_reference()
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        from common.replay_buffer import ReplayBuffer
+    finally:
+        os.chdir(cwd)
+    import io, contextlib
+    args = types.SimpleNamespace(n_actions=3, n_agents=3, state_shape=57, obs_shape=4, episode_limit=4, conv=False,
+                                 map_size=50)
+    rng = np.random.RandomState(5)
+    cases = []
+    for size in (7, 16, 100):
+        with contextlib.redirect_stdout(io.StringIO()):
+            rb = ReplayBuffer(args, size)
+        incs = [int(v) for v in rng.randint(1, max(2, size // 2), size=40)]
+        steps = []
+        for inc in incs:
+            idx = rb._get_storage_idx(inc)
+            latest = None
+            k = min(3, rb.current_size)
+            if k > 0:
+                # sample_latest returns buffer rows; recover the indices it used via a marker array
+                rb.buffers["r"][:, 0, 0] = np.arange(size)
+                latest = [int(v) for v in rb.sample_latest(k)["r"][:, 0, 0]]
+            steps.append(dict(inc=inc, idx=[int(v) for v in np.atleast_1d(idx)], current_idx=int(rb.current_idx),
+                              current_size=int(rb.current_size), latest3=latest))
+        cases.append(dict(size=size, steps=steps))
+    with open(os.path.join(HERE, "replay_indices.json"), "w") as f:
+        json.dump(cases, f)
+    print("replay_indices.json:", sum(len(c["steps"]) for c in cases), "steps")
+
+
+def capture_rnn_forward():
+    """Reference RNN (network/base_net.py:5-46) forward on seeded random weights and inputs, for flight_easy
+    (input 4 + 3 + n) and flight (conv front end).  Weights are ours (torch.manual_seed), not the shipped models."""
+    import_reference()
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        from network.base_net import RNN
+    finally:
+        os.chdir(cwd)
+    import torch
+    out = {}
+    for tag, conv, n in (("easy", False, 3), ("flight", True, 3)):
+        args = types.SimpleNamespace(conv=conv, map_size=50, rnn_hidden_dim=64, n_actions=3, dim_1=4, kernel_size_1=4,
+                                     stride_1=2, dim_2=1, kernel_size_2=3, stride_2=1, padding_2=1, conv_out_dim=16)
+        in_shape = 4 + 3 + n + (16 if conv else 0)
+        torch.manual_seed(1234)
+        net = RNN(in_shape, args).double()
+        rows = 6
+        width = (2500 if conv else 0) + 4 + 3 + n
+        x = torch.rand(rows, width, dtype=torch.float64)
+        h = torch.randn(rows, 64, dtype=torch.float64)
+        with torch.no_grad():
+            q, h2 = net(x, h)
+        for k, v in net.state_dict().items():
+            out[f"{tag}_w_{k}"] = v.numpy().astype(np.float32)
+        out[f"{tag}_x"], out[f"{tag}_h"] = x.numpy(), h.numpy()
+        out[f"{tag}_q"], out[f"{tag}_h2"] = q.numpy(), h2.numpy()
+    path = os.path.join(HERE, "rnn_forward.npz")
+    np.savez_compressed(path, **out)
+    print("rnn_forward.npz", f"{os.path.getsize(path)/1024:.0f} KiB")
+
+
 def capture_all_episodes():
     # episode dicts of common/rollout.py (the "next" row f1 of SURVEY.md section 8)
     capture_episode("episode_easy_n3_am0_s0_a1", "flight_easy", 3, 0, 0, 1)      # 200 steps, time-limit termination

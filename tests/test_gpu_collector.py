@@ -62,3 +62,31 @@ def test_random_policy_curve_matches_reference_results(n, agent_mode, want, tol)
     np.testing.assert_allclose(got, want, rtol=0, atol=tol)
     win_rate, reward, found = cs.evaluate(env, cs.random_policy(g))
     assert 0.0 <= win_rate <= 1.0 and abs(found / 15 * 100 - want[-1]) < tol + 0.5 and reward < 0
+
+
+@pytest.mark.parametrize("env_name", ["flight_easy", "flight"])
+def test_closed_loop_collect_store_sample(env_name):
+    """f1 + f2 + f3 together: a recurrent policy picks the actions of all (env, agent) pairs in one forward per step,
+    the collector builds the episode batch, the HBM replay buffer stores and samples it."""
+    B = 64 if env_name == "flight" else 256
+    args = cs.make_env_args(env_name, n_agents=3)
+    env = cs.BatchedFlightEnv(args, batch=B)
+    cs.apply_env_info(args, env)
+    torch.manual_seed(3)
+    agents = cs.BatchedAgents(args, B)
+    g = torch.Generator("cuda").manual_seed(5)
+    ep, rew, win, found = cs.EpisodeCollector(env).generate_episodes(policy=agents.policy(0.3, False, g))
+    T = args.episode_limit
+    assert ep["o"].shape == (B, T, 3, 2504 if env_name == "flight" else 4) and ep["u_onehot"].shape == (B, T, 3, 3)
+    real = ep["padded"][:, :, 0] == 0
+    assert (ep["u_onehot"].sum(-1)[real] == 1).all() and (ep["u_onehot"][~real] == 0).all()
+    assert torch.equal((ep["r"][:, :, 0] * real).sum(1), rew)
+    assert (ep["terminated"][:, -1, 0] == 1).all()
+    rb = cs.DeviceReplayBuffer(args, 2 * B + 10)
+    rb.store_episode(ep)
+    rb.store_episode(ep)
+    rb.store_episode({k: v[:20] for k, v in ep.items()})     # wraps around
+    assert rb.current_size == 2 * B + 10 and rb.current_idx == 10
+    s = rb.sample(32, generator=g)
+    assert s["o"].shape == (32, T, 3, ep["o"].shape[-1]) and s["s"].device.type == "cuda"
+    assert torch.equal(rb.buffers["r"][:10], ep["r"][10:20])
