@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
-LIB_PATH = os.path.join(CSRC, "libcoopsearch_hip.so")
+LIB_PATH = os.environ.get("COOPSEARCH_LIB") or os.path.join(CSRC, "libcoopsearch_hip.so")  # override: experiments only
 SOURCES = ["coopsearch.hip", "trig_table.inc"]
 HEADERS = [os.path.join(ROOT, "include", "coopsearch.h")]
 
@@ -19,6 +19,8 @@ def hipcc_path():
 
 
 def is_stale():
+    if os.environ.get("COOPSEARCH_LIB"):
+        return False
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)

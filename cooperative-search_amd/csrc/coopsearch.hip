@@ -1131,7 +1131,13 @@ __device__ __forceinline__ void build_rowbits(const DevParams &p, const double (
 // holds many of them and one workgroup's load latency overlaps another's arithmetic and stores.  The pending-
 // update flags are written only by k_step / k_reset (set or cleared on every launch), never here, so the
 // workgroups of one env need no ordering; `apply` = 0 makes this a pure get_obs sweep (cs_emit).
-constexpr int MAP_BLOCK = 320;
+#ifndef CS_MAP_BLOCK
+#define CS_MAP_BLOCK 256
+#endif
+#ifndef CS_MAP_NT
+#define CS_MAP_NT 1
+#endif
+constexpr int MAP_BLOCK = CS_MAP_BLOCK;
 
 template <int N>
 __global__ __launch_bounds__(MAP_BLOCK) void k_map(DevParams p, float *obs, int apply) {
@@ -1151,8 +1157,9 @@ __global__ __launch_bounds__(MAP_BLOCK) void k_map(DevParams p, float *obs, int 
 
     if (dirty || reset_pass) {
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        if (wave < 2 && (wave == 0 ? dirty : reset_pass)) {  // wave 0: the step's pass, wave 1: the reset-time pass
-            const int k = 1 - wave;
+        // wave 0 builds the step's pass and wave 1 the reset-time pass (a one-wave workgroup builds both in turn)
+        for (int k = 1; k >= 0; k--) {
+            if (wave != (MAP_BLOCK >= 128 ? 1 - k : 0) || !(k == 1 ? dirty : reset_pass)) continue;
             double ax[N], ay[N];
 #pragma unroll
             for (int i = 0; i < N; i++) {
@@ -1234,8 +1241,13 @@ __global__ __launch_bounds__(MAP_BLOCK) void k_map(DevParams p, float *obs, int 
         if (obs) {
             const v4f nv = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int a = 0; a < N; a++)  // write-once stream: keep it out of the caches
+            for (int a = 0; a < N; a++) {  // write-once stream: keep it out of the caches
+#if CS_MAP_NT
                 __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(obs + ((size_t)b * N + a) * row_w) + c);
+#else
+                reinterpret_cast<v4f *>(obs + ((size_t)b * N + a) * row_w)[c] = nv;
+#endif
+            }
         }
     }
 }

@@ -11,7 +11,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def trace_names(prefix=""):
     """Step-by-step env traces (the episode_*.npz files are RolloutWorker episode dicts, see test_gpu_collector.py)."""
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
-    return [n for n in names if not n.startswith("episode_")]
+    return [n for n in names if n.startswith(("easy_", "flight_"))]
 
 
 def load_trace(name):
