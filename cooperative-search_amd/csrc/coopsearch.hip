@@ -27,6 +27,8 @@ namespace {
 constexpr int G = 16;        // lanes per environment
 constexpr int BLOCK = 256;   // 4 wavefronts, 16 environments
 constexpr int MT_N = 624;
+constexpr int MT_PAD = 16;              // words 0..15 of each env's state are mirrored at 624..639, so a
+constexpr int MT_STRIDE = MT_N + MT_PAD;  // 16-word window starting anywhere in 0..623 never wraps
 constexpr int MT_M = 397;
 constexpr int TRIG_ROWS = 37, TRIG_COLS = 7;
 constexpr int FLAG_WIN = 1, FLAG_DIRTY = 2, FLAG_RESET_PASS = 4;
@@ -72,6 +74,13 @@ __device__ __forceinline__ void drain_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70
 
 __device__ __forceinline__ int wrap624(int v) { return v >= MT_N ? v - MT_N : v; }  // v < 2*624
 
+// every store to the circular state also refreshes the mirror of words 0..15 (second store duplicates the first
+// when the word has no mirror: unconditional, so no branch is introduced around vector memory operations)
+__device__ __forceinline__ void mt_store(unsigned *mt, int idx, unsigned v) {
+    mt[idx] = v;
+    mt[idx < MT_PAD ? MT_N + idx : idx] = v;
+}
+
 // Reset draws its random numbers 16 "attempts" at a time: lane l of the group rebuilds the four stream words
 // pos+4l .. pos+4l+3 (one memory round trip for the whole group; 64 words < 227, so they are independent of each
 // other) and turns them into the two uniforms one polar-gaussian attempt (or one uniform target) consumes.  Only
@@ -101,7 +110,7 @@ struct AttemptBatch {
     __device__ __forceinline__ void commit(unsigned *mt, int pos, int l, int words) const {
 #pragma unroll
         for (int q = 0; q < 4; q++)
-            if (4 * l + q < words) mt[wrap624(wrap624(pos + 4 * l) + q)] = nw[q];
+            if (4 * l + q < words) mt_store(mt, wrap624(wrap624(pos + 4 * l) + q), nw[q]);
     }
 };
 
@@ -169,6 +178,9 @@ __device__ __forceinline__ void norm_target(const DevParams &p, Env<N> &e) {
 }
 
 // The group's window into the circular MT19937 state: lane l holds words pos+l and pos+397+l.
+struct __attribute__((packed, aligned(4))) U4 { unsigned x, y, z, w; };  // 4-byte-aligned 16-byte access
+struct __attribute__((packed, aligned(4))) U2 { unsigned x, y; };
+
 struct MtWin {
     unsigned cur, far;
 };
@@ -252,7 +264,7 @@ __device__ __forceinline__ void env_store(const DevParams &p, int b, int t, cons
 template <int N>
 __device__ __forceinline__ int detect_pass(const DevParams &p, int b, int t, int gshift, Env<N> &e, MtWin win) {
     const bool is_tgt = t < p.n_targets;
-    unsigned *mt = p.mt + (size_t)b * MT_N;
+    unsigned *mt = p.mt + (size_t)b * MT_STRIDE;
     bool inr[N];
     int rank[N];
     int base = 0;
@@ -279,7 +291,7 @@ __device__ __forceinline__ int detect_pass(const DevParams &p, int b, int t, int
         hit = hit || (inr[i] && rank[i] < 7 && u <= p.detect_K);  // prob <= self.detect_prob, exact in integers
     }
     const int fast_words = base < 7 ? 2 * base : 14;
-    if (t < fast_words) mt[wrap624(e.mt_pos + t)] = nw;
+    if (t < fast_words) mt_store(mt, wrap624(e.mt_pos + t), nw);
     if (base > 7) {  // rare: direct loads for the ranks the window does not cover
         constexpr int PHASES = (N * G * 2 > 226) ? 2 : 1;
         constexpr int PER = (N + PHASES - 1) / PHASES;
@@ -307,8 +319,8 @@ __device__ __forceinline__ int detect_pass(const DevParams &p, int b, int t, int
                     int i1 = wrap624(i0 + 1);
                     unsigned n0 = mt_mix(w[k][0], w[k][1], w[k][3]);
                     unsigned n1 = mt_mix(w[k][1], w[k][2], w[k][4]);
-                    mt[i0] = n0;
-                    mt[i1] = n1;
+                    mt_store(mt, i0, n0);
+                    mt_store(mt, i1, n1);
                     unsigned long long u =
                         ((unsigned long long)(mt_temper(n0) >> 5) << 26) | (unsigned long long)(mt_temper(n1) >> 6);
                     hit = hit || (u <= p.detect_K);
@@ -461,7 +473,7 @@ __device__ __forceinline__ void env_reset(const DevParams &p, const double *T, i
         float4 *m4 = reinterpret_cast<float4 *>(p.prob + (size_t)b * p.cells);
         for (int c = t; c < p.cells / 4; c += G) m4[c] = make_float4(0.5f, 0.5f, 0.5f, 0.5f);
     }
-    unsigned *mt = p.mt + (size_t)b * MT_N;
+    unsigned *mt = p.mt + (size_t)b * MT_STRIDE;
     const unsigned tmask = p.n_targets >= 32 ? ~0u : ((1u << p.n_targets) - 1u);
     double mx = 0.0, my = 0.0;
     if (p.target_mode == 0) {
@@ -678,7 +690,7 @@ __device__ __forceinline__ void step_once(const DevParams &p, const double *T, c
                 e.flags |= FLAG_RESET_PASS;
             }
             env_store<N>(p, b, t, e, true);  // targets changed
-            win = mt_prefetch(p.mt + (size_t)b * MT_N, e.mt_pos, t);
+            win = mt_prefetch(p.mt + (size_t)b * MT_STRIDE, e.mt_pos, t);
             drain_vmem();
             done = false;
         }
@@ -692,7 +704,7 @@ __device__ __forceinline__ void step_once(const DevParams &p, const double *T, c
             env_trig<N>(T, e);  // frozen env: re-emit the unchanged observation
         }
         // the next step's window does not overlap the words just committed: request it before this step's stores
-        if (prefetch_next) win = mt_prefetch(p.mt + (size_t)b * MT_N, e.mt_pos, t);
+        if (prefetch_next) win = mt_prefetch(p.mt + (size_t)b * MT_STRIDE, e.mt_pos, t);
     }
     emit_wave<N>(p, io, tile, lane, t, grp, live, e, reward, term, slot0, nvalid);
 }
@@ -717,7 +729,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(DevParams p, StepIO io) {
     if (wave_b0 >= p.B) return;
     const int nvalid = p.B - wave_b0 < 4 ? p.B - wave_b0 : 4;
     MtWin win = {0u, 0u};
-    if (live) win = mt_prefetch(p.mt + (size_t)b * MT_N, e.mt_pos, t);
+    if (live) win = mt_prefetch(p.mt + (size_t)b * MT_STRIDE, e.mt_pos, t);
     step_once<N, VARIANT>(p, T, io, tiles[threadIdx.x >> 6], b, lane, (size_t)wave_b0, nvalid, live, act, win, false, e);
     if (live) env_store<N>(p, b, t, e, false);
 }
@@ -744,7 +756,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(DevParams p, StepIO io) {
     const int nvalid = p.B - wave_b0 < 4 ? p.B - wave_b0 : 4;
     WaveTile &tile = tiles[threadIdx.x >> 6];
     MtWin win = {0u, 0u};
-    if (live) win = mt_prefetch(p.mt + (size_t)b * MT_N, e.mt_pos, t);
+    if (live) win = mt_prefetch(p.mt + (size_t)b * MT_STRIDE, e.mt_pos, t);
     for (int s = 0; s < io.T; s++) {
         int act_next[N];
         const int sn = s + 1 < io.T ? s + 1 : s;
@@ -844,25 +856,28 @@ __device__ __forceinline__ int detect_lane(const DevParams &p, unsigned *mt, Env
     }
     const int total = __popcll(lo) + (N > 4 ? __popcll(hi) : 0);
     unsigned hitmask = 0;
-    int pos = e.mt_pos;
-    for (int r0 = 0; r0 < total; r0 += 4) {  // one np.random.rand() per in-range pair, found or not (quirk Q4)
-        unsigned cur[9], far[8];
+    int pos = e.mt_pos;  // always even: every consumer takes an even number of words
+    for (int r0 = 0; r0 < total; r0 += 8) {  // one np.random.rand() per in-range pair, found or not (quirk Q4)
+        // 17 + 16 words straight from the padded row (no wrap inside a window), as unaligned 16-byte loads
+        unsigned cur[17], far[16];
+        const unsigned *pc = mt + pos, *pf = mt + wrap624(pos + MT_M);
 #pragma unroll
-        for (int q = 0; q < 9; q++) cur[q] = mt[wrap624(pos + q)];
-        const int fpos = wrap624(pos + MT_M);
-#pragma unroll
-        for (int q = 0; q < 8; q++) far[q] = mt[wrap624(fpos + q)];
-        const int take = total - r0 < 4 ? total - r0 : 4;
-        unsigned tw[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const unsigned nw = mt_mix(cur[q], cur[q + 1], far[q]);
-            tw[q] = mt_temper(nw);
-            if (q < 2 * take) mt[wrap624(pos + q)] = nw;
+        for (int q = 0; q < 4; q++) {
+            const U4 c4 = *reinterpret_cast<const U4 *>(pc + 4 * q), f4 = *reinterpret_cast<const U4 *>(pf + 4 * q);
+            cur[4 * q] = c4.x; cur[4 * q + 1] = c4.y; cur[4 * q + 2] = c4.z; cur[4 * q + 3] = c4.w;
+            far[4 * q] = f4.x; far[4 * q + 1] = f4.y; far[4 * q + 2] = f4.z; far[4 * q + 3] = f4.w;
         }
+        cur[16] = pc[16 < MT_STRIDE - pos ? 16 : 0];  // word pos+16 exists in the row unless pos == 624 (never)
+        const int take = total - r0 < 8 ? total - r0 : 8;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < 8; k++) {
             if (k < take) {
+                const unsigned n0 = mt_mix(cur[2 * k], cur[2 * k + 1], far[2 * k]);
+                const unsigned n1 = mt_mix(cur[2 * k + 1], cur[2 * k + 2], far[2 * k + 1]);
+                const int i0 = wrap624(pos + 2 * k);  // even, so the pair never straddles 623|0
+                U2 pr = {n0, n1};
+                *reinterpret_cast<U2 *>(mt + i0) = pr;
+                *reinterpret_cast<U2 *>(mt + (i0 < MT_PAD ? MT_N + i0 : i0)) = pr;
                 int bit;
                 if (N <= 4 || lo) {
                     bit = __ffsll((long long)lo) - 1;
@@ -871,7 +886,7 @@ __device__ __forceinline__ int detect_lane(const DevParams &p, unsigned *mt, Env
                     bit = __ffsll((long long)hi) - 1;
                     hi &= hi - 1;
                 }
-                const unsigned long long u = ((unsigned long long)(tw[2 * k] >> 5) << 26) | (unsigned long long)(tw[2 * k + 1] >> 6);
+                const unsigned long long u = ((unsigned long long)(mt_temper(n0) >> 5) << 26) | (unsigned long long)(mt_temper(n1) >> 6);
                 hitmask |= (u <= p.detect_K ? 1u : 0u) << (bit & 15);  // prob <= self.detect_prob, exact in integers
             }
         }
@@ -924,7 +939,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_lane(DevParams p, StepIO io) 
     if (b0 >= p.B) return;  // whole wavefront out of range
     EnvL<N> e;
     int act[N];
-    unsigned *mt = p.mt + (size_t)(live ? b : 0) * MT_N;
+    unsigned *mt = p.mt + (size_t)(live ? b : 0) * MT_STRIDE;
     if (live) {
         envl_load<N>(p, b, T, e);
         load_actions<N>(io, (size_t)b, act);
@@ -1257,13 +1272,14 @@ __global__ void k_seed(DevParams p, const uint32_t *seeds) {
     // np.random.seed(s): init_genrand; the circular form starts at cursor 0 over the seed array
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= p.B) return;
-    unsigned *mt = p.mt + (size_t)b * MT_N;
+    unsigned *mt = p.mt + (size_t)b * MT_STRIDE;
     unsigned x = seeds[b];
     mt[0] = x;
     for (int i = 1; i < MT_N; i++) {
         x = 1812433253u * (x ^ (x >> 30)) + (unsigned)i;
         mt[i] = x;
     }
+    for (int i = 0; i < MT_PAD; i++) mt[MT_N + i] = mt[i];
     int *hdr = p.hdr + (size_t)b * CS_H_WORDS;
     hdr[CS_H_MT_POS] = 0;
     hdr[CS_H_WORDS_LO] = 0;
@@ -1427,7 +1443,7 @@ int cs_state_layout(const cs_config *cfg, cs_layout *out) {
     out->hdr_off = off;
     off = align_up(off + B * CS_H_WORDS * sizeof(int32_t), 256);
     out->mt_off = off;
-    off = align_up(off + B * MT_N * sizeof(uint32_t), 256);
+    off = align_up(off + B * MT_STRIDE * sizeof(uint32_t), 256);
     out->prob_off = off;
     if (cfg->variant == 1) off = align_up(off + B * (size_t)cfg->map_size * cfg->map_size * sizeof(float), 256);
     out->total_bytes = off;

@@ -145,7 +145,7 @@ class BatchedFlightEnv:
             tgt=self._view(lay.tgt_off, B * 32, torch.float64, (B, 16, 2)),
             agent=self._view(lay.agent_off, B * 32, torch.float64, (B, 8, 4)),
             hdr=self._view(lay.hdr_off, B * 16, torch.int32, (B, 16)),
-            mt=self._view(lay.mt_off, B * 624, torch.int32, (B, 624)),
+            mt=self._view(lay.mt_off, B * 640, torch.int32, (B, 640)),
         )
         if self.flight:
             d["prob"] = self._view(lay.prob_off, B * self.cells, torch.float32, (B, self.map_size, self.map_size))

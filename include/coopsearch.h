@@ -77,7 +77,8 @@ typedef struct cs_layout {
     size_t tgt_off;    /* double [B][16][2]   target (x, y)                                             */
     size_t agent_off;  /* double [B][8][4]    agent (x, y, yaw, spare)                                   */
     size_t hdr_off;    /* int32  [B][16]      CS_H_* words below                                         */
-    size_t mt_off;     /* uint32 [B][624]     MT19937 state, circular (incremental) form + cursor in hdr */
+    size_t mt_off;     /* uint32 [B][640]     MT19937 state, circular (incremental) form + cursor in hdr;
+                          words 624..639 mirror words 0..15                                          */
     size_t prob_off;   /* float  [B][map*map] probability map, first index = x cell (flight only)        */
 } cs_layout;
 
@@ -90,7 +91,7 @@ enum {
                            bits 8..15 out_flag[i]                                                            */
     CS_H_TIME_STEP = 4, /* env.time_step                                                                      */
     CS_H_TOTAL_REWARD = 5, /* env.total_reward (integer)                                                      */
-    CS_H_MT_POS = 6,    /* cursor into the circular MT19937 state, 0..623                                    */
+    CS_H_MT_POS = 6,    /* cursor into the circular MT19937 state, 0..623, always even                        */
     CS_H_EPISODES = 7,  /* resets performed                                                                  */
     CS_H_WORDS_LO = 8,  /* 32-bit MT outputs consumed since cs_seed (u64, lo/hi)                             */
     CS_H_WORDS_HI = 9,

@@ -48,7 +48,7 @@ def test_state_layout_host_only():
     assert L.cs_state_layout(C.byref(cfg), C.byref(lay)) == 0
     B = 4096
     assert lay.tgt_off == 0 and lay.agent_off == B * 256 and lay.hdr_off == lay.agent_off + B * 256
-    assert lay.mt_off == lay.hdr_off + B * 64 and lay.total_bytes == lay.mt_off + B * 624 * 4
+    assert lay.mt_off == lay.hdr_off + B * 64 and lay.total_bytes == lay.mt_off + B * 640 * 4
     cfg = _cfg(env="flight", n_agents=3, batch=8192)
     assert L.cs_state_layout(C.byref(cfg), C.byref(lay)) == 0
     assert lay.total_bytes == lay.prob_off + 8192 * 2500 * 4
