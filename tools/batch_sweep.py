@@ -1,0 +1,23 @@
+"""Batch sweep of the flight_easy rollout kernels (SURVEY.md section 8d asks for 2^12..2^22): env-steps/s and the
+algorithmic-bytes roofline fraction per batch size, group vs lane kernel.  Writes a markdown table."""
+import json, subprocess, sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rows = []
+for n in (3, 5):
+    for logb in range(10, 21, 2):
+        B = 1 << logb
+        for kernel in ("group", "lane"):
+            if kernel == "group" and B > (1 << 18):
+                continue
+            steps = 400 if B >= (1 << 18) else 1000
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-also",
+                                  "--workload", "c2" if n == 3 else "c3", "--mode", "rollout", "--kernel", kernel,
+                                  "--batch", str(B), "--steps", str(steps), "--warmup", "100"],
+                                 capture_output=True, text=True).stdout.strip().splitlines()[-1]
+            d = json.loads(out)
+            rows.append((n, B, kernel, d["value"], d["ms_per_step"] * 1e3, d["roofline"]["frac"]))
+            print(rows[-1], flush=True)
+print("\n| agents | batch | kernel | env-steps/s | us per step | algorithmic GB/s / 8000 |")
+print("|---|---|---|---|---|---|")
+for n, B, k, v, us, f in rows:
+    print(f"| {n} | {B} | {k} | {v:.3e} | {us:.2f} | {100*f:.1f} % |")
