@@ -340,6 +340,84 @@ def test_flight_full_size_smoke_properties():
     assert torch.equal(obs[:, :, 2500:], env.get_state()[:, :4 * n].reshape(B, n, 4))
 
 
+def _custom_args(variant, **kw):
+    args = cs.make_env_args(variant, n_agents=kw.pop("n_agents", 3), agent_mode=kw.pop("agent_mode", 0),
+                            target_mode=kw.pop("target_mode", 0))
+    for k, v in kw.items():
+        setattr(args, k, v)
+    return args
+
+
+@pytest.mark.parametrize("kernel", ["group", "lane"])
+@pytest.mark.parametrize("variant,kw", [
+    ("flight_easy", dict(n_agents=8, target_num=16, target_mode=1)),             # maximum sizes: 8 x 16 pairs, 2-phase draws
+    ("flight_easy", dict(n_agents=7, target_num=16, target_mode=1, view_range=30)),  # nearly every pair in range: > 7 draws/step
+    ("flight_easy", dict(n_agents=2, target_num=1, target_mode=1)),              # a single target
+    ("flight_easy", dict(n_agents=3, detect_prob=1.0)),                          # every in-range pair detects
+    ("flight_easy", dict(n_agents=3, detect_prob=0.0)),                          # draws consumed, nothing found (U <= 0 never... only U == 0)
+    ("flight_easy", dict(n_agents=4, map_size=20, view_range=3, agent_mode=1)),  # small map: agents crowd, force + walls every step
+    ("flight_easy", dict(n_agents=5, agent_velocity=2, force_dist=6, safe_dist=2, agent_mode=2)),
+    ("flight_easy", dict(n_agents=3, time_limit=7)),                             # many episode boundaries
+])
+def test_unusual_configurations_match_oracle(variant, kw, kernel):
+    B, T, kw = 96, 90, dict(kw)
+    args = _custom_args(variant, **kw)
+    n, m = args.n_agents, args.target_num
+    seeds = np.arange(B, dtype=np.uint32) * 3 + 11
+    env = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, freeze_done=False, auto_reset=True, kernel=kernel)
+    env.seed(seeds)
+    env.reset(init=True)
+    cfg = orc.make_config(variant=variant, n_agents=n, n_targets=m, agent_mode=args.agent_mode, target_mode=args.target_mode,
+                          map_size=args.map_size, view_range=args.view_range, time_limit=args.time_limit,
+                          velocity=float(args.agent_velocity), safe_dist=float(args.safe_dist),
+                          detect_prob=float(args.detect_prob), force_dist=float(args.force_dist))
+    rng = np.random.RandomState(2)
+    with orc.hip_equivalent_arithmetic():
+        ob = orc.OracleBatch(cfg, B, seeds)
+        ob.reset(init=True, threads=8)
+        compare_with_oracle(env, ob, B, n, m, "reset")
+        for t in range(T):
+            a = rng.randint(0, 3, size=(B, n)).astype(np.int32)
+            r, term, win = env.step(torch.from_numpy(a))
+            orr, ot, ow = ob.step(a, auto_reset=True, freeze_done=False, threads=8)
+            np.testing.assert_array_equal(r.cpu().numpy(), orr, err_msg=f"reward step {t}")
+            np.testing.assert_array_equal(term.cpu().numpy().astype(np.uint8), ot, err_msg=f"terminated step {t}")
+            np.testing.assert_array_equal(win.cpu().numpy().astype(np.uint8), ow, err_msg=f"win step {t}")
+            np.testing.assert_allclose(env.get_state().cpu().numpy(), ob.state, rtol=0, atol=F32_TOL)
+        compare_with_oracle(env, ob, B, n, m, "final")
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n_agents=3, map_size=20, view_range=4, agent_mode=1),
+    dict(n_agents=4, map_size=62, view_range=9, agent_mode=3),      # largest map the u64 lattice rows allow
+    dict(n_agents=2, map_size=50, view_range=7, detect_prob=1.0, agent_mode=2),
+    dict(n_agents=8, map_size=30, view_range=5, target_num=16, target_mode=1),
+])
+def test_flight_unusual_configurations_match_oracle(kw):
+    B, T, kw = 12, 45, dict(kw)
+    args = _custom_args("flight", **kw)
+    n, m, L = args.n_agents, args.target_num, args.map_size
+    seeds = np.arange(B, dtype=np.uint32) + 400
+    env = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, freeze_done=False, auto_reset=True)
+    env.seed(seeds)
+    env.reset(init=True)
+    cfg = orc.make_config(variant="flight", n_agents=n, n_targets=m, agent_mode=args.agent_mode, target_mode=args.target_mode,
+                          map_size=L, view_range=args.view_range, detect_prob=float(args.detect_prob))
+    rng = np.random.RandomState(4)
+    with orc.hip_equivalent_arithmetic():
+        ob = orc.OracleBatch(cfg, B, seeds)
+        ob.reset(init=True, threads=8)
+        for t in range(T):
+            a = rng.randint(0, 3, size=(B, n)).astype(np.int32)
+            r, term, win = env.step(torch.from_numpy(a))
+            orr, ot, ow = ob.step(a, auto_reset=True, freeze_done=False, threads=8)
+            np.testing.assert_array_equal(r.cpu().numpy(), orr, err_msg=f"reward step {t}")
+            if t % 5 == 4 or t == T - 1:
+                np.testing.assert_allclose(env.get_obs().cpu().numpy(), ob.obs, rtol=0, atol=F32_TOL,
+                                           err_msg=f"obs (map + feats) step {t}")
+        compare_with_oracle(env, ob, B, n, m, "flight final")
+
+
 def test_b1_adapter_runs_a_rollout_shaped_loop():
     """BASELINE config 1: the reference-typed B = 1 adapter driven like common/rollout.py:43-76."""
     meta, z = load_trace("easy_n3_am0_s0_a1")
