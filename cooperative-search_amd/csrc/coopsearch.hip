@@ -406,15 +406,35 @@ __device__ __forceinline__ void kinematics(const DevParams &p, const double *T, 
     e.flags = (e.flags & ~0xff00) | (int)(out << 8);
 }
 
+// Per-wavefront LDS staging tile for the group kernels: the 4 envs of a wavefront deposit their get_state rows,
+// obs features and step outputs here, then all 64 lanes write them out as contiguous dwords.  Every global store
+// of a step is thereby unconditional and sits in one straight-line block, so the compiler's vmcnt bookkeeping is
+// exact and a prefetched load is never waited for together with the step's own stores.
+constexpr int TILE_W = 4 * CS_MAX_AGENTS + 3 * CS_MAX_TARGETS;  // widest get_state row (80 floats)
+struct WaveTile {
+    float row[4][TILE_W];
+    float reward[4];
+    int term[4], win[4];
+    int pad[4];
+    double2 trig[4][2 * CS_MAX_AGENTS];  // (sin, cos) of the 2n headings of a step, per group (kinematics_group)
+};
+
 // ---------------------------------------------------------------------------------------------------------
-// Group version of phase 1: the 2n heading evaluations of a step (new heading and its wall reflection, per agent)
-// are spread over the group's lanes -- lane 2i takes agent i's heading, lane 2i+1 its reflection -- and the
-// sin/cos pairs are broadcast with wave shuffles, instead of every lane evaluating all 2n (2n <= 16 = lanes).
-// Phase 2 is the same sequential code as in kinematics().
+// Group version of the kinematics.
+//  * The 2n heading evaluations of a step (new heading and its wall reflection, per agent) are spread over the
+//    group's lanes -- lane 2i takes agent i's heading, lane 2i+1 its reflection -- and published through the
+//    wavefront's LDS tile, instead of every lane evaluating all 2n (2n <= 16 = lanes).
+//  * Fast path: the repulsion is zero unless two agents are within force_dist (3-14 % of env-steps), so all agents
+//    are first moved as if it were zero -- branch-free, all agents in parallel -- and every ordered pair (i, j) is
+//    then tested exactly as the reference would test it (agent i's PRE-move position against j's already-moved
+//    position if j < i, else j's old one).  If no pair is in range the reference's sequential loop would have
+//    added f = 0 everywhere and the tentative result IS its result (x + 0.0 kept, so even signed zeros agree);
+//    otherwise the group falls back to the sequential code.  Operation order per coordinate is the reference's:
+//    (x + v*cos) + f_x.
 // ---------------------------------------------------------------------------------------------------------
 template <int N, int VARIANT>
-__device__ __forceinline__ void kinematics_group(const DevParams &p, const double *T, const int (&act)[N], int t,
-                                                 Env<N> &e) {
+__device__ __forceinline__ void kinematics_group(const DevParams &p, const double *T, WaveTile &tile, const int (&act)[N],
+                                                 int t, int grp, Env<N> &e) {
     const double PI = 3.141592653589793, TWO_PI = 2.0 * 3.141592653589793, THREE_PI = 3.0 * 3.141592653589793;
     const double DYAW = 3.141592653589793 / 18.0;
     double yw[N], yr[N];
@@ -430,34 +450,80 @@ __device__ __forceinline__ void kinematics_group(const DevParams &p, const doubl
     }
     double ms, mc;
     trig_heading(T, mine, ms, mc);
-    unsigned out = 0;
+    if (t < 2 * N) tile.trig[grp][t] = make_double2(ms, mc);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double s1[N], c1[N], s2[N], c2[N];
 #pragma unroll
     for (int i = 0; i < N; i++) {
-        const double s1 = __shfl(ms, 2 * i, G), c1 = __shfl(mc, 2 * i, G);
-        const double s2 = __shfl(ms, 2 * i + 1, G), c2 = __shfl(mc, 2 * i + 1, G);
-        const double x0 = e.ax[i], y0 = e.ay[i];
-        double fx = 0.0, fy = 0.0;
+        const double2 a = tile.trig[grp][2 * i], r = tile.trig[grp][2 * i + 1];
+        s1[i] = a.x; c1[i] = a.y; s2[i] = r.x; c2[i] = r.y;
+    }
+    // ---- tentative move of every agent with zero repulsion
+    double xf[N], yf[N];
+    bool hitf[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const double x = (e.ax[i] + p.velocity * c1[i]) + 0.0;
+        const double y = (e.ay[i] + p.velocity * s1[i]) + 0.0;
+        const bool hit = VARIANT == 1 ? ((x < 0.0) | (x >= p.L) | (y < 0.0) | (y >= p.L))   // flight_env.py:328
+                                      : ((x < 0.0) | (x > p.L) | (y < 0.0) | (y > p.L));    // flight_env_easy.py:278
+        xf[i] = hit ? fmin(fmax(x, 0.0), p.L) : x;
+        yf[i] = hit ? fmin(fmax(y, 0.0), p.L) : y;
+        hitf[i] = hit;
+    }
+    // ---- would the reference have found any pair within force_dist?  (n >= 5: the fallback would run on ~45 % of
+    // wavefront-steps, so larger teams go straight to the sequential loop)
+    bool need = N > 4;
+#pragma unroll
+    for (int i = 0; i < (N > 4 ? 0 : N); i++) {
 #pragma unroll
         for (int j = 0; j < N; j++) {
             if (j == i) continue;
-            double xa = e.ax[j], ya = e.ay[j];  // already moved if j < i
-            double d2 = (xa - x0) * (xa - x0) + (ya - y0) * (ya - y0);
-            if (d2 < p.force_d2 && (xa != x0 || ya != y0)) {
-                double den = (x0 - xa) * (x0 - xa) + (y0 - ya) * (y0 - ya);
-                fx += p.force_k * (x0 - xa) / den;
-                fy += p.force_k * (y0 - ya) / den;
-            }
+            const double xa = j < i ? xf[j] : e.ax[j], ya = j < i ? yf[j] : e.ay[j];
+            const double dx = xa - e.ax[i], dy = ya - e.ay[i];
+            need = need | ((dx * dx + dy * dy < p.force_d2) & ((xa != e.ax[i]) | (ya != e.ay[i])));
         }
-        double x = (x0 + p.velocity * c1) + fx;
-        double y = (y0 + p.velocity * s1) + fy;
-        const bool hit = VARIANT == 1 ? (x < 0.0 || x >= p.L || y < 0.0 || y >= p.L)   // flight_env.py:328
-                                      : (x < 0.0 || x > p.L || y < 0.0 || y > p.L);    // flight_env_easy.py:278
-        e.ax[i] = hit ? fmin(fmax(x, 0.0), p.L) : x;
-        e.ay[i] = hit ? fmin(fmax(y, 0.0), p.L) : y;
-        e.yaw[i] = hit ? yr[i] : yw[i];
-        e.cs[i] = hit ? c2 : c1;
-        e.sn[i] = hit ? s2 : s1;
-        out |= hit ? (1u << i) : 0u;
+    }
+    unsigned out = 0;
+    if (!need) {
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            e.ax[i] = xf[i];
+            e.ay[i] = yf[i];
+            e.yaw[i] = hitf[i] ? yr[i] : yw[i];
+            e.cs[i] = hitf[i] ? c2[i] : c1[i];
+            e.sn[i] = hitf[i] ? s2[i] : s1[i];
+            out |= hitf[i] ? (1u << i) : 0u;
+        }
+    } else {  // the reference's sequential loop (quirk Q7)
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const double x0 = e.ax[i], y0 = e.ay[i];
+            double fx = 0.0, fy = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                if (j == i) continue;
+                double xa = e.ax[j], ya = e.ay[j];  // already moved if j < i
+                double d2 = (xa - x0) * (xa - x0) + (ya - y0) * (ya - y0);
+                if (d2 < p.force_d2 && (xa != x0 || ya != y0)) {
+                    double den = (x0 - xa) * (x0 - xa) + (y0 - ya) * (y0 - ya);
+                    fx += p.force_k * (x0 - xa) / den;
+                    fy += p.force_k * (y0 - ya) / den;
+                }
+            }
+            double x = (x0 + p.velocity * c1[i]) + fx;
+            double y = (y0 + p.velocity * s1[i]) + fy;
+            const bool hit = VARIANT == 1 ? (x < 0.0 || x >= p.L || y < 0.0 || y >= p.L)
+                                          : (x < 0.0 || x > p.L || y < 0.0 || y > p.L);
+            e.ax[i] = hit ? fmin(fmax(x, 0.0), p.L) : x;
+            e.ay[i] = hit ? fmin(fmax(y, 0.0), p.L) : y;
+            e.yaw[i] = hit ? yr[i] : yw[i];
+            e.cs[i] = hit ? c2[i] : c1[i];
+            e.sn[i] = hit ? s2[i] : s1[i];
+            out |= hit ? (1u << i) : 0u;
+        }
     }
     e.flags = (e.flags & ~0xff00) | (int)(out << 8);
 }
@@ -586,17 +652,14 @@ __device__ __forceinline__ void emit(const DevParams &p, int t, const Env<N> &e,
     }
 }
 
-// Per-wavefront LDS staging tile for the group kernels: the 4 envs of a wavefront deposit their get_state rows,
-// obs features and step outputs here, then all 64 lanes write them out as contiguous dwords.  Every global store
-// of a step is thereby unconditional and sits in one straight-line block, so the compiler's vmcnt bookkeeping is
-// exact and a prefetched load is never waited for together with the step's own stores.
-constexpr int TILE_W = 4 * CS_MAX_AGENTS + 3 * CS_MAX_TARGETS;  // widest get_state row (80 floats)
-struct WaveTile {
-    float row[4][TILE_W];
-    float reward[4];
-    int term[4], win[4];
-    int pad[4];
-};
+#ifdef CS_TIMELINE
+// debug build only: per-stage s_memtime stamps of wavefront 0 / block 0 (tools/exp_timeline.py)
+__device__ unsigned long long g_stamps[64][16];
+#define CS_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && g_tl_step >= 0 && g_tl_step < 64) g_stamps[g_tl_step][k] = __builtin_readcyclecounter(); } while (0)
+__device__ int g_tl_step_dummy;
+#else
+#define CS_STAMP(k) do {} while (0)
+#endif
 
 struct StepIO {
     const void *actions;  // [T][B][N] int32 / int64
@@ -615,11 +678,45 @@ __device__ __forceinline__ void load_actions(const StepIO &io, size_t row, int (
     for (int i = 0; i < N; i++) act[i] = a[i * stride];
 }
 
-// Wave-level write-out of one step (see WaveTile).  slot0 = output slot of the wavefront's first env, nvalid =
-// number of its envs that exist (1..4).  Called by all 64 lanes.
+// Loop-invariant part of the wave-level write-out: which tile element / output dword each lane moves.
 template <int N>
-__device__ __forceinline__ void emit_wave(const DevParams &p, const StepIO &io, WaveTile &tile, int lane, int t, int grp,
-                                          bool live, const Env<N> &e, int reward, bool term, size_t slot0, int nvalid) {
+struct EmitPlan {
+    static constexpr int K = (4 * (4 * N + 3 * CS_MAX_TARGETS) + 63) / 64;
+    int st_lds[K];   // float index into tile.row (flattened [4][TILE_W])
+    int st_out[K];   // dword index relative to state_out + slot0 * W
+    int obs_lds;     // float index of this lane's float4 in tile.row
+    int obs_out;     // float index relative to obs + slot0 * N * obs_w
+    int rtw;         // env (0..3) whose reward / terminated / win this lane writes
+};
+
+template <int N>
+__device__ __forceinline__ EmitPlan<N> make_emit_plan(const DevParams &p, int lane, int nvalid) {
+    EmitPlan<N> pl;
+    const int W = 4 * N + 3 * p.n_targets;
+    const int total = nvalid * W;
+    const float inv_w = 1.0f / (float)W;
+#pragma unroll
+    for (int k = 0; k < EmitPlan<N>::K; k++) {
+        int idx = lane + 64 * k;
+        idx = idx < total ? idx : total - 1;  // surplus lanes repeat the last element (same value, same address)
+        const int r = (int)(((float)idx + 0.5f) * inv_w);
+        pl.st_lds[k] = r * TILE_W + (idx - r * W);
+        pl.st_out[k] = idx;
+    }
+    const int l = lane < nvalid * N ? lane : nvalid * N - 1;
+    const int r = l / N, i = l - r * N;
+    const int obs_w = p.variant == 1 ? p.cells + 4 : 4;
+    pl.obs_lds = r * TILE_W + 4 * i;
+    pl.obs_out = (r * N + i) * obs_w + (p.variant == 1 ? p.cells : 0);
+    pl.rtw = (lane & 3) < nvalid ? (lane & 3) : nvalid - 1;
+    return pl;
+}
+
+// Wave-level write-out of one step (see WaveTile).  slot0 = output slot of the wavefront's first env.  Called by
+// all 64 lanes.
+template <int N>
+__device__ __forceinline__ void emit_wave(const DevParams &p, const StepIO &io, WaveTile &tile, const EmitPlan<N> &pl,
+                                          int t, int grp, bool live, const Env<N> &e, int reward, bool term, size_t slot0) {
     if (live) {
 #pragma unroll
         for (int i = 0; i < N; i++)
@@ -641,32 +738,18 @@ __device__ __forceinline__ void emit_wave(const DevParams &p, const StepIO &io, 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int W = 4 * N + 3 * p.n_targets;
-    {   // reward / terminated / win: lane -> env (lane & 3), duplicates write the same value
-        const int r = (lane & 3) < nvalid ? (lane & 3) : nvalid - 1;
-        io.reward[slot0 + r] = tile.reward[r];
-        io.terminated[slot0 + r] = (uint8_t)tile.term[r];
-        io.win[slot0 + r] = (uint8_t)tile.win[r];
-    }
+    const float *flat = &tile.row[0][0];
+    io.reward[slot0 + pl.rtw] = tile.reward[pl.rtw];  // duplicates write the same value
+    io.terminated[slot0 + pl.rtw] = (uint8_t)tile.term[pl.rtw];
+    io.win[slot0 + pl.rtw] = (uint8_t)tile.win[pl.rtw];
     if (io.obs) {  // one float4 per (env, agent)
-        const int l = lane < nvalid * N ? lane : nvalid * N - 1;
-        const int r = l / N, i = l - r * N;
         const size_t obs_w = p.variant == 1 ? (size_t)p.cells + 4 : 4;
-        const size_t off = ((slot0 + r) * N + i) * obs_w + (p.variant == 1 ? p.cells : 0);
-        *reinterpret_cast<float4 *>(io.obs + off) = *reinterpret_cast<const float4 *>(&tile.row[r][4 * i]);
+        *reinterpret_cast<float4 *>(io.obs + slot0 * N * obs_w + pl.obs_out) = *reinterpret_cast<const float4 *>(flat + pl.obs_lds);
     }
-    if (io.state) {  // the nvalid rows are contiguous in get_state's [B][W] layout
-        const int total = nvalid * W;
-        const float inv_w = 1.0f / (float)W;
-        float *dst = io.state + slot0 * W;
-        constexpr int K = (4 * (4 * N + 3 * CS_MAX_TARGETS) + 63) / 64;
+    if (io.state) {  // the wavefront's rows are contiguous in get_state's [B][W] layout
+        float *dst = io.state + slot0 * (size_t)(4 * N + 3 * p.n_targets);
 #pragma unroll
-        for (int k = 0; k < K; k++) {
-            int idx = lane + 64 * k;
-            idx = idx < total ? idx : total - 1;
-            const int r = (int)(((float)idx + 0.5f) * inv_w);
-            dst[idx] = tile.row[r][idx - r * W];
-        }
+        for (int k = 0; k < EmitPlan<N>::K; k++) dst[pl.st_out[k]] = flat[pl.st_lds[k]];
     }
     __builtin_amdgcn_wave_barrier();  // the tile is rewritten by the next step
 }
@@ -675,11 +758,15 @@ __device__ __forceinline__ void emit_wave(const DevParams &p, const StepIO &io, 
 // e.mt_pos (both already loaded); called by all 64 lanes of the wavefront (`live` = the lane's env exists).
 template <int N, int VARIANT>
 __device__ __forceinline__ void step_once(const DevParams &p, const double *T, const StepIO &io, WaveTile &tile, int b,
-                                          int lane, size_t slot0, int nvalid, bool live, const int (&act)[N],
+                                          int lane, size_t slot0, const EmitPlan<N> &plan, bool live, const int (&act)[N],
                                           MtWin &win, bool prefetch_next, Env<N> &e) {
     const int t = lane & (G - 1), grp = lane >> 4, gshift = lane & ~(G - 1);
     int reward = 0;
     bool term = true;
+#ifdef CS_TIMELINE
+    const int g_tl_step = (int)(slot0 / (size_t)p.B);
+#endif
+    CS_STAMP(0);
     if (live) {
         bool done = e.target_find >= p.n_targets || e.time_step >= p.time_limit;
         e.flags &= ~(FLAG_DIRTY | FLAG_RESET_PASS);  // pending-map-update flags describe THIS launch only
@@ -695,8 +782,11 @@ __device__ __forceinline__ void step_once(const DevParams &p, const double *T, c
             done = false;
         }
         if (!(done && (io.flags & CS_FREEZE_DONE))) {
-            kinematics_group<N, VARIANT>(p, T, act, t, e);
+            CS_STAMP(1);
+            kinematics_group<N, VARIANT>(p, T, tile, act, t, grp, e);
+            CS_STAMP(2);
             reward = detect_pass<N>(p, b, t, gshift, e, win);
+            CS_STAMP(3);
             e.total_reward += reward;
             e.time_step += 1;
             term = e.target_find >= p.n_targets || e.time_step >= p.time_limit;
@@ -706,7 +796,9 @@ __device__ __forceinline__ void step_once(const DevParams &p, const double *T, c
         // the next step's window does not overlap the words just committed: request it before this step's stores
         if (prefetch_next) win = mt_prefetch(p.mt + (size_t)b * MT_STRIDE, e.mt_pos, t);
     }
-    emit_wave<N>(p, io, tile, lane, t, grp, live, e, reward, term, slot0, nvalid);
+    CS_STAMP(4);
+    emit_wave<N>(p, io, tile, plan, t, grp, live, e, reward, term, slot0);
+    CS_STAMP(5);
 }
 
 template <int N, int VARIANT>
@@ -730,7 +822,8 @@ __global__ __launch_bounds__(BLOCK) void k_step(DevParams p, StepIO io) {
     const int nvalid = p.B - wave_b0 < 4 ? p.B - wave_b0 : 4;
     MtWin win = {0u, 0u};
     if (live) win = mt_prefetch(p.mt + (size_t)b * MT_STRIDE, e.mt_pos, t);
-    step_once<N, VARIANT>(p, T, io, tiles[threadIdx.x >> 6], b, lane, (size_t)wave_b0, nvalid, live, act, win, false, e);
+    const EmitPlan<N> plan = make_emit_plan<N>(p, lane, nvalid);
+    step_once<N, VARIANT>(p, T, io, tiles[threadIdx.x >> 6], b, lane, (size_t)wave_b0, plan, live, act, win, false, e);
     if (live) env_store<N>(p, b, t, e, false);
 }
 
@@ -755,13 +848,14 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(DevParams p, StepIO io) {
     if (wave_b0 >= p.B) return;
     const int nvalid = p.B - wave_b0 < 4 ? p.B - wave_b0 : 4;
     WaveTile &tile = tiles[threadIdx.x >> 6];
+    const EmitPlan<N> plan = make_emit_plan<N>(p, lane, nvalid);
     MtWin win = {0u, 0u};
     if (live) win = mt_prefetch(p.mt + (size_t)b * MT_STRIDE, e.mt_pos, t);
     for (int s = 0; s < io.T; s++) {
         int act_next[N];
         const int sn = s + 1 < io.T ? s + 1 : s;
         load_actions<N>(io, (size_t)sn * p.B + (live ? b : 0), act_next);
-        step_once<N, 0>(p, T, io, tile, b, lane, (size_t)s * p.B + wave_b0, nvalid, live, act, win, s + 1 < io.T, e);
+        step_once<N, 0>(p, T, io, tile, b, lane, (size_t)s * p.B + wave_b0, plan, live, act, win, s + 1 < io.T, e);
 #pragma unroll
         for (int i = 0; i < N; i++) act[i] = act_next[i];
     }
@@ -1550,5 +1644,12 @@ int cs_metrics(const cs_config *cfg, void *state_dev, double *out4_dev, void *st
     hipLaunchKernelGGL(k_metrics, dim3((p.B + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, out4_dev);
     return launched("cs_metrics");
 }
+
+#ifdef CS_TIMELINE
+int cs_debug_read_stamps(unsigned long long *host64x16) {
+    hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(host64x16, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64 * 16);
+}
+#endif
 
 }  // extern "C"
