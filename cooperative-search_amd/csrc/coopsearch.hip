@@ -712,11 +712,14 @@ __device__ __forceinline__ EmitPlan<N> make_emit_plan(const DevParams &p, int la
     return pl;
 }
 
-// Wave-level write-out of one step (see WaveTile).  slot0 = output slot of the wavefront's first env.  Called by
-// all 64 lanes.
+// Wave-level write-out of one step (see WaveTile), in two halves so that the rollout loop can overlap the LDS round
+// trip and the stores of step s with the arithmetic of step s+1:
+//   emit_deposit: every live lane writes its pieces of step s into the tile (end of step s);
+//   emit_flush:   all 64 lanes read the tile back and store it (called at the start of step s+1, or right away by
+//                 the single-step kernel).  slot0 = output slot of the wavefront's first env for the deposited step.
 template <int N>
-__device__ __forceinline__ void emit_wave(const DevParams &p, const StepIO &io, WaveTile &tile, const EmitPlan<N> &pl,
-                                          int t, int grp, bool live, const Env<N> &e, int reward, bool term, size_t slot0) {
+__device__ __forceinline__ void emit_deposit(const DevParams &p, WaveTile &tile, int t, int grp, bool live, const Env<N> &e,
+                                             int reward, bool term) {
     if (live) {
 #pragma unroll
         for (int i = 0; i < N; i++)
@@ -737,21 +740,43 @@ __device__ __forceinline__ void emit_wave(const DevParams &p, const StepIO &io, 
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+}
+
+template <int N>
+struct FlushRegs {
+    float st[EmitPlan<N>::K];
+    float4 obs;
+    float reward;
+    int term, win;
+};
+
+template <int N>
+__device__ __forceinline__ void emit_flush_load(const WaveTile &tile, const EmitPlan<N> &pl, FlushRegs<N> &f) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const float *flat = &tile.row[0][0];
-    io.reward[slot0 + pl.rtw] = tile.reward[pl.rtw];  // duplicates write the same value
-    io.terminated[slot0 + pl.rtw] = (uint8_t)tile.term[pl.rtw];
-    io.win[slot0 + pl.rtw] = (uint8_t)tile.win[pl.rtw];
+    f.reward = tile.reward[pl.rtw];
+    f.term = tile.term[pl.rtw];
+    f.win = tile.win[pl.rtw];
+    f.obs = *reinterpret_cast<const float4 *>(flat + pl.obs_lds);
+#pragma unroll
+    for (int k = 0; k < EmitPlan<N>::K; k++) f.st[k] = flat[pl.st_lds[k]];
+}
+
+template <int N>
+__device__ __forceinline__ void emit_flush_store(const DevParams &p, const StepIO &io, const EmitPlan<N> &pl,
+                                                 const FlushRegs<N> &f, size_t slot0) {
+    io.reward[slot0 + pl.rtw] = f.reward;  // duplicates write the same value
+    io.terminated[slot0 + pl.rtw] = (uint8_t)f.term;
+    io.win[slot0 + pl.rtw] = (uint8_t)f.win;
     if (io.obs) {  // one float4 per (env, agent)
         const size_t obs_w = p.variant == 1 ? (size_t)p.cells + 4 : 4;
-        *reinterpret_cast<float4 *>(io.obs + slot0 * N * obs_w + pl.obs_out) = *reinterpret_cast<const float4 *>(flat + pl.obs_lds);
+        *reinterpret_cast<float4 *>(io.obs + slot0 * N * obs_w + pl.obs_out) = f.obs;
     }
     if (io.state) {  // the wavefront's rows are contiguous in get_state's [B][W] layout
         float *dst = io.state + slot0 * (size_t)(4 * N + 3 * p.n_targets);
 #pragma unroll
-        for (int k = 0; k < EmitPlan<N>::K; k++) dst[pl.st_out[k]] = flat[pl.st_lds[k]];
+        for (int k = 0; k < EmitPlan<N>::K; k++) dst[pl.st_out[k]] = f.st[k];
     }
-    __builtin_amdgcn_wave_barrier();  // the tile is rewritten by the next step
 }
 
 // One env.step for the group's env, state in registers.  `act` are this step's actions, `win` the MT window at
@@ -759,10 +784,14 @@ __device__ __forceinline__ void emit_wave(const DevParams &p, const StepIO &io, 
 template <int N, int VARIANT>
 __device__ __forceinline__ void step_once(const DevParams &p, const double *T, const StepIO &io, WaveTile &tile, int b,
                                           int lane, size_t slot0, const EmitPlan<N> &plan, bool live, const int (&act)[N],
-                                          MtWin &win, bool prefetch_next, Env<N> &e) {
+                                          MtWin &win, bool prefetch_next, bool flush_prev, size_t prev_slot0,
+                                          bool defer_flush, Env<N> &e) {
     const int t = lane & (G - 1), grp = lane >> 4, gshift = lane & ~(G - 1);
     int reward = 0;
     bool term = true;
+    // the previous step's rows: LDS reads now, global stores after this step's arithmetic
+    FlushRegs<N> fr;
+    if (flush_prev) emit_flush_load<N>(tile, plan, fr);
 #ifdef CS_TIMELINE
     const int g_tl_step = (int)(slot0 / (size_t)p.B);
 #endif
@@ -797,7 +826,12 @@ __device__ __forceinline__ void step_once(const DevParams &p, const double *T, c
         if (prefetch_next) win = mt_prefetch(p.mt + (size_t)b * MT_STRIDE, e.mt_pos, t);
     }
     CS_STAMP(4);
-    emit_wave<N>(p, io, tile, plan, t, grp, live, e, reward, term, slot0);
+    if (flush_prev) emit_flush_store<N>(p, io, plan, fr, prev_slot0);
+    emit_deposit<N>(p, tile, t, grp, live, e, reward, term);
+    if (!defer_flush) {
+        emit_flush_load<N>(tile, plan, fr);
+        emit_flush_store<N>(p, io, plan, fr, slot0);
+    }
     CS_STAMP(5);
 }
 
@@ -823,7 +857,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(DevParams p, StepIO io) {
     MtWin win = {0u, 0u};
     if (live) win = mt_prefetch(p.mt + (size_t)b * MT_STRIDE, e.mt_pos, t);
     const EmitPlan<N> plan = make_emit_plan<N>(p, lane, nvalid);
-    step_once<N, VARIANT>(p, T, io, tiles[threadIdx.x >> 6], b, lane, (size_t)wave_b0, plan, live, act, win, false, e);
+    step_once<N, VARIANT>(p, T, io, tiles[threadIdx.x >> 6], b, lane, (size_t)wave_b0, plan, live, act, win, false, false, 0, false, e);
     if (live) env_store<N>(p, b, t, e, false);
 }
 
@@ -849,15 +883,23 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(DevParams p, StepIO io) {
     const int nvalid = p.B - wave_b0 < 4 ? p.B - wave_b0 : 4;
     WaveTile &tile = tiles[threadIdx.x >> 6];
     const EmitPlan<N> plan = make_emit_plan<N>(p, lane, nvalid);
+    constexpr bool PIPE = N <= 4;
     MtWin win = {0u, 0u};
     if (live) win = mt_prefetch(p.mt + (size_t)b * MT_STRIDE, e.mt_pos, t);
     for (int s = 0; s < io.T; s++) {
         int act_next[N];
         const int sn = s + 1 < io.T ? s + 1 : s;
         load_actions<N>(io, (size_t)sn * p.B + (live ? b : 0), act_next);
-        step_once<N, 0>(p, T, io, tile, b, lane, (size_t)s * p.B + wave_b0, plan, live, act, win, s + 1 < io.T, e);
+        // n <= 4: the rows of step s are stored while step s+1 computes (costs ~12 VGPRs; larger teams have none spare)
+        step_once<N, 0>(p, T, io, tile, b, lane, (size_t)s * p.B + wave_b0, plan, live, act, win, s + 1 < io.T,
+                        PIPE && s > 0, (size_t)(s - 1) * p.B + wave_b0, PIPE, e);
 #pragma unroll
         for (int i = 0; i < N; i++) act[i] = act_next[i];
+    }
+    if (PIPE) {  // rows of the last step
+        FlushRegs<N> fr;
+        emit_flush_load<N>(tile, plan, fr);
+        emit_flush_store<N>(p, io, plan, fr, (size_t)(io.T - 1) * p.B + wave_b0);
     }
     if (live) env_store<N>(p, b, t, e, false);
 }
