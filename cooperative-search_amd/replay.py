@@ -30,17 +30,15 @@ class DeviceReplayBuffer:
         self.buffers = {k: torch.empty(shapes[k], dtype=dtype, device=self.device) for k in KEYS}
 
     def _get_storage_idx(self, inc=None):
+        """Ring positions for the next `inc` episodes.  Same sequence as the reference's three-case rule
+        (replay_buffer.py:84-101), written as modular arithmetic: writing starts at the cursor (or at 0 when the cursor
+        sits exactly at `size`, which the reference leaves un-wrapped after an exact fill), wraps modulo `size`, and the
+        cursor ends one past the last written slot -- again left at `size` rather than 0 after an exact fill."""
         inc = inc or 1
-        if self.current_idx + inc <= self.size:
-            idx = np.arange(self.current_idx, self.current_idx + inc)
-            self.current_idx += inc
-        elif self.current_idx < self.size:
-            overflow = inc - (self.size - self.current_idx)
-            idx = np.concatenate([np.arange(self.current_idx, self.size), np.arange(0, overflow)])
-            self.current_idx = overflow
-        else:
-            idx = np.arange(0, inc)
-            self.current_idx = inc
+        start = 0 if self.current_idx >= self.size else self.current_idx
+        idx = (start + np.arange(inc)) % self.size
+        end = start + inc
+        self.current_idx = end if end <= self.size else end - self.size
         self.current_size = min(self.size, self.current_size + inc)
         return idx
 
@@ -61,11 +59,9 @@ class DeviceReplayBuffer:
         return {k: v.index_select(0, idx) for k, v in self.buffers.items()}
 
     def latest_indices(self, batch_size):
+        """The `batch_size` most recently stored slots, oldest first (replay_buffer.py:70-79)."""
         assert self.can_sample(batch_size)
-        if self.current_idx >= batch_size:
-            return list(range(self.current_idx - batch_size, self.current_idx))
-        left = batch_size - self.current_idx
-        return list(range(self.current_size - left, self.current_size)) + list(range(self.current_idx))
+        return [(self.current_idx - batch_size + k) % self.current_size for k in range(batch_size)]
 
     def sample_latest(self, batch_size):
         idx = torch.as_tensor(self.latest_indices(batch_size), device=self.device)
