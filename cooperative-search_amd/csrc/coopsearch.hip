@@ -497,20 +497,29 @@ __device__ __forceinline__ void kinematics_group(const DevParams &p, const doubl
             e.sn[i] = hitf[i] ? s2[i] : s1[i];
             out |= hitf[i] ? (1u << i) : 0u;
         }
-    } else {  // the reference's sequential loop (quirk Q7)
+    } else {  // the reference's sequential loop (quirk Q7); one branch per agent: its pairs are tested branch-free first
 #pragma unroll
         for (int i = 0; i < N; i++) {
             const double x0 = e.ax[i], y0 = e.ay[i];
             double fx = 0.0, fy = 0.0;
+            bool any = false;
 #pragma unroll
             for (int j = 0; j < N; j++) {
                 if (j == i) continue;
-                double xa = e.ax[j], ya = e.ay[j];  // already moved if j < i
-                double d2 = (xa - x0) * (xa - x0) + (ya - y0) * (ya - y0);
-                if (d2 < p.force_d2 && (xa != x0 || ya != y0)) {
-                    double den = (x0 - xa) * (x0 - xa) + (y0 - ya) * (y0 - ya);
-                    fx += p.force_k * (x0 - xa) / den;
-                    fy += p.force_k * (y0 - ya) / den;
+                const double dx = e.ax[j] - x0, dy = e.ay[j] - y0;  // e.ax[j] already moved if j < i
+                any = any | ((dx * dx + dy * dy < p.force_d2) & ((e.ax[j] != x0) | (e.ay[j] != y0)));
+            }
+            if (any) {
+#pragma unroll
+                for (int j = 0; j < N; j++) {
+                    if (j == i) continue;
+                    double xa = e.ax[j], ya = e.ay[j];
+                    double d2 = (xa - x0) * (xa - x0) + (ya - y0) * (ya - y0);
+                    if (d2 < p.force_d2 && (xa != x0 || ya != y0)) {
+                        double den = (x0 - xa) * (x0 - xa) + (y0 - ya) * (y0 - ya);
+                        fx += p.force_k * (x0 - xa) / den;
+                        fy += p.force_k * (y0 - ya) / den;
+                    }
                 }
             }
             double x = (x0 + p.velocity * c1[i]) + fx;
