@@ -279,6 +279,39 @@ def test_rollout_kernel_equals_stepwise(kernel):
             assert torch.equal(e1.raw()[k], e2.raw()[k]), k
 
 
+@pytest.mark.parametrize("n", [3, 5])
+def test_group_and_lane_kernels_can_be_interleaved(n):
+    """Both kernels share one state layout (incl. the mirrored head of the MT rows that only the lane kernel reads
+    and every writer must maintain): alternating them step by step -- single steps and short rollouts, with
+    auto-resets -- must reproduce a pure group-kernel run bit for bit."""
+    B, T = 1000, 330
+    args = cs.make_env_args("flight_easy", n_agents=n)
+    args.time_limit = 60   # frequent resets: the reset path writes MT words too
+    seeds = np.arange(B, dtype=np.uint32) + 9000
+    ref = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, freeze_done=False, auto_reset=True, kernel="group")
+    mix = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, freeze_done=False, auto_reset=True, kernel="group")
+    g = torch.Generator("cuda").manual_seed(77)
+    t = 0
+    k = 0
+    while t < T:
+        chunk = (1, 3, 1, 7)[k % 4]
+        mix.kernel = ("lane", "group")[k % 2]
+        a = torch.randint(0, 3, (chunk, B, n), dtype=torch.int32, device="cuda", generator=g)
+        if chunk == 1:
+            r1, t1, w1 = ref.step(a[0])
+            r2, t2, w2 = mix.step(a[0])
+            assert torch.equal(r1, r2) and torch.equal(t1, t2) and torch.equal(w1, w2), f"step {t}"
+        else:
+            o1, o2 = ref.rollout(a), mix.rollout(a)
+            for key in ("reward", "terminated", "win", "obs", "state"):
+                assert torch.equal(o1[key], o2[key]), f"{key} at step {t}"
+        t += chunk
+        k += 1
+    for key in ("tgt", "agent", "hdr", "mt"):
+        assert torch.equal(ref.raw()[key], mix.raw()[key]), key
+    assert hdr(ref)[:, _lib.H_EPISODES].min() >= 5
+
+
 @pytest.mark.parametrize("n,B", [(3, 4096), (5, 16384)])
 def test_full_size_properties_and_shard_invariance(n, B):
     """BASELINE configs 2/3 at full size: domain invariants + bit-exact shard invariance (rank-local halves with
