@@ -479,3 +479,24 @@ def test_b1_adapter_runs_a_rollout_shaped_loop():
         env.step([0, 1])
     with pytest.raises(Exception, match="Agent id out of range"):
         env.get_avail_agent_actions(3)
+
+
+def test_b1_flight_adapter_matches_golden_trace():
+    """FlightSearchEnv (probability-map variant) through the reference-typed B = 1 adapter."""
+    meta, z = load_trace("flight_n3_am3_s3_a2")
+    args = cs.make_env_args("flight", n_agents=3, agent_mode=3)
+    env = cs.FlightSearchEnv(args, cs.load_targets(), seed=meta["seed"])
+    assert env.get_env_info()["obs_shape"] == 4      # quirk Q8: reported as 4 although get_obs is 2504 wide
+    env.seed(meta["seed"])
+    env.reset(init=True)
+    np.testing.assert_allclose(env.prob_map, z["e0_reset_prob_map"], atol=F32_TOL)
+    for t in range(30):
+        obs = env.get_obs()
+        assert obs.shape == (3, 2504) and obs.dtype == np.float64
+        r, term, win = env.step([int(a) for a in z["e0_actions"][t]])
+        assert (r, int(term), int(win)) == (int(z["e0_reward"][t]), int(z["e0_terminated"][t]), int(z["e0_win"][t]))
+        assert env.target_find == int(z["e0_target_find"][t]) and env.out_flag == list(z["e0_out_flag"][t])
+        np.testing.assert_allclose(np.array(env.agent_pos), z["e0_agent_pos"][t], atol=1e-9)
+    m15 = z["e0_prob_maps"][list(z["e0_prob_map_steps"]).index(30)]
+    np.testing.assert_allclose(env.prob_map, m15, atol=F32_TOL)
+    np.testing.assert_allclose(env.get_obs()[0, :2500], m15.reshape(-1), atol=F32_TOL)
