@@ -1,4 +1,6 @@
 """Builds csrc/libcoopsearch_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+import contextlib
+import fcntl
 import os
 import shutil
 import subprocess
@@ -28,6 +30,18 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+@contextlib.contextmanager
+def _build_lock():
+    """One builder at a time (bench.py under torchrun starts N ranks at once); the others wait, then re-check."""
+    path = os.path.join(CSRC, ".build.lock")
+    with open(path, "w") as f:
+        fcntl.flock(f, fcntl.LOCK_EX)
+        try:
+            yield
+        finally:
+            fcntl.flock(f, fcntl.LOCK_UN)
+
+
 def build_extension(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 ... -> csrc/libcoopsearch_hip.so.  -ffp-contract=off is part of the numerics
     contract, not a tuning knob."""
@@ -36,12 +50,16 @@ def build_extension(force=False, verbose=False):
     hipcc = hipcc_path()
     if hipcc is None:
         raise RuntimeError("hipcc not found: cannot build libcoopsearch_hip.so")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-           "-I", os.path.join(ROOT, "include"), os.path.join(CSRC, "coopsearch.hip"), "-o", LIB_PATH + ".tmp"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=CSRC)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    with _build_lock():
+        if not force and not is_stale():  # another process built it while we waited
+            return LIB_PATH
+        tmp = f"{LIB_PATH}.tmp.{os.getpid()}"
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+               "-I", os.path.join(ROOT, "include"), os.path.join(CSRC, "coopsearch.hip"), "-o", tmp]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, cwd=CSRC)
+        os.replace(tmp, LIB_PATH)
     return LIB_PATH
 
 

@@ -8,6 +8,7 @@ this module.  The product package (cooperative-search_amd/) never does.
 ONE environment; `OracleBatch` drives B independent envs (OpenMP over envs).
 """
 import ctypes as C
+import fcntl
 import os
 import subprocess
 
@@ -38,7 +39,12 @@ def build(force=False):
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(
             os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "flight_oracle.h")),
             os.path.getmtime(os.path.join(_HERE, "trig_table.inc"))):
-        subprocess.check_call(["make", "-C", _HERE, "liboracle_flight.so"], stdout=subprocess.DEVNULL)
+        with open(os.path.join(_HERE, ".build.lock"), "w") as lk:  # one builder at a time
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            try:
+                subprocess.check_call(["make", "-C", _HERE, "liboracle_flight.so"], stdout=subprocess.DEVNULL)
+            finally:
+                fcntl.flock(lk, fcntl.LOCK_UN)
     return _LIB_PATH
 
 
