@@ -100,3 +100,21 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, fn)).read()
                 assert "oracle" not in txt.replace("the oracle keeps its own copy", "").replace('"oracle", "trig_table.inc"', ""), \
                     f"{fn} mentions the oracle"
+
+
+def test_c_example_compiles_and_links_against_the_abi(tmp_path):
+    """examples/c_api_demo.cpp is the non-Python consumer of the boundary: it must compile against include/coopsearch.h
+    and link against the built library (it is executed on the GPU box by tests/test_gpu_parity.py)."""
+    import shutil
+    import subprocess
+    from cooperative_search_amd import build
+    hipcc = build.hipcc_path()
+    if hipcc is None:
+        pytest.skip("hipcc not available")
+    _lib.load()
+    out = tmp_path / "c_api_demo"
+    csrc = os.path.dirname(_lib.library_path())
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "c_api_demo.cpp"), "-L", csrc, "-lcoopsearch_hip",
+                           f"-Wl,-rpath,{csrc}", "-o", str(out)])
+    assert out.exists()

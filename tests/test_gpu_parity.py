@@ -500,3 +500,21 @@ def test_b1_flight_adapter_matches_golden_trace():
     m15 = z["e0_prob_maps"][list(z["e0_prob_map_steps"]).index(30)]
     np.testing.assert_allclose(env.prob_map, m15, atol=F32_TOL)
     np.testing.assert_allclose(env.get_obs()[0, :2500], m15.reshape(-1), atol=F32_TOL)
+
+
+def test_c_example_runs_and_reproduces_the_random_policy_statistics(tmp_path):
+    """The plain C++/HIP consumer of the C ABI (no Python, no torch in that process)."""
+    import os, re, subprocess
+    from cooperative_search_amd import build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.dirname(_lib.library_path())
+    exe = tmp_path / "c_api_demo"
+    subprocess.check_call([build.hipcc_path(), "--offload-arch=gfx950", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "c_api_demo.cpp"), "-L", csrc, "-lcoopsearch_hip",
+                           f"-Wl,-rpath,{csrc}", "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    m = re.search(r"episodes (\d+)\s+mean episode_reward (-?[\d.]+)\s+win rate ([\d.]+)\s+mean targets_find ([\d.]+)", out.stdout)
+    assert m, out.stdout
+    assert int(m.group(1)) == 4096
+    assert abs(float(m.group(4)) / 15 * 100 - 84.87) < 3.0     # shipped random-policy figure for 3a15t AM0
