@@ -37,7 +37,7 @@ class EpisodeCollector:
             term = torch.empty(T, B, dtype=torch.bool, device=dev)
             o[0].copy_(env.get_obs())
             s[0].copy_(env.get_state())
-            if actions is not None and not env.flight:
+            if actions is not None and (not env.flight or env.batch * env.time_limit * env.n_agents * env.obs_width * 4 < (8 << 30)):
                 acts = torch.as_tensor(actions, device=dev)
                 out = env.rollout(acts)
                 o[1:].copy_(out["obs"])

@@ -1660,9 +1660,24 @@ int cs_rollout(const cs_config *cfg, void *state_dev, const void *actions_dev, i
     DevParams p;
     int rc = make_params(cfg, state_dev, &p);
     if (rc) return rc;
-    if (cfg->variant != 0) return fail(CS_E_CONFIG, "cs_rollout: flight_easy only (the flight map update is its own kernel)");
     if (T < 1) return fail(CS_E_ARG, "T must be >= 1");
     if (!actions_dev || !reward_dev || !terminated_dev || !win_dev) return fail(CS_E_ARG, "null rollout buffer");
+    if (cfg->variant == 1) {
+        // flight: the map update is its own bandwidth-bound kernel, so a rollout is T (k_step, k_map) pairs enqueued
+        // back to back by this one call, each writing its own [t] slice of the outputs
+        hipStream_t s = (hipStream_t)stream;
+        const size_t n = (size_t)cfg->n_agents, W = 4 * n + 3 * (size_t)cfg->n_targets, B = (size_t)p.B;
+        const size_t obs_w = n * ((size_t)p.cells + 4), act_w = n * ((flags & CS_ACTIONS_I64) ? 8 : 4);
+        for (int t = 0; t < T; t++) {
+            StepIO it{(const char *)actions_dev + (size_t)t * B * act_w, reward_dev + (size_t)t * B,
+                      terminated_dev + (size_t)t * B, win_dev + (size_t)t * B,
+                      obs_dev ? obs_dev + (size_t)t * B * obs_w : nullptr,
+                      state_out_dev ? state_out_dev + (size_t)t * B * W : nullptr, flags, 1};
+            CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL((k_step<N, 1>), dim3(env_blocks(p)), dim3(BLOCK), 0, s, p, it));
+            CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_map<N>, map_grid(p), dim3(MAP_BLOCK), 0, s, p, it.obs, 1));
+        }
+        return launched("cs_rollout");
+    }
     StepIO io{actions_dev, reward_dev, terminated_dev, win_dev, obs_dev, state_out_dev, flags, T};
     if (use_lane_kernel(cfg, flags)) {
         CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_rollout_lane<N>, dim3(lane_blocks(p)), dim3(BLOCK),

@@ -217,11 +217,10 @@ class BatchedFlightEnv:
         return self._reward, self._terminated.view(torch.bool), self._win.view(torch.bool)
 
     def rollout(self, actions, emit=True, out=None, update_views=True):
-        """T steps in one launch (flight_easy): actions [T, B, n] -> dict of [T, B, ...] tensors.
+        """T steps from one call (flight_easy: ONE launch; flight: T step+map launch pairs): actions [T, B, n] -> dict of
+        [T, B, ...] tensors.
         `out` reuses caller buffers (keys reward/terminated/win/obs/state); update_views=False skips refreshing
         the live get_obs()/get_state() buffers afterwards (they then lag until the next step/refresh)."""
-        if self.flight:
-            raise Exception("rollout: flight_easy only")
         T = int(actions.shape[0])
         a = self._actions(actions, (T, self.batch))
         B, n = self.batch, self.n_agents
@@ -230,7 +229,7 @@ class BatchedFlightEnv:
                 reward=torch.empty(T, B, dtype=torch.float32, device=self.device),
                 terminated=torch.empty(T, B, dtype=torch.uint8, device=self.device),
                 win=torch.empty(T, B, dtype=torch.uint8, device=self.device),
-                obs=torch.empty(T, B, n, 4, dtype=torch.float32, device=self.device) if emit else None,
+                obs=torch.empty(T, B, n, self.obs_width, dtype=torch.float32, device=self.device) if emit else None,
                 state=torch.empty(T, B, self.state_shape, dtype=torch.float32, device=self.device) if emit else None,
             )
         else:

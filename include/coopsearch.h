@@ -131,9 +131,10 @@ int cs_step(const cs_config *cfg, void *state_dev, const void *actions_dev, int 
             float *reward_dev, uint8_t *terminated_dev, uint8_t *win_dev,
             float *obs_dev, float *state_out_dev, void *stream);
 
-/* T consecutive env.step calls in ONE launch with the env resident in registers (flight_easy only):
- * actions [T][B][n]; reward [T][B]; terminated/win [T][B]; obs [T][B][n][4]; state_out [T][B][4n+3m]
- * (obs/state_out may be NULL).  Same results as T cs_step calls with the same flags. */
+/* T consecutive env.step calls from ONE call: actions [T][B][n]; reward [T][B]; terminated/win [T][B];
+ * obs [T][B][n][obs width]; state_out [T][B][4n+3m] (obs/state_out may be NULL).  Same results as T cs_step calls
+ * with the same flags.  flight_easy: one launch with the env resident in registers; flight: T (step, map) launch
+ * pairs enqueued back to back. */
 int cs_rollout(const cs_config *cfg, void *state_dev, const void *actions_dev, int T, int flags,
                float *reward_dev, uint8_t *terminated_dev, uint8_t *win_dev,
                float *obs_dev, float *state_out_dev, void *stream);

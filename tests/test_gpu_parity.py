@@ -518,3 +518,50 @@ def test_c_example_runs_and_reproduces_the_random_policy_statistics(tmp_path):
     assert m, out.stdout
     assert int(m.group(1)) == 4096
     assert abs(float(m.group(4)) / 15 * 100 - 84.87) < 3.0     # shipped random-policy figure for 3a15t AM0
+
+
+def test_flight_rollout_call_equals_stepwise():
+    B, n, T = 96, 3, 40
+    args = cs.make_env_args("flight", n_agents=n)
+    args.time_limit = 17
+    seeds = np.arange(B, dtype=np.uint32) + 321
+    acts = torch.randint(0, 3, (T, B, n), dtype=torch.int64, device="cuda", generator=torch.Generator("cuda").manual_seed(2))
+    e1 = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, freeze_done=False, auto_reset=True)
+    e2 = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, freeze_done=False, auto_reset=True)
+    out = e2.rollout(acts)
+    assert out["obs"].shape == (T, B, n, 2504)
+    for t in range(T):
+        r, term, win = e1.step(acts[t])
+        assert torch.equal(r, out["reward"][t]) and torch.equal(term, out["terminated"][t]) and torch.equal(win, out["win"][t])
+        assert torch.equal(e1.get_obs(), out["obs"][t]) and torch.equal(e1.get_state(), out["state"][t])
+    for k in ("tgt", "agent", "hdr", "mt", "prob"):
+        assert torch.equal(e1.raw()[k], e2.raw()[k]), k
+
+
+@pytest.mark.parametrize("kernel", ["group", "lane"])
+def test_long_horizon_matches_oracle(kernel):
+    """20 000 steps per env with auto-reset: ~100+ episodes, the circular MT19937 state wraps ~70 times (cursor,
+    mirrored head, reset-time batches landing anywhere in the ring).  Rewards are compared every step (in rollout
+    chunks), the full raw state at the end."""
+    B, n, m, chunk, chunks = 64, 3, 15, 250, 80
+    seeds = np.arange(B, dtype=np.uint32) * 7 + 5
+    env = cs.BatchedFlightEnv(cs.make_env_args("flight_easy", n_agents=n), batch=B, seeds=seeds, freeze_done=False,
+                              auto_reset=True, kernel=kernel)
+    env.seed(seeds)
+    env.reset(init=True)
+    cfg = orc.make_config(n_agents=n)
+    rng = np.random.RandomState(99)
+    with orc.hip_equivalent_arithmetic():
+        ob = orc.OracleBatch(cfg, B, seeds)
+        ob.reset(init=True, threads=8)
+        for c in range(chunks):
+            a = rng.randint(0, 3, size=(chunk, B, n)).astype(np.int32)
+            out = env.rollout(torch.from_numpy(a), emit=False, update_views=False)
+            want = np.empty((chunk, B), dtype=np.float32)
+            for t in range(chunk):
+                r, _, _ = ob.step(a[t], auto_reset=True, freeze_done=False, threads=8, emit=False)
+                want[t] = r
+            np.testing.assert_array_equal(out["reward"].cpu().numpy(), want, err_msg=f"chunk {c}")
+        compare_with_oracle(env, ob, B, n, m, "after 20000 steps")
+    h = hdr(env)
+    assert h[:, _lib.H_EPISODES].min() >= 100 and int(words(h).min()) > 40 * 624
