@@ -11,7 +11,7 @@ from .env import BatchedFlightEnv, FlightSearchEnvEasy, FlightSearchEnv  # noqa:
 from . import _lib as lib  # noqa: F401
 from . import dist  # noqa: F401
 from .replay import DeviceReplayBuffer  # noqa: F401
-from .agents import AgentRNN, BatchedAgents, rnn_input_shape  # noqa: F401
+from .agents import AgentRNN, BatchedAgents, FusedAgents, rnn_input_shape  # noqa: F401
 from .collector import EpisodeCollector, evaluate, collect_experiment_data, random_policy  # noqa: F401
 
 __all__ = ["BatchedFlightEnv", "FlightSearchEnvEasy", "FlightSearchEnv", "load_targets", "default_circle_dict",

@@ -95,3 +95,93 @@ class BatchedAgents:
                 self.init_hidden()
             return self.choose_action(obs, last_onehot, None, epsilon, evaluate, generator)
         return fn
+
+
+class FusedAgents:
+    """`BatchedAgents` for the non-conv (flight_easy) network with the whole forward + choice in ONE HIP launch
+    (csrc/policy.hip, `cs_policy_forward`): obs ++ one-hot(last action) ++ one-hot(agent id) -> fc1 -> GRUCell -> fc2 ->
+    argmax / epsilon-greedy, fp32 on the matrix cores.  Same parameters as `AgentRNN` (the reference's state_dict
+    loads into `net`, then `load_weights()` repacks them).  Requires last_action and reuse_network (the reference's
+    defaults, common/arguments.py:52-53) and no availability mask (every action is always available in this env,
+    flight_env_easy.py:184-188)."""
+
+    def __init__(self, args, batch, device="cuda", net=None, seed=0):
+        import ctypes as C
+
+        from . import _lib
+        if getattr(args, "conv", False):
+            raise ValueError("FusedAgents covers the non-conv network; use BatchedAgents for flight's conv front end")
+        if not (getattr(args, "last_action", True) and getattr(args, "reuse_network", True)):
+            raise ValueError("FusedAgents needs last_action and reuse_network (the reference's defaults)")
+        if args.rnn_hidden_dim != 64 or 4 + args.n_actions + args.n_agents > 16 or args.obs_shape != 4:
+            raise ValueError("FusedAgents: rnn_hidden_dim must be 64, obs_shape 4 and 4 + n_actions + n_agents <= 16")
+        self._C, self._lib = C, _lib
+        self._L = _lib.load()
+        self.args, self.batch, self.device = args, int(batch), torch.device(device)
+        self.n_agents, self.n_actions = args.n_agents, args.n_actions
+        self.rows = self.batch * self.n_agents
+        self.net = (net or AgentRNN(rnn_input_shape(args), args)).to(self.device)
+        self.seed, self.calls = int(seed), 0
+        self.hidden = torch.zeros(self.rows, 64, device=self.device)
+        # previous action on entry (-1 = none), chosen action on return: the kernel updates it in place
+        self.actions = torch.full((self.batch, self.n_agents), -1, dtype=torch.int64, device=self.device)
+        self.q = torch.zeros(self.batch, self.n_agents, self.n_actions, device=self.device)
+        self.load_weights()
+
+    def load_weights(self):
+        """Repack `self.net`'s parameters into MFMA fragment order (host side, once per weight update)."""
+        import numpy as np
+        C = self._C
+        sd = {k: v.detach().to("cpu", torch.float32).contiguous().numpy() for k, v in self.net.state_dict().items()}
+        order = ["fc1.weight", "fc1.bias", "rnn.weight_ih", "rnn.bias_ih", "rnn.weight_hh", "rnn.bias_hh",
+                 "fc2.0.weight", "fc2.0.bias", "fc2.2.weight", "fc2.2.bias"]
+        packed = np.zeros(self._L.cs_policy_packed_floats(), dtype=np.float32)
+        rc = self._L.cs_policy_pack(*[C.c_void_p(sd[k].ctypes.data) for k in order], sd["fc1.weight"].shape[1],
+                                    self.n_actions, C.c_void_p(packed.ctypes.data))
+        if rc != 0:
+            raise self._lib.CoopSearchError(self._L.cs_policy_last_error().decode())
+        self.packed = torch.from_numpy(packed).to(self.device)
+
+    def init_hidden(self):
+        self.hidden.zero_()
+        self.actions.fill_(-1)
+
+    def choose_action(self, obs, epsilon=0.0, evaluate=False, want_q=False):
+        """obs: float32 [B, n, >=4] device tensor whose last dim is contiguous (the env's live obs buffer works
+        directly).  Returns the int64 [B, n] action buffer (overwritten by the next call); it is also remembered as the
+        next call's last action, like rollout.py:55-63."""
+        C = self._C
+        if obs.dtype != torch.float32 or obs.stride(-1) != 1 or obs.shape[0] * obs.shape[1] != self.rows:
+            raise ValueError("obs must be float32 [B, n, 4] with a contiguous last dimension")
+        if obs.stride(0) != obs.shape[1] * obs.stride(1):
+            obs = obs.contiguous()
+        vp = lambda t: C.c_void_p(t.data_ptr())
+        eps = 0.0 if evaluate else float(epsilon)
+        rc = self._L.cs_policy_forward(vp(self.packed), vp(obs), obs.stride(1), 0, vp(self.actions), vp(self.hidden),
+                                       vp(self.q) if want_q else None, vp(self.actions), self.rows, self.n_agents,
+                                       self.n_actions, eps, self.seed, self.calls,
+                                       C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        if rc != 0:
+            raise self._lib.CoopSearchError(self._L.cs_policy_last_error().decode())
+        self.calls += 1
+        return self.actions
+
+    def forward_raw(self, x, want_q=True):
+        """Forward on caller-assembled input rows x [rows, 4 + n_actions + n_agents] (greedy choice)."""
+        C = self._C
+        x = x.to(torch.float32).contiguous()
+        vp = lambda t: C.c_void_p(t.data_ptr())
+        rc = self._L.cs_policy_forward(vp(self.packed), vp(x), x.stride(0), 0, None, vp(self.hidden),
+                                       vp(self.q) if want_q else None, vp(self.actions), self.rows, self.n_agents,
+                                       self.n_actions, 0.0, self.seed, self.calls,
+                                       C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        if rc != 0:
+            raise self._lib.CoopSearchError(self._L.cs_policy_last_error().decode())
+        return self.actions
+
+    def policy(self, epsilon=0.0, evaluate=True):
+        def fn(obs, state, last_onehot, t):
+            if t == 0:
+                self.init_hidden()
+            return self.choose_action(obs, epsilon, evaluate)
+        return fn

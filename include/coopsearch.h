@@ -147,6 +147,33 @@ int cs_emit(const cs_config *cfg, void *state_dev, float *obs_dev, float *state_
  * (double[4]; the caller zeroes it, then all-gathers / all-reduces the partials over RCCL.) */
 int cs_metrics(const cs_config *cfg, void *state_dev, double *out4_dev, void *stream);
 
+/* ---- caller-side row f3: fused forward of the shared recurrent agent network ------------
+ * Replaces the per-agent batch-1 loop of agent/agent.py:33-75 (choose_action) over network/base_net.py:5-46
+ * (fc1 -> ReLU -> GRUCell(64) -> fc2[Linear, ReLU, Linear]) for the non-conv (flight_easy) network: ONE launch
+ * for all rows = B * n_agents, fp32 on the matrix cores, epsilon-greedy choice on the device. */
+
+/* floats in a packed weight blob */
+size_t cs_policy_packed_floats(void);
+
+/* HOST: torch-layout weights (fc1.weight [64][in_dim], rnn.weight_ih / weight_hh [192][64], fc2.0.weight [64][64],
+ * fc2.2.weight [n_actions][64] and their biases) -> packed_host[cs_policy_packed_floats()], to be copied to the device.
+ * in_dim = 4 + n_actions + n_agents <= 16 (obs ++ one-hot last action ++ one-hot agent id, agent.py:41-52). */
+int cs_policy_pack(const float *fc1_w, const float *fc1_b, const float *w_ih, const float *b_ih, const float *w_hh,
+                   const float *b_hh, const float *fc2a_w, const float *fc2a_b, const float *fc2b_w, const float *fc2b_b,
+                   int in_dim, int n_actions, float *packed_host);
+
+/* One forward over rows = B*n (row r: env r / n_agents, agent r % n_agents).  obs row r = 4 floats at
+ * obs_dev + r*obs_stride + obs_offset (floats; 16-byte aligned); last_dev[r] = previous action or < 0 for none
+ * (last_dev NULL = raw mode: the row at obs_dev + r*obs_stride + obs_offset already holds all 4 + n_actions +
+ * n_agents inputs, any alignment);
+ * hidden_dev float [rows][64] updated in place; q_dev float [rows][n_actions] or NULL; actions_dev int64 [rows]:
+ * argmax_a q (first maximum), or with probability epsilon a uniform action drawn from a counter-based generator
+ * keyed by (seed, step, row). */
+int cs_policy_forward(const float *packed_dev, const float *obs_dev, int obs_stride, int obs_offset,
+                      const int64_t *last_dev, float *hidden_dev, float *q_dev, int64_t *actions_dev, int rows,
+                      int n_agents, int n_actions, float epsilon, uint64_t seed, uint32_t step, void *stream);
+const char *cs_policy_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif
