@@ -146,25 +146,31 @@ class FusedAgents:
         self.hidden.zero_()
         self.actions.fill_(-1)
 
-    def choose_action(self, obs, epsilon=0.0, evaluate=False, want_q=False):
+    def choose_action(self, obs, epsilon=0.0, evaluate=False, want_q=False, last=None, out=None):
         """obs: float32 [B, n, >=4] device tensor whose last dim is contiguous (the env's live obs buffer works
         directly).  Returns the int64 [B, n] action buffer (overwritten by the next call); it is also remembered as the
-        next call's last action, like rollout.py:55-63."""
+        next call's last action, like rollout.py:55-63.  A collector can pass `last` (int64 [B, n] previous actions,
+        -1 = none) and `out` (int64 [B, n] destination, e.g. row t of its action table) to avoid any copy."""
         C = self._C
         if obs.dtype != torch.float32 or obs.stride(-1) != 1 or obs.shape[0] * obs.shape[1] != self.rows:
             raise ValueError("obs must be float32 [B, n, 4] with a contiguous last dimension")
         if obs.stride(0) != obs.shape[1] * obs.stride(1):
             obs = obs.contiguous()
+        last = self.actions if last is None else last
+        out = self.actions if out is None else out
+        for t in (last, out):
+            if t.dtype != torch.int64 or t.numel() != self.rows or not t.is_contiguous():
+                raise ValueError("last / out must be contiguous int64 [B, n]")
         vp = lambda t: C.c_void_p(t.data_ptr())
         eps = 0.0 if evaluate else float(epsilon)
-        rc = self._L.cs_policy_forward(vp(self.packed), vp(obs), obs.stride(1), 0, vp(self.actions), vp(self.hidden),
-                                       vp(self.q) if want_q else None, vp(self.actions), self.rows, self.n_agents,
+        rc = self._L.cs_policy_forward(vp(self.packed), vp(obs), obs.stride(1), 0, vp(last), vp(self.hidden),
+                                       vp(self.q) if want_q else None, vp(out), self.rows, self.n_agents,
                                        self.n_actions, eps, self.seed, self.calls,
                                        C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
         if rc != 0:
             raise self._lib.CoopSearchError(self._L.cs_policy_last_error().decode())
         self.calls += 1
-        return self.actions
+        return out
 
     def forward_raw(self, x, want_q=True):
         """Forward on caller-assembled input rows x [rows, 4 + n_actions + n_agents] (greedy choice)."""

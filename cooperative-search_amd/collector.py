@@ -18,9 +18,11 @@ class EpisodeCollector:
     def __init__(self, env):
         self.env = env
 
-    def generate_episodes(self, policy=None, actions=None, init=False):
+    def generate_episodes(self, policy=None, actions=None, init=False, agents=None, epsilon=0.0, evaluate=True):
         """One episode per env.  Either `actions` (open-loop table, int [T, B, n]; flight_easy runs it as ONE fused
-        rollout launch) or `policy(obs[B,n,obs], state[B,S], last_onehot[B,n,A], t) -> int actions [B, n]`.
+        rollout launch), `policy(obs[B,n,obs], state[B,S], last_onehot[B,n,A], t) -> int actions [B, n]`, or `agents`
+        (a `FusedAgents`: two launches per step -- policy kernel, env step -- writing straight into the [T, ...] episode
+        tables, no copies).
         Returns (episode dict of float32 [B, T, ...] tensors, episode_reward[B], win_tag[B] bool, targets_find[B])."""
         env = self.env
         B, n, T, A = env.batch, env.n_agents, env.time_limit, env.n_actions
@@ -45,18 +47,21 @@ class EpisodeCollector:
                 u.copy_(acts.to(torch.int64))
                 r.copy_(out["reward"])
                 term.copy_(out["terminated"])
+            elif agents is not None:
+                agents.init_hidden()
+                none = torch.full((B, n), -1, dtype=torch.int64, device=dev)
+                for t in range(T):
+                    agents.choose_action(o[t], epsilon, evaluate, last=u[t - 1] if t else none, out=u[t])
+                    env.step(u[t], out=dict(reward=r[t], terminated=term[t], obs=o[t + 1], state=s[t + 1]))
+                env.refresh()
             else:
                 last = torch.zeros(B, n, A, dtype=torch.float32, device=dev)
                 for t in range(T):
                     a = actions[t] if actions is not None else policy(o[t], s[t], last, t)
-                    a = torch.as_tensor(a, device=dev).to(torch.int64)
-                    rr, tt, _ = env.step(a)
-                    u[t].copy_(a)
-                    r[t].copy_(rr)
-                    term[t].copy_(tt)
-                    o[t + 1].copy_(env.get_obs())
-                    s[t + 1].copy_(env.get_state())
-                    last = torch.nn.functional.one_hot(a, A).to(torch.float32)
+                    u[t].copy_(torch.as_tensor(a, device=dev))
+                    env.step(u[t], out=dict(reward=r[t], terminated=term[t], obs=o[t + 1], state=s[t + 1]))
+                    last = torch.nn.functional.one_hot(u[t], A).to(torch.float32)
+                env.refresh()
             # a step is real if the env had not terminated before it
             done_before = torch.zeros(T, B, dtype=torch.bool, device=dev)
             done_before[1:] = term[:-1]

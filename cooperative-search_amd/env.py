@@ -207,14 +207,26 @@ class BatchedFlightEnv:
             f |= _lib.KERNEL_LANE
         return f
 
-    def step(self, actions):
+    def step(self, actions, out=None):
         """env.step(act_list) for every env: actions [B, n] in {0,1,2} -> (reward[B] f32, terminated[B] bool,
-        win[B] bool).  The returned tensors (and get_obs/get_state) are overwritten by the next step."""
+        win[B] bool).  The returned tensors (and get_obs/get_state) are overwritten by the next step.
+        `out` (dict with any of reward/terminated/win/obs/state, contiguous tensors of the right shape) makes the
+        kernel write those results straight into caller buffers (a collector's [T, ...] rows) instead of the live
+        views; the live get_obs()/get_state() then lag until the next plain step() or refresh()."""
         a = self._actions(actions, (self.batch,))
+        dst = dict(reward=self._reward, terminated=self._terminated, win=self._win, obs=self._obs, state=self._state)
+        if out:
+            for k, v in out.items():
+                if v is None:
+                    continue
+                if k not in dst or v.numel() * v.element_size() != dst[k].numel() * dst[k].element_size() \
+                        or not v.is_contiguous() or v.device != dst[k].device:
+                    raise ValueError(f"step(out=): bad destination for {k!r}")
+                dst[k] = v
         _lib.check(self._L.cs_step(self._cfgp, self._blob.data_ptr(), a.data_ptr(), self._flags(a),
-                                   self._reward.data_ptr(), self._terminated.data_ptr(), self._win.data_ptr(),
-                                   self._obs.data_ptr(), self._state.data_ptr(), self._stream()))
-        return self._reward, self._terminated.view(torch.bool), self._win.view(torch.bool)
+                                   dst["reward"].data_ptr(), dst["terminated"].data_ptr(), dst["win"].data_ptr(),
+                                   dst["obs"].data_ptr(), dst["state"].data_ptr(), self._stream()))
+        return dst["reward"], dst["terminated"].view(torch.bool), dst["win"].view(torch.bool)
 
     def rollout(self, actions, emit=True, out=None, update_views=True):
         """T steps from one call (flight_easy: ONE launch; flight: T step+map launch pairs): actions [T, B, n] -> dict of

@@ -6,6 +6,7 @@ import os
 import re
 import types
 
+import numpy as np
 import pytest
 
 import cooperative_search_amd as cs
@@ -118,3 +119,38 @@ def test_c_example_compiles_and_links_against_the_abi(tmp_path):
                            os.path.join(ROOT, "examples", "c_api_demo.cpp"), "-L", csrc, "-lcoopsearch_hip",
                            f"-Wl,-rpath,{csrc}", "-o", str(out)])
     assert out.exists()
+
+
+def test_policy_pack_layout_host_only():
+    """cs_policy_pack is pure host code: fragment (column tile nt, k-step kk) holds W[16nt + (l & 15)][4kk + (l >> 4)]
+    for lane l (the B operand of one 16x16x4 MFMA), zero padded; biases follow."""
+    import ctypes as C
+    L = _lib.load()
+    rng = np.random.default_rng(3)
+    in_dim, nA = 10, 3
+    ws = [rng.standard_normal(s).astype(np.float32) for s in
+          ((64, in_dim), (64,), (192, 64), (192,), (192, 64), (192,), (64, 64), (64,), (nA, 64), (nA,))]
+    n = L.cs_policy_packed_floats()
+    packed = np.full(n, np.nan, dtype=np.float32)
+    rc = L.cs_policy_pack(*[C.c_void_p(w.ctypes.data) for w in ws], in_dim, nA, C.c_void_p(packed.ctypes.data))
+    assert rc == 0 and not np.isnan(packed).any()
+    lanes = np.arange(64)
+
+    def frag(off, nt, kk, ksteps):
+        return packed[off + (nt * ksteps + kk) * 64: off + (nt * ksteps + kk) * 64 + 64]
+
+    off = 0
+    for w, tiles, ksteps in ((ws[0], 4, 4), (ws[2], 12, 16), (ws[4], 12, 16), (ws[6], 4, 16), (ws[8], 1, 16)):
+        for nt in range(tiles):
+            for kk in range(ksteps):
+                rows, ks = 16 * nt + (lanes & 15), 4 * kk + (lanes >> 4)
+                want = np.where((rows < w.shape[0]) & (ks < w.shape[1]),
+                                w[np.minimum(rows, w.shape[0] - 1), np.minimum(ks, w.shape[1] - 1)], 0.0)
+                assert np.array_equal(frag(off, nt, kk, ksteps), want.astype(np.float32))
+        off += tiles * ksteps * 64
+    for b, width in ((ws[1], 64), (ws[3], 192), (ws[5], 192), (ws[7], 64), (ws[9], 16)):
+        assert np.array_equal(packed[off:off + len(b)], b) and not packed[off + len(b):off + width].any()
+        off += width
+    assert off == n
+    assert L.cs_policy_pack(*[C.c_void_p(w.ctypes.data) for w in ws], 17, nA, C.c_void_p(packed.ctypes.data)) != 0
+    assert b"in_dim" in L.cs_policy_last_error()

@@ -108,3 +108,36 @@ def test_closed_loop_with_fused_agents_matches_batched_agents():
     # near-ties in q may flip a handful of envs; the bulk must agree exactly
     same = (res[0][0] == res[1][0]) & (res[0][1] == res[1][1])
     assert same.float().mean().item() > 0.97
+
+
+def test_collector_and_evaluate_accept_the_fused_policy():
+    a = _args(3)
+    B = 256
+    env = cs.BatchedFlightEnv(a, batch=B, freeze_done=True)
+    cs.apply_env_info(a, env)
+    torch.manual_seed(1)
+    fused = FusedAgents(a, B)
+    col = cs.EpisodeCollector(env)
+    ep, rew, win, found = col.generate_episodes(policy=fused.policy(0.0, True))
+    # the zero-copy path (policy kernel and env step write straight into the episode tables) gives the same batch
+    env.seed(np.arange(B))
+    ep_a, rew_a, win_a, found_a = col.generate_episodes(policy=fused.policy(0.0, True), init=True)
+    env.seed(np.arange(B))
+    ep_b, rew_b, win_b, found_b = col.generate_episodes(agents=fused, init=True)
+    for k in ep_a:
+        assert torch.equal(ep_a[k], ep_b[k]), k
+    assert torch.equal(rew_a, rew_b) and torch.equal(win_a, win_b) and torch.equal(found_a, found_b)
+    assert torch.equal(env.get_obs(), ep_b["o_next"][:, -1]) or bool((ep_b["padded"][:, -1] == 1).any())
+    assert ep["u"].shape[:3] == (B, a.episode_limit, 3) and ep["u"].min() >= 0 and ep["u"].max() <= 2
+    # the recorded actions are what the network picks for the recorded observations (replay through the torch module)
+    ref = BatchedAgents(a, B, net=fused.net)
+    last = torch.zeros(B, 3, 3, device="cuda")
+    agree, total = 0, 0
+    for t in range(20):
+        act = ref.choose_action(ep["o"][:, t], last, evaluate=True)
+        agree += (act == ep["u"][:, t, :, 0].long()).sum().item()
+        total += act.numel()
+        last = torch.nn.functional.one_hot(ep["u"][:, t, :, 0].long(), 3).float()
+    assert agree / total > 0.99
+    win_rate, episode_reward, targets_find = cs.evaluate(env, fused.policy(0.0, True))
+    assert 0.0 <= win_rate <= 1.0 and 0.0 <= targets_find <= 15.0

@@ -10,17 +10,21 @@ import cooperative_search_amd as cs
 
 def main():
     res = []
-    for env_name, n, B in (("flight_easy", 3, 4096), ("flight_easy", 5, 16384), ("flight", 3, 1024)):
+    for env_name, n, B in (("flight_easy", 3, 4096), ("flight_easy", 5, 16384), ("flight_easy", 3, 65536), ("flight", 3, 1024)):
         args = cs.make_env_args(env_name, n_agents=n)
         env = cs.BatchedFlightEnv(args, batch=B, freeze_done=True)
         cs.apply_env_info(args, env)
         torch.manual_seed(0)
-        agents = cs.BatchedAgents(args, B)
+        fused = env_name == "flight_easy" and os.environ.get("TORCH_POLICY") != "1"
+        agents = cs.FusedAgents(args, B) if fused else cs.BatchedAgents(args, B)   # csrc/policy.hip vs torch modules
         T = args.episode_limit
         last = torch.zeros(B, n, 3, device="cuda")
         actions = torch.zeros(B, n, dtype=torch.int64, device="cuda")
 
         def one_step():
+            if fused:   # one launch: input assembly, fc1, GRU, fc2, argmax; last action kept in the action buffer
+                env.step(agents.choose_action(env.get_obs()))
+                return
             a = agents.choose_action(env.get_obs(), last, evaluate=True)
             actions.copy_(a)
             env.step(actions)
@@ -54,15 +58,16 @@ def main():
         col = cs.EpisodeCollector(env)
         rb = cs.DeviceReplayBuffer(args, 2 * B)
         pol = agents.policy(0.0, True)
-        col.generate_episodes(policy=pol)
+        kw = dict(agents=agents) if fused else dict(policy=pol)
+        col.generate_episodes(**kw)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        ep, rew, win, found = col.generate_episodes(policy=pol)
+        ep, rew, win, found = col.generate_episodes(**kw)
         rb.store_episode(ep)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         executed = float((ep["padded"][:, :, 0] == 0).sum().item())
-        res.append(dict(workload=f"{env_name} {n}a15t B={B}", policy_plus_step_eager=eager, policy_plus_step_hipgraph=graphed,
+        res.append(dict(workload=f"{env_name} {n}a15t B={B}", policy="fused HIP" if fused else "torch", policy_plus_step_eager=eager, policy_plus_step_hipgraph=graphed,
                         collect_and_store_episodes=B * T / dt, executed_env_steps_per_s=executed / dt,
                         episodes_per_s=B / dt))
         print(json.dumps(res[-1]), flush=True)

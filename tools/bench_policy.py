@@ -20,7 +20,10 @@ def timed(fn, iters):
 
 
 def main():
-    for n, B in ((3, 4096), (5, 16384), (3, 65536)):
+    sizes = ((3, 4096), (5, 16384), (3, 65536))
+    if len(sys.argv) == 3:   # python tools/bench_policy.py N_AGENTS BATCH
+        sizes = ((int(sys.argv[1]), int(sys.argv[2])),)
+    for n, B in sizes:
         args = cs.make_env_args("flight_easy", n_agents=n)
         env = cs.BatchedFlightEnv(args, batch=B, freeze_done=True)
         cs.apply_env_info(args, env)
