@@ -171,6 +171,40 @@ def side_measurement(cs, dev, label, env_name, n, B, mode, K, W, kernel):
             "roofline_achieved_GBps": achieved, "roofline_frac": achieved / HBM_PEAK_GBPS}
 
 
+def closed_loop_measurement(cs, dev, n, B, K, W):
+    """`also` entry: the reference's recurrent agent network (agents.FusedAgents -> csrc/policy.hip) picks every action
+    from the live obs, then env.step: two launches per env step, nothing leaves the device."""
+    args = cs.make_env_args("flight_easy", n_agents=n)
+    env = cs.BatchedFlightEnv(args, batch=B, device=dev, freeze_done=False, auto_reset=True)
+    cs.apply_env_info(args, env)
+    torch.manual_seed(0)
+    agents = cs.FusedAgents(args, B, device=dev)
+    for _ in range(W):
+        env.step(agents.choose_action(env.get_obs()))
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    for _ in range(K):
+        env.step(agents.choose_action(env.get_obs()))
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    obs = env.get_obs()
+    e0.record()
+    for _ in range(200):
+        agents.choose_action(obs)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    pol_us = e0.elapsed_time(e1) * 1e3 / 200
+    flops = 2.0 * B * n * (16 * 64 + 2 * 192 * 64 + 64 * 64 + 64 * 16)
+    del env, agents
+    torch.cuda.empty_cache()
+    return {"workload": f"closed loop: flight_easy {n}a15t B={B}, recurrent policy (k_policy) + env step per step",
+            "mode": "closed-loop", "value": B * K / dt, "unit": "env-steps/s", "ms_per_step": dt * 1e3 / K,
+            "policy_kernel_us": pol_us, "policy_roofline": {"bound": "mfma", "achieved": flops / pol_us / 1e6,
+                                                            "peak": 157.3, "unit": "TFLOP/s", "frac": flops / pol_us / 1e6 / 157.3,
+                                                            "dtype": "f32"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -280,6 +314,8 @@ def main():
                                  2000, 200, "auto"),
                 side_measurement(cs, dev, "flight_easy 3a15t B=262144 (lane-per-env kernel; batch sweep asymptote)",
                                  "flight_easy", 3, 262144, "rollout", 400, 100, "lane"),
+                closed_loop_measurement(cs, dev, 3, 4096, 4000, 400),
+                closed_loop_measurement(cs, dev, 3, 65536, 1000, 100),
             ]
         print(json.dumps(line))
     if world > 1:
