@@ -14,7 +14,7 @@ FREEZE_DONE, AUTO_RESET, ACTIONS_I64, KERNEL_GROUP, KERNEL_LANE = 1, 2, 4, 8, 16
 
 EXPORTS = ["cs_abi_version", "cs_last_error", "cs_state_layout", "cs_init", "cs_seed", "cs_reset", "cs_step",
            "cs_rollout", "cs_emit", "cs_metrics", "cs_policy_packed_floats", "cs_policy_pack", "cs_policy_forward",
-           "cs_policy_last_error"]
+           "cs_policy_conv_features", "cs_policy_last_error"]
 
 
 class CsConfig(C.Structure):
@@ -74,8 +74,9 @@ def load():
     L.cs_policy_packed_floats.restype = C.c_size_t
     L.cs_policy_last_error.restype = C.c_char_p
     L.cs_policy_pack.argtypes = [vp] * 10 + [C.c_int, C.c_int, vp]
-    L.cs_policy_forward.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float,
-                                    C.c_uint64, C.c_uint32, vp]
+    L.cs_policy_forward.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int,
+                                    C.c_float, C.c_uint64, C.c_uint32, vp]
+    L.cs_policy_conv_features.argtypes = [vp] * 7 + [C.c_int64, C.c_int, vp, vp]
     for name in EXPORTS:
         fn = getattr(L, name)
         if name not in ("cs_abi_version", "cs_last_error", "cs_policy_packed_floats", "cs_policy_last_error"):

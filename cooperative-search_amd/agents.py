@@ -98,27 +98,34 @@ class BatchedAgents:
 
 
 class FusedAgents:
-    """`BatchedAgents` for the non-conv (flight_easy) network with the whole forward + choice in ONE HIP launch
-    (csrc/policy.hip, `cs_policy_forward`): obs ++ one-hot(last action) ++ one-hot(agent id) -> fc1 -> GRUCell -> fc2 ->
-    argmax / epsilon-greedy, fp32 on the matrix cores.  Same parameters as `AgentRNN` (the reference's state_dict
-    loads into `net`, then `load_weights()` repacks them).  Requires last_action and reuse_network (the reference's
-    defaults, common/arguments.py:52-53) and no availability mask (every action is always available in this env,
-    flight_env_easy.py:184-188)."""
+    """`BatchedAgents` with the whole forward + choice in HIP (csrc/policy.hip): obs ++ one-hot(last action) ++
+    one-hot(agent id) -> fc1 -> GRUCell -> fc2 -> argmax / epsilon-greedy in ONE launch (`cs_policy_forward`, fp32 on the
+    matrix cores); for flight's conv network one more launch computes the 16 conv features of every env's probability map
+    (`cs_policy_conv_features`, once per env: all its agents observe the same map).  Same parameters as `AgentRNN` (the
+    reference's state_dict loads into `net`, then `load_weights()` repacks them).  Requires last_action and
+    reuse_network (the reference's defaults, common/arguments.py:52-53), the reference's conv hyper-parameters
+    (:256-265) and no availability mask (every action is always available in this env, flight_env_easy.py:184-188)."""
+
+    CONV_HYPER = dict(map_size=50, dim_1=4, kernel_size_1=4, stride_1=2, dim_2=1, kernel_size_2=3, stride_2=1, padding_2=1,
+                      conv_out_dim=16)
 
     def __init__(self, args, batch, device="cuda", net=None, seed=0):
         import ctypes as C
 
         from . import _lib
-        if getattr(args, "conv", False):
-            raise ValueError("FusedAgents covers the non-conv network; use BatchedAgents for flight's conv front end")
+        self.conv = bool(getattr(args, "conv", False))
+        if self.conv and any(getattr(args, k, None) != v for k, v in self.CONV_HYPER.items()):
+            raise ValueError(f"FusedAgents' conv front end is built for {self.CONV_HYPER}; use BatchedAgents otherwise")
         if not (getattr(args, "last_action", True) and getattr(args, "reuse_network", True)):
             raise ValueError("FusedAgents needs last_action and reuse_network (the reference's defaults)")
-        if args.rnn_hidden_dim != 64 or 4 + args.n_actions + args.n_agents > 16 or args.obs_shape != 4:
+        cells = args.map_size ** 2 if self.conv else 0
+        # obs_shape is 4 for flight too (flight_env.py:34): the map is not counted, consumers add it when args.conv
+        if args.rnn_hidden_dim != 64 or args.obs_shape != 4 or 4 + args.n_actions + args.n_agents > 16:
             raise ValueError("FusedAgents: rnn_hidden_dim must be 64, obs_shape 4 and 4 + n_actions + n_agents <= 16")
         self._C, self._lib = C, _lib
         self._L = _lib.load()
         self.args, self.batch, self.device = args, int(batch), torch.device(device)
-        self.n_agents, self.n_actions = args.n_agents, args.n_actions
+        self.n_agents, self.n_actions, self.cells = args.n_agents, args.n_actions, cells
         self.rows = self.batch * self.n_agents
         self.net = (net or AgentRNN(rnn_input_shape(args), args)).to(self.device)
         self.seed, self.calls = int(seed), 0
@@ -126,6 +133,7 @@ class FusedAgents:
         # previous action on entry (-1 = none), chosen action on return: the kernel updates it in place
         self.actions = torch.full((self.batch, self.n_agents), -1, dtype=torch.int64, device=self.device)
         self.q = torch.zeros(self.batch, self.n_agents, self.n_actions, device=self.device)
+        self.feat = torch.zeros(self.batch, 16, device=self.device) if self.conv else None
         self.load_weights()
 
     def load_weights(self):
@@ -141,20 +149,37 @@ class FusedAgents:
         if rc != 0:
             raise self._lib.CoopSearchError(self._L.cs_policy_last_error().decode())
         self.packed = torch.from_numpy(packed).to(self.device)
+        if self.conv:  # the conv / linear tensors are used as they are (torch layout, fp32, contiguous device copies)
+            self.conv_w = [self.net.state_dict()[k].detach().to(self.device, torch.float32).contiguous().clone()
+                           for k in ("conv.0.weight", "conv.0.bias", "conv.2.weight", "conv.2.bias", "linear.weight",
+                                     "linear.bias")]
+
+    def _stream(self):
+        return self._C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise self._lib.CoopSearchError(self._L.cs_policy_last_error().decode())
+
+    def _conv_features(self, maps, map_stride, n_maps, feat):
+        vp = lambda t: self._C.c_void_p(t.data_ptr())
+        self._check(self._L.cs_policy_conv_features(*[vp(w) for w in self.conv_w], vp(maps), map_stride, n_maps,
+                                                    vp(feat), self._stream()))
 
     def init_hidden(self):
         self.hidden.zero_()
         self.actions.fill_(-1)
 
     def choose_action(self, obs, epsilon=0.0, evaluate=False, want_q=False, last=None, out=None):
-        """obs: float32 [B, n, >=4] device tensor whose last dim is contiguous (the env's live obs buffer works
-        directly).  Returns the int64 [B, n] action buffer (overwritten by the next call); it is also remembered as the
+        """obs: float32 [B, n, obs_shape] device tensor, contiguous (the env's live obs buffer works directly).
+        Returns the int64 [B, n] action buffer (overwritten by the next call); it is also remembered as the
         next call's last action, like rollout.py:55-63.  A collector can pass `last` (int64 [B, n] previous actions,
         -1 = none) and `out` (int64 [B, n] destination, e.g. row t of its action table) to avoid any copy."""
         C = self._C
-        if obs.dtype != torch.float32 or obs.stride(-1) != 1 or obs.shape[0] * obs.shape[1] != self.rows:
-            raise ValueError("obs must be float32 [B, n, 4] with a contiguous last dimension")
-        if obs.stride(0) != obs.shape[1] * obs.stride(1):
+        width = self.cells + 4
+        if obs.dtype != torch.float32 or obs.shape[-1] != width or obs.numel() != self.rows * width:
+            raise ValueError(f"obs must be float32 [B, n, {width}]")
+        if not obs.is_contiguous():
             obs = obs.contiguous()
         last = self.actions if last is None else last
         out = self.actions if out is None else out
@@ -162,27 +187,30 @@ class FusedAgents:
             if t.dtype != torch.int64 or t.numel() != self.rows or not t.is_contiguous():
                 raise ValueError("last / out must be contiguous int64 [B, n]")
         vp = lambda t: C.c_void_p(t.data_ptr())
+        if self.conv:  # the map of an env's first row stands for all its rows (flight_env.py:223-230)
+            self._conv_features(obs, self.n_agents * width, self.batch, self.feat)
         eps = 0.0 if evaluate else float(epsilon)
-        rc = self._L.cs_policy_forward(vp(self.packed), vp(obs), obs.stride(1), 0, vp(last), vp(self.hidden),
-                                       vp(self.q) if want_q else None, vp(out), self.rows, self.n_agents,
-                                       self.n_actions, eps, self.seed, self.calls,
-                                       C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
-        if rc != 0:
-            raise self._lib.CoopSearchError(self._L.cs_policy_last_error().decode())
+        self._check(self._L.cs_policy_forward(vp(self.packed), vp(obs), width, self.cells, vp(last),
+                                              vp(self.feat) if self.conv else None, self.n_agents, vp(self.hidden),
+                                              vp(self.q) if want_q else None, vp(out), self.rows, self.n_agents,
+                                              self.n_actions, eps, self.seed, self.calls, self._stream()))
         self.calls += 1
         return out
 
     def forward_raw(self, x, want_q=True):
-        """Forward on caller-assembled input rows x [rows, 4 + n_actions + n_agents] (greedy choice)."""
+        """Forward on caller-assembled input rows x [rows, (map_size^2 +) 4 + n_actions + n_agents] (greedy choice; conv
+        features per ROW here, since raw rows need not share maps)."""
         C = self._C
         x = x.to(torch.float32).contiguous()
         vp = lambda t: C.c_void_p(t.data_ptr())
-        rc = self._L.cs_policy_forward(vp(self.packed), vp(x), x.stride(0), 0, None, vp(self.hidden),
-                                       vp(self.q) if want_q else None, vp(self.actions), self.rows, self.n_agents,
-                                       self.n_actions, 0.0, self.seed, self.calls,
-                                       C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
-        if rc != 0:
-            raise self._lib.CoopSearchError(self._L.cs_policy_last_error().decode())
+        feat = None
+        if self.conv:
+            feat = torch.empty(self.rows, 16, device=self.device)
+            self._conv_features(x, x.stride(0), self.rows, feat)
+        self._check(self._L.cs_policy_forward(vp(self.packed), vp(x), x.stride(0), self.cells, None,
+                                              vp(feat) if self.conv else None, 1, vp(self.hidden),
+                                              vp(self.q) if want_q else None, vp(self.actions), self.rows, self.n_agents,
+                                              self.n_actions, 0.0, self.seed, self.calls, self._stream()))
         return self.actions
 
     def policy(self, epsilon=0.0, evaluate=True):

@@ -7,7 +7,7 @@
 //     h1 = relu(W1 x + b1);  h' = GRUCell(h1, h);  q = W3 relu(W2 h' + b2) + b3
 //     action = argmax_a q  (greedy)  or uniform over actions with probability epsilon
 // The GEMM-shaped products run on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products and sums,
-// 32 cycles per 16x16x4 block).  Non-conv (flight_easy) networks only; flight's conv front end stays in torch.
+// 32 cycles per 16x16x4 block).  flight adds k_conv_features (below) for the conv front end of its network.
 //
 // Decomposition (measured alternatives are listed in DESIGN.md section 8): a BLOCK of 4 wavefronts owns a tile of 16
 // rows and wavefront w computes column tile w (16 of the 64 hidden columns) of every layer, 120 MFMAs per tile:
@@ -30,7 +30,8 @@
 namespace {
 
 constexpr int H = 64;            // rnn_hidden_dim of the reference (common/arguments.py:58)
-constexpr int KIN = 16;          // padded input width (4 + n_actions + n_agents <= 16)
+constexpr int KIN_MAX = 32;      // padded input width: 16 (obs ++ last ++ id) or 32 (+ 16 conv features in front)
+constexpr int NFEAT = 16;        // conv_out_dim of the reference's flight network (common/arguments.py:265)
 constexpr int LDW = 68;          // LDS row stride in floats (68 % 32 = 4: 2-way conflicts at most on the A reads)
 constexpr int PBLOCK = 256;      // 4 wavefronts, one 16-column tile each
 
@@ -39,8 +40,8 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 // packed weight fragments, in floats: fragment (column tile nt, k-step kk) holds, for lane l,
 // W[16*nt + (l & 15)][4*kk + (l >> 4)] -- the B operand of one 16x16x4 MFMA
 constexpr int FR = 64;
-constexpr int OFF_W1 = 0;                           // [4 col tiles][4 k-steps][64]
-constexpr int OFF_WIH = OFF_W1 + 4 * 4 * FR;        // [12][16][64]
+constexpr int OFF_W1 = 0;                           // [4 col tiles][8 k-steps][64] (k-steps 4..7 zero when in_dim <= 16)
+constexpr int OFF_WIH = OFF_W1 + 4 * (KIN_MAX / 4) * FR;  // [12][16][64]
 constexpr int OFF_WHH = OFF_WIH + 12 * 16 * FR;     // [12][16][64]
 constexpr int OFF_W2 = OFF_WHH + 12 * 16 * FR;      // [4][16][64]
 constexpr int OFF_W3 = OFF_W2 + 4 * 16 * FR;        // [1][16][64]
@@ -59,6 +60,8 @@ struct PolicyParams {
     const float *w;          // packed
     const float *obs;
     const int64_t *last;     // [rows] last action index, < 0 = none (all-zero one-hot); null = raw input rows
+    const float *feat;       // [rows / rows_per_feat][16] conv features placed in front of the obs columns, or null
+    int rows_per_feat;
     float *hidden;           // [rows][64] in/out
     float *q;                // [rows][n_actions] or null
     int64_t *actions;        // [rows]
@@ -98,6 +101,7 @@ __device__ __forceinline__ f32x4 mfma_chain(const float *a_lds, const float (&bf
     return acc;
 }
 
+template <int KS1>   // k-steps of fc1: 4 (inputs <= 16 wide) or 8 (<= 32 wide: conv features in front)
 __global__ __launch_bounds__(PBLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_policy(PolicyParams p) {
     __shared__ float s_a[16 * LDW];      // x, then h'
     __shared__ float s_b[16 * LDW];      // h1, then f
@@ -109,10 +113,10 @@ __global__ __launch_bounds__(PBLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 
     // every weight fragment this wavefront will use (120 floats per lane) and its biases, once
-    float b1[KIN / 4], bg[6][16], b2[16], b3f[4];
+    float b1[KS1], bg[6][16], b2[16], b3f[4];
     const unsigned ulane = lane;  // uniform base + 32-bit lane offset
 #pragma unroll
-    for (int kk = 0; kk < KIN / 4; kk++) b1[kk] = (p.w + OFF_W1 + (w * (KIN / 4) + kk) * FR)[ulane];
+    for (int kk = 0; kk < KS1; kk++) b1[kk] = (p.w + OFF_W1 + (w * (KIN_MAX / 4) + kk) * FR)[ulane];
 #pragma unroll
     for (int g = 0; g < 3; g++)   // torch.nn.GRUCell: gates ordered r, z, n in weight_ih / weight_hh
 #pragma unroll
@@ -130,24 +134,38 @@ __global__ __launch_bounds__(PBLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const float bir = p.w[OFF_BIH + col], biz = p.w[OFF_BIH + 64 + col], bin = p.w[OFF_BIH + 128 + col];
     const float bhr = p.w[OFF_BHH + col], bhz = p.w[OFF_BHH + 64 + col], bhn = p.w[OFF_BHH + 128 + col];
 
-    // staging: 16 threads per row, one input column and four hidden values each
+    // staging: 16 threads per row, NCOL input columns and four hidden values each.  Input row (agent.py:41-52,
+    // base_net.py:31-39): [16 conv features |] obs(4) | one_hot(last action) | one_hot(agent id); raw mode (no `last`):
+    // [16 conv features |] the caller's own columns.
+    constexpr int NCOL = KS1 / 4;
     const int tiles = (p.rows + 15) / 16;
-    const int in_dim = 4 + p.n_actions + p.n_agents;
+    const int fbase = p.feat ? NFEAT : 0, in_dim = fbase + 4 + p.n_actions + p.n_agents;
     const int srow = threadIdx.x >> 4, kcol = threadIdx.x & 15;
-    const bool col_float = p.last ? kcol < 4 : kcol < in_dim, col_last = p.last && kcol >= 4 && kcol < 4 + p.n_actions;
-    float xv;     // raw input value (obs column or caller-assembled row), where the column is a float input
-    int lav;      // last action of the row, in the one-hot(last action) columns
+    enum { ZERO, OBS, FEAT, LAST, AGENT };
+    int kind[NCOL], kidx[NCOL];
+#pragma unroll
+    for (int j = 0; j < NCOL; j++) {
+        const int k = kcol + 16 * j, ko = k - fbase;
+        kind[j] = k >= in_dim ? ZERO : k < fbase ? FEAT : (!p.last || ko < 4) ? OBS : ko < 4 + p.n_actions ? LAST : AGENT;
+        kidx[j] = kind[j] == FEAT ? k : kind[j] == OBS ? ko : kind[j] == LAST ? ko - 4 : ko - 4 - p.n_actions;
+    }
+    float xv[NCOL];   // float inputs (obs / feature columns)
+    int lav[NCOL];    // last action of the row (one-hot(last action) columns)
     float4 hv;
     auto fetch = [&](int tile) {   // loads only: nothing here waits for memory
         const int row = 16 * tile + srow < p.rows ? 16 * tile + srow : p.rows - 1;
-        xv = col_float ? p.obs[(size_t)row * p.obs_stride + p.obs_offset + kcol] : 0.0f;
-        lav = col_last ? (int)p.last[row] : -1;
+#pragma unroll
+        for (int j = 0; j < NCOL; j++) {
+            xv[j] = kind[j] == OBS ? p.obs[(size_t)row * p.obs_stride + p.obs_offset + kidx[j]]
+                  : kind[j] == FEAT ? p.feat[(size_t)(row / p.rows_per_feat) * NFEAT + kidx[j]] : 0.0f;
+            lav[j] = kind[j] == LAST ? (int)p.last[row] : -1;
+        }
         hv = *reinterpret_cast<const float4 *>(p.hidden + (size_t)row * H + 4 * kcol);
     };
-    auto input_value = [&](int row) {   // obs ++ one_hot(last action) ++ one_hot(agent id), agent.py:41-52
-        if (col_float) return xv;
-        if (col_last) return kcol - 4 == lav ? 1.0f : 0.0f;
-        return (p.last && kcol < in_dim && kcol - 4 - p.n_actions == row % p.n_agents) ? 1.0f : 0.0f;
+    auto input_value = [&](int j, int row) {
+        if (kind[j] == OBS || kind[j] == FEAT) return xv[j];
+        if (kind[j] == LAST) return kidx[j] == lav[j] ? 1.0f : 0.0f;
+        return (kind[j] == AGENT && kidx[j] == row % p.n_agents) ? 1.0f : 0.0f;
     };
 
     int tile = blockIdx.x;
@@ -155,14 +173,16 @@ __global__ __launch_bounds__(PBLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     for (int iter = 0; tile < tiles; tile += gridDim.x, iter++) {
         const int row0 = 16 * tile;
         POL_STAMP(0);
-        s_a[srow * LDW + kcol] = input_value(row0 + srow < p.rows ? row0 + srow : p.rows - 1);
+#pragma unroll
+        for (int j = 0; j < NCOL; j++)
+            s_a[srow * LDW + kcol + 16 * j] = input_value(j, row0 + srow < p.rows ? row0 + srow : p.rows - 1);
         *reinterpret_cast<float4 *>(s_h + srow * LDW + 4 * kcol) = hv;
         if (tile + (int)gridDim.x < tiles) fetch(tile + gridDim.x);
         __syncthreads();
         POL_STAMP(1);
 
         {   // h1 = relu(W1 x + b1), columns 16w..16w+15
-            const f32x4 acc = mfma_chain<KIN / 4>(s_a, b1, lane, zero);
+            const f32x4 acc = mfma_chain<KS1>(s_a, b1, lane, zero);
 #pragma unroll
             for (int r = 0; r < 4; r++) s_b[(crow + r) * LDW + col] = fmaxf(acc[r] + bias1, 0.0f);
         }
@@ -240,18 +260,132 @@ __global__ __launch_bounds__(PBLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     }
 }
 
+
+// ---- flight: conv front end of the agent network (network/base_net.py:9-18,31-36) ---------------------------------
+// Conv2d(1, 4, k=4, s=2) -> ReLU -> Conv2d(4, 1, k=3, s=1, p=1) -> ReLU -> Linear(576, 16) on the 50 x 50 probability
+// map (the reference's flight hyper-parameters, common/arguments.py:256-265; anything else stays on the torch path).
+// One block per map: the map, both conv outputs and the 16 x 576 linear weights live in LDS (60 KB, two blocks per
+// CU); persistent blocks loop over maps.  All agents of an env observe the same map (flight_env.py:223-230), so the
+// batched caller runs this once per ENV and k_policy fans the 16 features out to the env's rows.
+constexpr int MAPW = 50, C1W = 24, C1P = 26, C1CH = 4, NPOS = C1W * C1W, LIN_LD = NPOS + 1;
+
+struct ConvParams {
+    const float *c1w, *c1b, *c2w, *c2b, *lw, *lb;  // torch layouts: [4][1][4][4], [4], [1][4][3][3], [1], [16][576], [16]
+    const float *maps;                             // map m at maps + m * map_stride, 2500 floats ([50][50] row-major)
+    long long map_stride;
+    int n_maps, vec4;                              // vec4: every map is 16-byte aligned
+    float *feat;                                   // [n_maps][16]
+};
+
+__global__ __launch_bounds__(PBLOCK) void k_conv_features(ConvParams p) {
+    __shared__ float s_map[MAPW * MAPW];
+    __shared__ float s_c1[C1CH][C1P * C1P];   // conv1 output with the zero border conv2's padding needs
+    __shared__ float s_c2[NPOS];
+    __shared__ float s_lw[NFEAT * LIN_LD];
+    const int t = threadIdx.x;
+    float w1[C1CH][16], bias1[C1CH], w2[C1CH * 9], bias2;
+#pragma unroll
+    for (int c = 0; c < C1CH; c++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) w1[c][i] = p.c1w[c * 16 + i];
+        bias1[c] = p.c1b[c];
+    }
+    // 105 uniform weights do not fit the ~100 SGPRs a wavefront has: conv2's 37 are parked in VGPRs (the copy through
+    // inline asm keeps the compiler from treating them as scalars again), conv1's 68 stay scalar
+    auto to_vgpr = [](float sv) {
+        float vv;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(vv) : "s"(sv));
+        return vv;
+    };
+#pragma unroll
+    for (int i = 0; i < C1CH * 9; i++) w2[i] = to_vgpr(p.c2w[i]);
+    bias2 = to_vgpr(p.c2b[0]);
+    for (int i = t; i < NFEAT * NPOS; i += PBLOCK) s_lw[(i / NPOS) * LIN_LD + i % NPOS] = p.lw[i];
+    for (int i = t; i < C1CH * C1P * C1P; i += PBLOCK) (&s_c1[0][0])[i] = 0.0f;
+    const int j = t >> 4, sl = t & 15;   // linear: 16 threads per output feature
+    const float lbias = p.lb[j];
+
+    // The next map is fetched into registers while this one computes, and a map's 16 features are stored one
+    // iteration late: at the top of an iteration the only memory operations in flight are then the prefetch loads
+    // (loads and stores share one in-order counter, see k_policy).
+    constexpr int NV = (MAPW * MAPW / 4 + PBLOCK - 1) / PBLOCK;   // float4 per thread and map
+    static_assert(NV == 3, "three float4 per thread");
+    float4 pre0, pre1, pre2;   // plain scalars: an indexed private array captured by a lambda ends up in LDS
+    pre0 = pre1 = pre2 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define CONV_FETCH(m_)                                                                                        \
+    do {                                                                                                      \
+        const float4 *src4 = reinterpret_cast<const float4 *>(p.maps + (size_t)(m_) * p.map_stride);          \
+        pre0 = src4[t];                                                                                       \
+        pre1 = src4[t + PBLOCK];                                                                              \
+        if (t + 2 * PBLOCK < MAPW * MAPW / 4) pre2 = src4[t + 2 * PBLOCK];                                    \
+    } while (0)
+    if (p.vec4 && blockIdx.x < p.n_maps) CONV_FETCH(blockIdx.x);
+    float pend = 0.0f;
+    int pend_m = -1;
+    for (int m = blockIdx.x; m < p.n_maps; m += gridDim.x) {
+        if (p.vec4) {
+            reinterpret_cast<float4 *>(s_map)[t] = pre0;
+            reinterpret_cast<float4 *>(s_map)[t + PBLOCK] = pre1;
+            if (t + 2 * PBLOCK < MAPW * MAPW / 4) reinterpret_cast<float4 *>(s_map)[t + 2 * PBLOCK] = pre2;
+            if (m + (int)gridDim.x < p.n_maps) CONV_FETCH(m + gridDim.x);
+        } else {   // unaligned maps (caller-assembled rows): plain loads
+            const float *src = p.maps + (size_t)m * p.map_stride;
+            for (int i = t; i < MAPW * MAPW; i += PBLOCK) s_map[i] = src[i];
+        }
+        if (pend_m >= 0 && sl == 0) p.feat[(size_t)pend_m * NFEAT + j] = pend;
+        __syncthreads();
+        for (int pos = t; pos < NPOS; pos += PBLOCK) {   // conv1 + ReLU: 4 channels per position
+            const int oy = pos / C1W, ox = pos % C1W;
+            float in[16];
+#pragma unroll
+            for (int ky = 0; ky < 4; ky++)
+#pragma unroll
+                for (int kx = 0; kx < 4; kx++) in[ky * 4 + kx] = s_map[(2 * oy + ky) * MAPW + 2 * ox + kx];
+#pragma unroll
+            for (int c = 0; c < C1CH; c++) {
+                float acc = bias1[c];
+#pragma unroll
+                for (int i = 0; i < 16; i++) acc = fmaf(w1[c][i], in[i], acc);
+                s_c1[c][(oy + 1) * C1P + ox + 1] = fmaxf(acc, 0.0f);
+            }
+        }
+        __syncthreads();
+        for (int pos = t; pos < NPOS; pos += PBLOCK) {   // conv2 (pad 1) + ReLU
+            const int oy = pos / C1W, ox = pos % C1W;
+            float acc = bias2;
+#pragma unroll
+            for (int c = 0; c < C1CH; c++)
+#pragma unroll
+                for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                    for (int kx = 0; kx < 3; kx++)
+                        acc = fmaf(w2[c * 9 + ky * 3 + kx], s_c1[c][(oy + ky) * C1P + ox + kx], acc);
+            s_c2[pos] = fmaxf(acc, 0.0f);
+        }
+        __syncthreads();
+        float acc = 0.0f;   // linear 576 -> 16: feature j by 16 threads, 36 terms each, butterfly over the 16 lanes
+#pragma unroll 4
+        for (int i = 0; i < NPOS / 16; i++) acc = fmaf(s_lw[j * LIN_LD + sl + 16 * i], s_c2[sl + 16 * i], acc);
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        pend = acc + lbias;
+        pend_m = m;
+        // the next map's staging only writes s_map (last read before the second barrier above)
+    }
+    if (pend_m >= 0 && sl == 0) p.feat[(size_t)pend_m * NFEAT + j] = pend;
+#undef CONV_FETCH
+}
+
 thread_local char g_perr[200] = "";
 
 // persistent grid: as many blocks as the device holds at once (queried once)
-int resident_blocks() {
-    static const int resident = [] {
-        int dev = 0, cus = 256, per_cu = 2;
-        if (hipGetDevice(&dev) != hipSuccess) return 512;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_policy, PBLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 2;
-        return cus * per_cu;
-    }();
-    return resident;
+template <typename K>
+int resident_blocks(K kernel) {
+    int dev = 0, cus = 256, per_cu = 2;
+    if (hipGetDevice(&dev) != hipSuccess) return 512;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, PBLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    return cus * per_cu;
 }
 
 }  // namespace
@@ -265,8 +399,8 @@ size_t cs_policy_packed_floats(void) { return (size_t)PACKED_FLOATS; }
 int cs_policy_pack(const float *fc1_w, const float *fc1_b, const float *w_ih, const float *b_ih, const float *w_hh,
                    const float *b_hh, const float *fc2a_w, const float *fc2a_b, const float *fc2b_w, const float *fc2b_b,
                    int in_dim, int n_actions, float *packed) {
-    if (in_dim < 1 || in_dim > KIN || n_actions < 1 || n_actions > 16) {
-        snprintf(g_perr, sizeof(g_perr), "cs_policy_pack: in_dim must be 1..16 and n_actions 1..16");
+    if (in_dim < 1 || in_dim > KIN_MAX || n_actions < 1 || n_actions > 16) {
+        snprintf(g_perr, sizeof(g_perr), "cs_policy_pack: in_dim must be 1..32 and n_actions 1..16");
         return CS_E_ARG;
     }
     for (int i = 0; i < PACKED_FLOATS; i++) packed[i] = 0.0f;
@@ -278,7 +412,7 @@ int cs_policy_pack(const float *fc1_w, const float *fc1_b, const float *w_ih, co
                     packed[off + (nt * ksteps + kk) * FR + l] = (n < n_out && k < k_in) ? w[(size_t)n * k_in + k] : 0.0f;
                 }
     };
-    frag(OFF_W1, 4, KIN / 4, fc1_w, 64, in_dim);
+    frag(OFF_W1, 4, KIN_MAX / 4, fc1_w, 64, in_dim);
     frag(OFF_WIH, 12, 16, w_ih, 192, 64);
     frag(OFF_WHH, 12, 16, w_hh, 192, 64);
     frag(OFF_W2, 4, 16, fc2a_w, 64, 64);
@@ -293,21 +427,51 @@ int cs_policy_pack(const float *fc1_w, const float *fc1_b, const float *w_ih, co
 
 // One forward of the shared agent network over `rows` = B*n rows (row r = env r / n_agents, agent r % n_agents).
 // obs row r = 4 floats at obs_dev + r*obs_stride + obs_offset; last_dev[r] = last action (< 0: none);
+// feat_dev (nullable): 16 conv features per group of rows_per_feat rows, placed in front of the obs columns;
 // hidden_dev [rows][64] is updated in place; q_dev (nullable) [rows][n_actions]; actions_dev [rows] int64.
 int cs_policy_forward(const float *packed_dev, const float *obs_dev, int obs_stride, int obs_offset, const int64_t *last_dev,
-                      float *hidden_dev, float *q_dev, int64_t *actions_dev, int rows, int n_agents, int n_actions,
-                      float epsilon, uint64_t seed, uint32_t step, void *stream) {
+                      const float *feat_dev, int rows_per_feat, float *hidden_dev, float *q_dev, int64_t *actions_dev,
+                      int rows, int n_agents, int n_actions, float epsilon, uint64_t seed, uint32_t step, void *stream) {
+    const int in_dim = (feat_dev ? NFEAT : 0) + 4 + n_actions + n_agents;
     if (!packed_dev || !obs_dev || !hidden_dev || !actions_dev || rows < 1 || n_agents < 1 || n_actions < 1 ||
-        4 + n_actions + n_agents > KIN) {
-        snprintf(g_perr, sizeof(g_perr), "cs_policy_forward: bad argument (need 4 + n_actions + n_agents <= 16)");
+        in_dim > KIN_MAX || (feat_dev && rows_per_feat < 1)) {
+        snprintf(g_perr, sizeof(g_perr), "cs_policy_forward: bad argument (input width %d, limit %d)", in_dim, KIN_MAX);
         return CS_E_ARG;
     }
     PolicyParams p{rows, n_agents, n_actions, obs_stride, obs_offset, epsilon, seed, step, packed_dev, obs_dev, last_dev,
-                   hidden_dev, q_dev, actions_dev};
-    const int tiles = (rows + 15) / 16, resident = resident_blocks();
-    hipLaunchKernelGGL(k_policy, dim3(tiles < resident ? tiles : resident), dim3(PBLOCK), 0, (hipStream_t)stream, p);
+                   feat_dev, rows_per_feat, hidden_dev, q_dev, actions_dev};
+    const int tiles = (rows + 15) / 16;
+    if (in_dim <= 16) {
+        static const int resident = resident_blocks(k_policy<4>);   // persistent grid: what the device holds at once
+        hipLaunchKernelGGL(k_policy<4>, dim3(tiles < resident ? tiles : resident), dim3(PBLOCK), 0, (hipStream_t)stream, p);
+    } else {
+        static const int resident = resident_blocks(k_policy<8>);
+        hipLaunchKernelGGL(k_policy<8>, dim3(tiles < resident ? tiles : resident), dim3(PBLOCK), 0, (hipStream_t)stream, p);
+    }
     if (hipGetLastError() != hipSuccess) {
         snprintf(g_perr, sizeof(g_perr), "cs_policy_forward: kernel launch failed");
+        return CS_E_LAUNCH;
+    }
+    return CS_OK;
+}
+
+// flight: conv features of n_maps probability maps (map m = 2500 floats at maps_dev + m*map_stride) -> feat_dev
+// [n_maps][16].  Weights are the torch tensors of network/base_net.py's `conv` / `linear` as they are (device pointers).
+int cs_policy_conv_features(const float *conv1_w_dev, const float *conv1_b_dev, const float *conv2_w_dev,
+                            const float *conv2_b_dev, const float *lin_w_dev, const float *lin_b_dev,
+                            const float *maps_dev, int64_t map_stride, int n_maps, float *feat_dev, void *stream) {
+    if (!conv1_w_dev || !conv1_b_dev || !conv2_w_dev || !conv2_b_dev || !lin_w_dev || !lin_b_dev || !maps_dev || !feat_dev ||
+        n_maps < 1) {
+        snprintf(g_perr, sizeof(g_perr), "cs_policy_conv_features: bad argument");
+        return CS_E_ARG;
+    }
+    const int vec4 = ((uintptr_t)maps_dev % 16 == 0) && (map_stride % 4 == 0);
+    ConvParams p{conv1_w_dev, conv1_b_dev, conv2_w_dev, conv2_b_dev, lin_w_dev, lin_b_dev, maps_dev, (long long)map_stride,
+                 n_maps, vec4, feat_dev};
+    static const int resident = resident_blocks(k_conv_features);
+    hipLaunchKernelGGL(k_conv_features, dim3(n_maps < resident ? n_maps : resident), dim3(PBLOCK), 0, (hipStream_t)stream, p);
+    if (hipGetLastError() != hipSuccess) {
+        snprintf(g_perr, sizeof(g_perr), "cs_policy_conv_features: kernel launch failed");
         return CS_E_LAUNCH;
     }
     return CS_OK;

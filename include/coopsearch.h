@@ -149,29 +149,42 @@ int cs_metrics(const cs_config *cfg, void *state_dev, double *out4_dev, void *st
 
 /* ---- caller-side row f3: fused forward of the shared recurrent agent network ------------
  * Replaces the per-agent batch-1 loop of agent/agent.py:33-75 (choose_action) over network/base_net.py:5-46
- * (fc1 -> ReLU -> GRUCell(64) -> fc2[Linear, ReLU, Linear]) for the non-conv (flight_easy) network: ONE launch
- * for all rows = B * n_agents, fp32 on the matrix cores, epsilon-greedy choice on the device. */
+ * ([conv ->] fc1 -> ReLU -> GRUCell(64) -> fc2[Linear, ReLU, Linear]): ONE launch for all rows = B * n_agents, fp32 on
+ * the matrix cores, epsilon-greedy choice on the device; for flight, one more launch for the conv front end. */
 
 /* floats in a packed weight blob */
 size_t cs_policy_packed_floats(void);
 
 /* HOST: torch-layout weights (fc1.weight [64][in_dim], rnn.weight_ih / weight_hh [192][64], fc2.0.weight [64][64],
  * fc2.2.weight [n_actions][64] and their biases) -> packed_host[cs_policy_packed_floats()], to be copied to the device.
- * in_dim = 4 + n_actions + n_agents <= 16 (obs ++ one-hot last action ++ one-hot agent id, agent.py:41-52). */
+ * in_dim = [16 conv features +] 4 + n_actions + n_agents <= 32 (agent.py:41-52, base_net.py:31-39). */
 int cs_policy_pack(const float *fc1_w, const float *fc1_b, const float *w_ih, const float *b_ih, const float *w_hh,
                    const float *b_hh, const float *fc2a_w, const float *fc2a_b, const float *fc2b_w, const float *fc2b_b,
                    int in_dim, int n_actions, float *packed_host);
 
 /* One forward over rows = B*n (row r: env r / n_agents, agent r % n_agents).  obs row r = 4 floats at
- * obs_dev + r*obs_stride + obs_offset (floats; 16-byte aligned); last_dev[r] = previous action or < 0 for none
+ * obs_dev + r*obs_stride + obs_offset (floats); last_dev[r] = previous action or < 0 for none
  * (last_dev NULL = raw mode: the row at obs_dev + r*obs_stride + obs_offset already holds all 4 + n_actions +
- * n_agents inputs, any alignment);
+ * n_agents non-conv inputs);
+ * feat_dev (NULL for flight_easy): float [rows / rows_per_feat][16] conv features (cs_policy_conv_features) that go in
+ * front of the obs columns; rows r*rows_per_feat .. +rows_per_feat-1 share feature row r (rows_per_feat = n_agents
+ * when the features were computed once per env);
  * hidden_dev float [rows][64] updated in place; q_dev float [rows][n_actions] or NULL; actions_dev int64 [rows]:
  * argmax_a q (first maximum), or with probability epsilon a uniform action drawn from a counter-based generator
  * keyed by (seed, step, row). */
 int cs_policy_forward(const float *packed_dev, const float *obs_dev, int obs_stride, int obs_offset,
-                      const int64_t *last_dev, float *hidden_dev, float *q_dev, int64_t *actions_dev, int rows,
-                      int n_agents, int n_actions, float epsilon, uint64_t seed, uint32_t step, void *stream);
+                      const int64_t *last_dev, const float *feat_dev, int rows_per_feat, float *hidden_dev, float *q_dev,
+                      int64_t *actions_dev, int rows, int n_agents, int n_actions, float epsilon, uint64_t seed,
+                      uint32_t step, void *stream);
+
+/* flight: the conv front end of base_net.py:9-18,31-36 with the reference's hyper-parameters (common/arguments.py:256-265:
+ * Conv2d(1,4,k=4,s=2) -> ReLU -> Conv2d(4,1,k=3,s=1,p=1) -> ReLU -> Linear(576,16)) on n_maps 50x50 probability maps;
+ * map m = 2500 floats at maps_dev + m*map_stride.  The weight pointers are the torch tensors as they are (device).
+ * All agents of an env observe the same map (flight_env.py:223-230): run it once per env on the env's first obs row
+ * (map_stride = n_agents * 2504) and pass rows_per_feat = n_agents to cs_policy_forward. */
+int cs_policy_conv_features(const float *conv1_w_dev, const float *conv1_b_dev, const float *conv2_w_dev,
+                            const float *conv2_b_dev, const float *lin_w_dev, const float *lin_b_dev,
+                            const float *maps_dev, int64_t map_stride, int n_maps, float *feat_dev, void *stream);
 const char *cs_policy_last_error(void);
 
 #ifdef __cplusplus

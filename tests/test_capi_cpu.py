@@ -140,7 +140,7 @@ def test_policy_pack_layout_host_only():
         return packed[off + (nt * ksteps + kk) * 64: off + (nt * ksteps + kk) * 64 + 64]
 
     off = 0
-    for w, tiles, ksteps in ((ws[0], 4, 4), (ws[2], 12, 16), (ws[4], 12, 16), (ws[6], 4, 16), (ws[8], 1, 16)):
+    for w, tiles, ksteps in ((ws[0], 4, 8), (ws[2], 12, 16), (ws[4], 12, 16), (ws[6], 4, 16), (ws[8], 1, 16)):
         for nt in range(tiles):
             for kk in range(ksteps):
                 rows, ks = 16 * nt + (lanes & 15), 4 * kk + (lanes >> 4)
@@ -152,5 +152,5 @@ def test_policy_pack_layout_host_only():
         assert np.array_equal(packed[off:off + len(b)], b) and not packed[off + len(b):off + width].any()
         off += width
     assert off == n
-    assert L.cs_policy_pack(*[C.c_void_p(w.ctypes.data) for w in ws], 17, nA, C.c_void_p(packed.ctypes.data)) != 0
+    assert L.cs_policy_pack(*[C.c_void_p(w.ctypes.data) for w in ws], 33, nA, C.c_void_p(packed.ctypes.data)) != 0
     assert b"in_dim" in L.cs_policy_last_error()

@@ -141,3 +141,75 @@ def test_collector_and_evaluate_accept_the_fused_policy():
     assert agree / total > 0.99
     win_rate, episode_reward, targets_find = cs.evaluate(env, fused.policy(0.0, True))
     assert 0.0 <= win_rate <= 1.0 and 0.0 <= targets_find <= 15.0
+
+
+# ---- flight: conv front end (k_conv_features) + 26-wide fc1 -----------------------------------------------------------
+
+def _flight_args(n=3):
+    a = cs.make_env_args("flight", n_agents=n)
+    a.n_actions, a.obs_shape, a.rnn_hidden_dim, a.last_action, a.reuse_network = 3, 4, 64, True, True
+    return a
+
+
+def test_flight_fused_forward_matches_reference_fixture():
+    """The reference's own conv RNN outputs (fp64) for seeded weights and random 2510-wide rows (one map per row)."""
+    z = np.load(os.path.join(GOLD, "rnn_forward.npz"))
+    a = _flight_args(3)
+    net = AgentRNN(26, a).cuda()
+    net.load_state_dict({k[len("flight_w_"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("flight_w_")})
+    x = torch.from_numpy(z["flight_x"]).float().cuda()
+    rows = x.shape[0]
+    fused = FusedAgents(a, rows // 3, net=net)
+    fused.hidden.copy_(torch.from_numpy(z["flight_h"]).float().cuda())
+    act = fused.forward_raw(x, want_q=True)
+    assert np.allclose(fused.q.reshape(rows, -1).cpu().numpy(), z["flight_q"], atol=TOL, rtol=TOL)
+    assert np.allclose(fused.hidden.cpu().numpy(), z["flight_h2"], atol=TOL, rtol=TOL)
+    assert np.array_equal(act.reshape(-1).cpu().numpy(), z["flight_q"].argmax(1))
+
+
+@pytest.mark.parametrize("n,B", [(3, 1), (3, 50), (5, 33)])
+def test_flight_fused_forward_matches_torch_module(n, B):
+    torch.manual_seed(7 * n + B)
+    a = _flight_args(n)
+    net = AgentRNN(rnn_input_shape(a), a).cuda()
+    for p in net.parameters():
+        p.data.mul_(2.0)
+    fused = FusedAgents(a, B, net=net)
+    ref = BatchedAgents(a, B, net=net)
+    last = torch.zeros(B, n, 3, device="cuda")
+    for t in range(4):
+        maps = torch.rand(B, 1, 2500, device="cuda").expand(B, n, 2500)       # one map per env, as get_obs gives
+        obs = torch.cat([maps, torch.rand(B, n, 4, device="cuda")], 2).contiguous()
+        act = fused.choose_action(obs, want_q=True).clone()
+        x = torch.cat([obs, last, ref.agent_ids], 2).reshape(B * n, -1)
+        with torch.no_grad():
+            q_ref, ref.hidden = net(x, ref.hidden)
+        q_ref = q_ref.reshape(B, n, -1)
+        assert torch.allclose(fused.q, q_ref, atol=5 * TOL, rtol=5 * TOL), (t, (fused.q - q_ref).abs().max().item())
+        assert torch.allclose(fused.hidden, ref.hidden, atol=5 * TOL, rtol=5 * TOL)
+        # the conv features themselves
+        with torch.no_grad():
+            f_ref = net.linear(net.conv(obs[:, 0, :2500].reshape(B, 1, 50, 50)).reshape(B, -1))
+        assert torch.allclose(fused.feat, f_ref, atol=5 * TOL, rtol=5 * TOL)
+        clear = (q_ref.topk(2, dim=2).values.diff(dim=2).abs()[..., 0]) > 1e-3
+        assert (act == q_ref.argmax(2))[clear].all()
+        ref.hidden = fused.hidden.clone()
+        last = torch.nn.functional.one_hot(act, 3).float()
+
+
+def test_flight_closed_loop_and_collector_with_fused_agents():
+    a = _flight_args(3)
+    B = 64
+    env = cs.BatchedFlightEnv(a, batch=B, freeze_done=True)
+    cs.apply_env_info(a, env)
+    torch.manual_seed(3)
+    fused = FusedAgents(a, B)
+    ref = BatchedAgents(a, B, net=fused.net)
+    col = cs.EpisodeCollector(env)
+    env.seed(np.arange(B))
+    ep_f, rew_f, win_f, found_f = col.generate_episodes(agents=fused, init=True)
+    env.seed(np.arange(B))
+    ep_t, rew_t, win_t, found_t = col.generate_episodes(policy=ref.policy(0.0, True), init=True)
+    same = (ep_f["u"] == ep_t["u"]).reshape(B, -1).all(1) & (found_f == found_t)
+    assert same.float().mean().item() > 0.9   # a near-tie in q flips an env's whole trajectory; the bulk is identical
+    assert torch.equal(ep_f["o"][same], ep_t["o"][same]) and torch.equal(ep_f["r"][same], ep_t["r"][same])

@@ -15,7 +15,7 @@ def main():
         env = cs.BatchedFlightEnv(args, batch=B, freeze_done=True)
         cs.apply_env_info(args, env)
         torch.manual_seed(0)
-        fused = env_name == "flight_easy" and os.environ.get("TORCH_POLICY") != "1"
+        fused = os.environ.get("TORCH_POLICY") != "1"
         agents = cs.FusedAgents(args, B) if fused else cs.BatchedAgents(args, B)   # csrc/policy.hip vs torch modules
         T = args.episode_limit
         last = torch.zeros(B, n, 3, device="cuda")
