@@ -565,3 +565,30 @@ def test_long_horizon_matches_oracle(kernel):
         compare_with_oracle(env, ob, B, n, m, "after 20000 steps")
     h = hdr(env)
     assert h[:, _lib.H_EPISODES].min() >= 100 and int(words(h).min()) > 40 * 624
+
+
+def test_flight_long_horizon_matches_oracle():
+    """flight, default time limit, 1000 steps with auto-reset (5 episodes per env): the probability map persists
+    across episodes and decays towards 0 where the agents keep looking; rewards / flags exact throughout."""
+    B, T, n, m = 8, 1000, 3, 15
+    seeds = np.arange(B, dtype=np.uint32) + 901
+    args = cs.make_env_args("flight", n_agents=n, agent_mode=0)
+    env = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, freeze_done=False, auto_reset=True)
+    env.seed(seeds)
+    env.reset(init=True)
+    cfg = orc.make_config(variant="flight", n_agents=n, agent_mode=0)
+    rng = np.random.RandomState(23)
+    with orc.hip_equivalent_arithmetic():
+        ob = orc.OracleBatch(cfg, B, seeds)
+        ob.reset(init=True, threads=8)
+        for t in range(T):
+            a = rng.randint(0, 3, size=(B, n)).astype(np.int32)
+            r, term, win = env.step(torch.from_numpy(a))
+            orr, ot, ow = ob.step(a, auto_reset=True, freeze_done=False, threads=8)
+            np.testing.assert_array_equal(r.cpu().numpy(), orr, err_msg=f"reward step {t}")
+            np.testing.assert_array_equal(term.cpu().numpy().astype(np.uint8), ot)
+            if t % 100 == 99:
+                np.testing.assert_allclose(env.get_obs().cpu().numpy(), ob.obs, rtol=0, atol=F32_TOL,
+                                           err_msg=f"obs (map + feats) step {t}")
+        compare_with_oracle(env, ob, B, n, m, "flight long horizon")
+        assert hdr(env)[:, _lib.H_EPISODES].min() >= 5
