@@ -180,13 +180,24 @@ def closed_loop_measurement(cs, dev, n, B, K, W, env_name="flight_easy"):
     cs.apply_env_info(args, env)
     torch.manual_seed(0)
     agents = cs.FusedAgents(args, B, device=dev)
-    for _ in range(W):
-        env.step(agents.choose_action(env.get_obs()))
+    one_launch = env_name == "flight_easy"   # k_rollout_policy: 100 closed-loop steps per launch
+    chunk = 100
+    out = env.rollout_policy(agents, chunk) if one_launch else None
+
+    def advance(steps):
+        if one_launch:
+            for _ in range(steps // chunk):
+                env.rollout_policy(agents, chunk, out=out, update_views=False)
+        else:
+            for _ in range(steps):
+                env.step(agents.choose_action(env.get_obs()))
+
+    K, W = (K // chunk) * chunk, max(chunk, (W // chunk) * chunk)
+    advance(W)
     torch.cuda.synchronize(dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    for _ in range(K):
-        env.step(agents.choose_action(env.get_obs()))
+    advance(K)
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     obs = env.get_obs()
@@ -198,7 +209,9 @@ def closed_loop_measurement(cs, dev, n, B, K, W, env_name="flight_easy"):
     pol_us = e0.elapsed_time(e1) * 1e3 / 200
     del env, agents
     torch.cuda.empty_cache()
-    out = {"workload": f"closed loop: {env_name} {n}a15t B={B}, recurrent policy (csrc/policy.hip) + env step per step",
+    out = {"workload": f"closed loop: {env_name} {n}a15t B={B}, recurrent policy picks every action"
+                       + (" (k_rollout_policy: network + env step fused, 100 steps per launch)" if one_launch
+                          else " (conv features, policy, step, map kernels per step)"),
            "mode": "closed-loop", "value": B * K / dt, "unit": "env-steps/s", "ms_per_step": dt * 1e3 / K,
            "policy_kernels_us": pol_us}
     if env_name == "flight_easy":   # one kernel, GEMM-shaped: price it against the fp32 matrix peak

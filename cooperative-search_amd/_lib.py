@@ -13,8 +13,8 @@ H_WORDS_LO, H_WORDS_HI, H_CURR_REWARD, H_NEWLY_RESET = 8, 9, 10, 11
 FREEZE_DONE, AUTO_RESET, ACTIONS_I64, KERNEL_GROUP, KERNEL_LANE = 1, 2, 4, 8, 16
 
 EXPORTS = ["cs_abi_version", "cs_last_error", "cs_state_layout", "cs_init", "cs_seed", "cs_reset", "cs_step",
-           "cs_rollout", "cs_emit", "cs_metrics", "cs_policy_packed_floats", "cs_policy_pack", "cs_policy_forward",
-           "cs_policy_conv_features", "cs_policy_last_error"]
+           "cs_rollout", "cs_rollout_policy", "cs_emit", "cs_metrics", "cs_policy_packed_floats", "cs_policy_pack", "cs_policy_forward",
+           "cs_policy_conv_features", "cs_policy_last_error", "cs_store_episodes", "cs_episodes_last_error"]
 
 
 class CsConfig(C.Structure):
@@ -33,6 +33,11 @@ class CsConfig(C.Structure):
 class CsLayout(C.Structure):
     _fields_ = [("total_bytes", C.c_size_t), ("tgt_off", C.c_size_t), ("agent_off", C.c_size_t),
                 ("hdr_off", C.c_size_t), ("mt_off", C.c_size_t), ("prob_off", C.c_size_t)]
+
+
+class CsEpisodeOut(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("o", "u", "s", "r", "o_next", "s_next", "avail_u", "avail_u_next", "u_onehot",
+                                          "padded", "terminated")]
 
 
 class CoopSearchError(RuntimeError):
@@ -69,17 +74,22 @@ def load():
     L.cs_reset.argtypes = [C.POINTER(CsConfig), vp, vp, C.c_int, vp, vp, vp]
     L.cs_step.argtypes = [C.POINTER(CsConfig), vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.cs_rollout.argtypes = [C.POINTER(CsConfig), vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
+    L.cs_rollout_policy.argtypes = [C.POINTER(CsConfig), vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32,
+                                    vp, vp, vp, vp, vp, vp, vp]
     L.cs_emit.argtypes = [C.POINTER(CsConfig), vp, vp, vp, vp]
     L.cs_metrics.argtypes = [C.POINTER(CsConfig), vp, vp, vp]
     L.cs_policy_packed_floats.restype = C.c_size_t
     L.cs_policy_last_error.restype = C.c_char_p
+    L.cs_episodes_last_error.restype = C.c_char_p
+    L.cs_store_episodes.argtypes = [C.c_int] * 6 + [vp] * 6 + [C.POINTER(CsEpisodeOut), vp]
     L.cs_policy_pack.argtypes = [vp] * 10 + [C.c_int, C.c_int, vp]
     L.cs_policy_forward.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int,
                                     C.c_float, C.c_uint64, C.c_uint32, vp]
     L.cs_policy_conv_features.argtypes = [vp] * 7 + [C.c_int64, C.c_int, vp, vp]
     for name in EXPORTS:
         fn = getattr(L, name)
-        if name not in ("cs_abi_version", "cs_last_error", "cs_policy_packed_floats", "cs_policy_last_error"):
+        if name not in ("cs_abi_version", "cs_last_error", "cs_policy_packed_floats", "cs_policy_last_error",
+                        "cs_episodes_last_error"):
             fn.restype = C.c_int
     if L.cs_abi_version() != 1:
         raise CoopSearchError("libcoopsearch_hip.so: ABI version mismatch")

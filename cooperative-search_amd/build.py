@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB_PATH = os.environ.get("COOPSEARCH_LIB") or os.path.join(CSRC, "libcoopsearch_hip.so")  # override: experiments only
-SOURCES = ["coopsearch.hip", "policy.hip", "trig_table.inc"]
+SOURCES = ["coopsearch.hip", "policy.hip", "episodes.hip", "policy_dev.h", "trig_table.inc"]
 HEADERS = [os.path.join(ROOT, "include", "coopsearch.h")]
 
 
@@ -55,7 +55,7 @@ def build_extension(force=False, verbose=False):
             return LIB_PATH
         tmp = f"{LIB_PATH}.tmp.{os.getpid()}"
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-               "-I", os.path.join(ROOT, "include"), os.path.join(CSRC, "coopsearch.hip"), os.path.join(CSRC, "policy.hip"), "-o", tmp]
+               "-I", os.path.join(ROOT, "include"), os.path.join(CSRC, "coopsearch.hip"), os.path.join(CSRC, "policy.hip"), os.path.join(CSRC, "episodes.hip"), "-o", tmp]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd, cwd=CSRC)

@@ -7,22 +7,82 @@ dimension of B episodes instead of 1.  `evaluate` is `Runner.evaluate` (runner.p
 `collect_experiment_data` the found-fraction curve of runner.py:139-171 / rollout.py:143-204, both reduced over
 ranks with the all-gather of dist.py.
 
-The env arithmetic stays in the HIP kernels; this module only moves tensors (torch ops on the device).
+The env arithmetic stays in the HIP kernels; the episode batch itself (masking, padding, the [T, B] -> [B, T]
+transposition) is assembled by `cs_store_episodes` (csrc/episodes.hip) in one pass, either into fresh tensors or
+straight into the ring of a `DeviceReplayBuffer`.
 """
+import ctypes as C
+
 import torch
 
+from . import _lib
 from . import dist as _dist
+from .replay import KEYS
+
+
+def assemble_episodes(o, s, u, r, term, n_actions, out=None, slots=None):
+    """Step-major tables -> the reference's 11-key episode batch (rollout.py:66-76,105-132) with one kernel pass.
+    o [T+1, B, n, w], s [T+1, B, S], u int64 [T, B, n], r [T, B], term bool/uint8 [T, B] (device, contiguous).
+    out: dict of float32 [slots, T, ...] destinations (default: fresh [B, T, ...] tensors); slots: int64 [B] destination
+    slot of each env's episode (default: its own index)."""
+    T, B, n = u.shape
+    w, S, A = o.shape[-1], s.shape[-1], int(n_actions)
+    dev = o.device
+    if out is None:
+        shapes = {"o": (B, T, n, w), "u": (B, T, n, 1), "s": (B, T, S), "r": (B, T, 1), "o_next": (B, T, n, w),
+                  "s_next": (B, T, S), "avail_u": (B, T, n, A), "avail_u_next": (B, T, n, A), "u_onehot": (B, T, n, A),
+                  "padded": (B, T, 1), "terminated": (B, T, 1)}
+        out = {k: torch.empty(shapes[k], dtype=torch.float32, device=dev) for k in KEYS}
+    for t in (o, s, u, r, term) + tuple(out[k] for k in KEYS):
+        if not t.is_contiguous() or t.device != dev:
+            raise ValueError("assemble_episodes: tensors must be contiguous and on one device")
+    if any(out[k].dtype != torch.float32 or out[k].shape[1] != T for k in KEYS) or u.dtype != torch.int64:
+        raise ValueError("assemble_episodes: destinations must be float32 [slots, T, ...] and u int64")
+    L = _lib.load()
+    eo = _lib.CsEpisodeOut(**{k: out[k].data_ptr() for k in KEYS})
+    rc = L.cs_store_episodes(B, T, n, A, w, S, o.data_ptr(), s.data_ptr(), u.data_ptr(), r.data_ptr(),
+                             term.view(torch.uint8).data_ptr(), slots.data_ptr() if slots is not None else None,
+                             C.byref(eo), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise _lib.CoopSearchError(L.cs_episodes_last_error().decode())
+    return out
+
+
+def assemble_episodes_torch(o, s, u, r, term, n_actions):
+    """The same batch with stock torch ops (the definition the kernel is tested against)."""
+    T, B, n = u.shape
+    A = int(n_actions)
+    done_before = torch.zeros(T, B, dtype=torch.bool, device=o.device)
+    done_before[1:] = term[:-1].to(torch.bool)
+    real = ~done_before  # a step is real if the env had not terminated before it
+    rf = real.to(torch.float32)
+
+    def bt(x):  # [T, B, ...] -> [B, T, ...]
+        return x.transpose(0, 1).contiguous()
+
+    m4 = rf[:, :, None, None]
+    onehot = torch.nn.functional.one_hot(u, A).to(torch.float32)
+    ones = torch.ones(T, B, n, A, dtype=torch.float32, device=o.device)
+    return dict(
+        o=bt(o[:-1] * m4), s=bt(s[:-1] * rf[:, :, None]), u=bt((u.to(torch.float32) * rf[:, :, None])[..., None]),
+        r=bt((r * rf)[..., None]), avail_u=bt(ones * m4), o_next=bt(o[1:] * m4), s_next=bt(s[1:] * rf[:, :, None]),
+        avail_u_next=bt(ones * m4), u_onehot=bt(onehot * m4), padded=bt((1.0 - rf)[..., None]),
+        terminated=bt(torch.where(real, term.to(torch.float32), torch.ones_like(rf))[..., None]))
 
 
 class EpisodeCollector:
     def __init__(self, env):
         self.env = env
 
-    def generate_episodes(self, policy=None, actions=None, init=False, agents=None, epsilon=0.0, evaluate=True):
+    def generate_episodes(self, policy=None, actions=None, init=False, agents=None, epsilon=0.0, evaluate=True,
+                          one_launch=True, into=None):
         """One episode per env.  Either `actions` (open-loop table, int [T, B, n]; flight_easy runs it as ONE fused
         rollout launch), `policy(obs[B,n,obs], state[B,S], last_onehot[B,n,A], t) -> int actions [B, n]`, or `agents`
-        (a `FusedAgents`: two launches per step -- policy kernel, env step -- writing straight into the [T, ...] episode
-        tables, no copies).
+        (a `FusedAgents`: flight_easy with n <= 5 and one_launch: the WHOLE episode -- T x (network forward, env step)
+        -- is one kernel launch, `env.rollout_policy`; otherwise two launches per step; both write straight into the
+        [T, ...] episode tables, no copies).
+        `into` (a `DeviceReplayBuffer`): the batch is written straight into the buffer's next B ring slots
+        (store_episode without the intermediate copy) and the returned episode dict is None.
         Returns (episode dict of float32 [B, T, ...] tensors, episode_reward[B], win_tag[B] bool, targets_find[B])."""
         env = self.env
         B, n, T, A = env.batch, env.n_agents, env.time_limit, env.n_actions
@@ -47,6 +107,10 @@ class EpisodeCollector:
                 u.copy_(acts.to(torch.int64))
                 r.copy_(out["reward"])
                 term.copy_(out["terminated"])
+            elif agents is not None and one_launch and not env.flight and n <= 5:
+                agents.init_hidden()
+                env.rollout_policy(agents, T, epsilon, evaluate,
+                                   out=dict(actions=u, reward=r, terminated=term, obs=o[1:], state=s[1:]))
             elif agents is not None:
                 agents.init_hidden()
                 none = torch.full((B, n), -1, dtype=torch.int64, device=dev)
@@ -62,23 +126,12 @@ class EpisodeCollector:
                     env.step(u[t], out=dict(reward=r[t], terminated=term[t], obs=o[t + 1], state=s[t + 1]))
                     last = torch.nn.functional.one_hot(u[t], A).to(torch.float32)
                 env.refresh()
-            # a step is real if the env had not terminated before it
-            done_before = torch.zeros(T, B, dtype=torch.bool, device=dev)
-            done_before[1:] = term[:-1]
-            real = ~done_before  # [T, B]
-            rf = real.to(torch.float32)
-
-            def bt(x):  # [T, B, ...] -> [B, T, ...]
-                return x.transpose(0, 1).contiguous()
-
-            m4 = rf[:, :, None, None]
-            onehot = torch.nn.functional.one_hot(u, A).to(torch.float32)
-            ones = torch.ones(T, B, n, A, dtype=torch.float32, device=dev)
-            episode = dict(
-                o=bt(o[:-1] * m4), s=bt(s[:-1] * rf[:, :, None]), u=bt((u.to(torch.float32) * rf[:, :, None])[..., None]),
-                r=bt((r * rf)[..., None]), avail_u=bt(ones * m4), o_next=bt(o[1:] * m4), s_next=bt(s[1:] * rf[:, :, None]),
-                avail_u_next=bt(ones * m4), u_onehot=bt(onehot * m4), padded=bt((1.0 - rf)[..., None]),
-                terminated=bt(torch.where(real, term.to(torch.float32), torch.ones_like(rf))[..., None]))
+            if into is not None:
+                slots = torch.as_tensor(into._get_storage_idx(inc=B), device=dev)
+                assemble_episodes(o, s, u, r, term, A, out=into.buffers, slots=slots)
+                episode = None
+            else:
+                episode = assemble_episodes(o, s, u, r, term, A)
             episode_reward = env.total_reward.to(torch.float32).clone()
             win_tag = env.win_flag.clone()  # terminated and win_flag (rollout.py:64): a win always terminates
             targets_find = env.target_find.clone()

@@ -24,6 +24,8 @@
 
 namespace {
 
+#include "policy_dev.h"
+
 constexpr int G = 16;        // lanes per environment
 constexpr int BLOCK = 256;   // 4 wavefronts, 16 environments
 constexpr int MT_N = 624;
@@ -914,6 +916,229 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(DevParams p, StepIO io) {
 }
 
 // =========================================================================================================
+// Fused closed-loop rollout (flight_easy): T x (agent network forward -> env.step) in ONE launch.
+//
+// The caller-side row f3 (csrc/policy.hip) and the env step are both latency-bound at the batch sizes a collector
+// uses (B = 4096: one wavefront per SIMD), and two launches per step cost ~20 us.  Here a block keeps its 16 envs
+// (4 wavefronts x 4 groups, as k_rollout) AND their 16*N network rows resident: the N row tiles of 16 rows go
+// through fc1 -> GRUCell -> fc2 on the fp32 matrix cores exactly as in k_policy (wavefront w owns hidden columns
+// 16w..16w+15; same fragment order, same summation order, so the actions are bit-identical to the two-kernel loop),
+// the hidden state never leaves LDS between steps, the chosen actions go through LDS to the env groups, and the
+// env step is step_once of k_rollout (same MT19937 order, same emission).
+// =========================================================================================================
+struct PolicyIO {
+    const float *w;          // packed weights (cs_policy_pack)
+    float *hidden;           // [B*N][64] in/out
+    const int64_t *last;     // [B][N] action before the first step (< 0 = none)
+    int64_t *actions;        // [T][B][N] chosen actions
+    float epsilon;
+    unsigned long long seed;
+    unsigned step0;          // epsilon-greedy counter of the first step (one per step, as one cs_policy_forward call each)
+};
+
+template <int N>
+__global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io, PolicyIO pio) {
+    __shared__ double T[TRIG_ROWS * TRIG_COLS];
+    __shared__ WaveTile tiles[BLOCK / 64];
+    __shared__ int s_act[16 * N];          // last / chosen action per row (row = env_in_block * N + agent)
+    __shared__ float s_b3[16];
+    extern __shared__ float pol_lds[];     // s_a | s_b | s_h, each [16N][LDW]; the partial q of fc2 aliases s_a
+    constexpr int ROWS = 16 * N, NA = 3;   // the env has three actions (flight_env_easy.py:32)
+    float *s_a = pol_lds, *s_b = pol_lds + ROWS * LDW, *s_h = pol_lds + 2 * ROWS * LDW;
+    float *s_q = s_a;                      // [4][ROWS * 17] <= ROWS * LDW floats
+    const int gid = blockIdx.x * BLOCK + threadIdx.x;
+    const int b = gid / G, t = gid % G;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = lane >> 4;
+    const bool live = b < p.B;
+    const int b0 = blockIdx.x * (BLOCK / G);                 // first env of the block
+    const int rows_valid = (p.B - b0 < 16 ? p.B - b0 : 16) * N;
+    Env<N> e;
+    if (live) env_load<N>(p, b, t, e);
+    load_trig_to_lds(T);
+    const int wave_b0 = b0 + 4 * w;
+    const int nvalid = p.B - wave_b0 < 4 ? p.B - wave_b0 : 4;
+    const bool wave_valid = nvalid > 0;                      // wave-uniform
+    WaveTile &tile = tiles[w];
+    const EmitPlan<N> plan = make_emit_plan<N>(p, lane, wave_valid ? nvalid : 1);
+    constexpr bool PIPE = N <= 4;
+
+    // ---- policy: weight fragments and biases of this wavefront's column tile, once (k_policy)
+    const int crow = (lane >> 4) * 4, ccol = lane & 15, col = 16 * w + ccol;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    float b1[4], bg[6][16], b2[16], b3f[4];
+    {
+        const unsigned ulane = lane;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) b1[kk] = (pio.w + OFF_W1 + (w * (KIN_MAX / 4) + kk) * FR)[ulane];
+#pragma unroll
+        for (int g = 0; g < 3; g++)
+#pragma unroll
+            for (int kk = 0; kk < 16; kk++) {
+                bg[2 * g][kk] = (pio.w + OFF_WIH + ((w + 4 * g) * 16 + kk) * FR)[ulane];
+                bg[2 * g + 1][kk] = (pio.w + OFF_WHH + ((w + 4 * g) * 16 + kk) * FR)[ulane];
+            }
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) b2[kk] = (pio.w + OFF_W2 + (w * 16 + kk) * FR)[ulane];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) b3f[kk] = (pio.w + OFF_W3 + (4 * w + kk) * FR)[ulane];
+    }
+    const float bias1 = pio.w[OFF_B1 + col], bias2 = pio.w[OFF_B2 + col];
+    const float bir = pio.w[OFF_BIH + col], biz = pio.w[OFF_BIH + 64 + col], bin = pio.w[OFF_BIH + 128 + col];
+    const float bhr = pio.w[OFF_BHH + col], bhz = pio.w[OFF_BHH + 64 + col], bhn = pio.w[OFF_BHH + 128 + col];
+    if (threadIdx.x < 16) s_b3[threadIdx.x] = pio.w[OFF_B3 + threadIdx.x];
+    // hidden state and last actions of the block's rows -> LDS
+    const int srow = threadIdx.x >> 4, kcol = threadIdx.x & 15;
+#pragma unroll
+    for (int m = 0; m < N; m++) {
+        const int r = 16 * m + srow;
+        const size_t grow = (size_t)b0 * N + (r < rows_valid ? r : 0);
+        *reinterpret_cast<float4 *>(s_h + r * LDW + 4 * kcol) =
+            *reinterpret_cast<const float4 *>(pio.hidden + grow * H + 4 * kcol);
+    }
+    for (int r = threadIdx.x; r < ROWS; r += BLOCK) s_act[r] = r < rows_valid ? (int)pio.last[(size_t)b0 * N + r] : -1;
+    // the current observation of every env goes into its wavefront's tile (what get_obs would return now)
+    if (live) env_trig<N>(T, e);
+    emit_deposit<N>(p, tile, t, grp, live, e, 0, false);
+    MtWin win = {0u, 0u};
+    if (live) win = mt_prefetch(p.mt + (size_t)b * MT_STRIDE, e.mt_pos, t);
+    const int in_dim = 4 + NA + N;
+
+    for (int s = 0; s < io.T; s++) {
+        __syncthreads();   // tiles / s_act of the previous step are complete; s_q (= s_a) has been consumed
+        // ---- x = obs(4) | one_hot(last action) | one_hot(agent id) per row (agent.py:41-52), one column per thread
+#pragma unroll
+        for (int m = 0; m < N; m++) {
+            const int r = 16 * m + srow, el = r / N, ag = r - el * N;
+            float v = 0.0f;
+            if (kcol < 4) v = tiles[el >> 2].row[el & 3][4 * ag + kcol];
+            else if (kcol < 4 + NA) v = (kcol - 4 == s_act[r]) ? 1.0f : 0.0f;
+            else if (kcol < in_dim) v = (kcol - 4 - NA == ag) ? 1.0f : 0.0f;
+            s_a[r * LDW + kcol] = r < rows_valid ? v : 0.0f;
+        }
+        __syncthreads();
+        {   // h1 = relu(W1 x + b1), columns 16w..16w+15 of every row tile
+            f32x4 acc[N];
+#pragma unroll
+            for (int m = 0; m < N; m++) acc[m] = zero;
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+                for (int m = 0; m < N; m++)
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(s_a[(16 * m + (lane & 15)) * LDW + 4 * kk + (lane >> 4)],
+                                                                  b1[kk], acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < N; m++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) s_b[(16 * m + crow + r) * LDW + col] = fmaxf(acc[m][r] + bias1, 0.0f);
+        }
+        __syncthreads();
+        {   // GRUCell: per row tile the six chains in k_policy's order
+            f32x4 hnew[N];
+#pragma unroll
+            for (int m = 0; m < N; m++) {
+                f32x4 ir = zero, iz = zero, in_ = zero, hr = zero, hz = zero, hn_ = zero;
+#pragma unroll
+                for (int kk = 0; kk < 16; kk++) {
+                    const float ax = s_b[(16 * m + (lane & 15)) * LDW + 4 * kk + (lane >> 4)];
+                    const float ah = s_h[(16 * m + (lane & 15)) * LDW + 4 * kk + (lane >> 4)];
+                    ir = __builtin_amdgcn_mfma_f32_16x16x4f32(ax, bg[0][kk], ir, 0, 0, 0);
+                    hr = __builtin_amdgcn_mfma_f32_16x16x4f32(ah, bg[1][kk], hr, 0, 0, 0);
+                    iz = __builtin_amdgcn_mfma_f32_16x16x4f32(ax, bg[2][kk], iz, 0, 0, 0);
+                    hz = __builtin_amdgcn_mfma_f32_16x16x4f32(ah, bg[3][kk], hz, 0, 0, 0);
+                    in_ = __builtin_amdgcn_mfma_f32_16x16x4f32(ax, bg[4][kk], in_, 0, 0, 0);
+                    hn_ = __builtin_amdgcn_mfma_f32_16x16x4f32(ah, bg[5][kk], hn_, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float rg = sigmoidf_((ir[r] + bir) + (hr[r] + bhr));
+                    const float zg = sigmoidf_((iz[r] + biz) + (hz[r] + bhz));
+                    const float ng = tanhf_((in_[r] + bin) + rg * (hn_[r] + bhn));
+                    hnew[m][r] = (1.0f - zg) * ng + zg * s_h[(16 * m + crow + r) * LDW + col];
+                    s_a[(16 * m + crow + r) * LDW + col] = hnew[m][r];
+                }
+            }
+            __syncthreads();   // every wavefront has finished reading s_h
+#pragma unroll
+            for (int m = 0; m < N; m++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) s_h[(16 * m + crow + r) * LDW + col] = hnew[m][r];
+        }
+        {   // f = relu(W2 h' + b2)
+            f32x4 acc[N];
+#pragma unroll
+            for (int m = 0; m < N; m++) acc[m] = zero;
+#pragma unroll
+            for (int kk = 0; kk < 16; kk++)
+#pragma unroll
+                for (int m = 0; m < N; m++)
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(s_a[(16 * m + (lane & 15)) * LDW + 4 * kk + (lane >> 4)],
+                                                                  b2[kk], acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < N; m++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) s_b[(16 * m + crow + r) * LDW + col] = fmaxf(acc[m][r] + bias2, 0.0f);
+        }
+        __syncthreads();   // f complete; s_a (h') no longer needed: its space now takes the partial q
+        {
+            f32x4 acc[N];
+#pragma unroll
+            for (int m = 0; m < N; m++) acc[m] = zero;
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+                for (int m = 0; m < N; m++)
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                        s_b[(16 * m + (lane & 15)) * LDW + 16 * w + 4 * kk + (lane >> 4)], b3f[kk], acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < N; m++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) s_q[w * (ROWS * 17) + (16 * m + crow + r) * 17 + ccol] = acc[m][r];
+        }
+        __syncthreads();
+        for (int r = threadIdx.x; r < ROWS; r += BLOCK) {   // argmax / epsilon-greedy, one thread per row
+            float best = -3.0e38f;
+            int arg = 0;
+            for (int a = 0; a < NA; a++) {
+                const int o = r * 17 + a;
+                const float qv = ((s_q[o] + s_q[ROWS * 17 + o]) + (s_q[2 * ROWS * 17 + o] + s_q[3 * ROWS * 17 + o])) + s_b3[a];
+                if (qv > best) {
+                    best = qv;
+                    arg = a;
+                }
+            }
+            const int grow = b0 * N + r;
+            const int act = epsilon_greedy(arg, pio.epsilon, pio.seed, pio.step0 + (unsigned)s, grow, NA);
+            s_act[r] = act;
+            if (r < rows_valid) pio.actions[((size_t)s * p.B + b0) * N + r] = act;
+        }
+        __syncthreads();
+        // ---- env.step with the chosen actions
+        int act[N];
+        const int el = 4 * w + grp;
+#pragma unroll
+        for (int i = 0; i < N; i++) act[i] = s_act[el * N + i];
+        if (wave_valid)
+            step_once<N, 0>(p, T, io, tile, b, lane, (size_t)s * p.B + wave_b0, plan, live, act, win, s + 1 < io.T,
+                            PIPE && s > 0, (size_t)(s - 1) * p.B + wave_b0, PIPE, e);
+    }
+    if (PIPE && wave_valid) {  // rows of the last step
+        FlushRegs<N> fr;
+        emit_flush_load<N>(tile, plan, fr);
+        emit_flush_store<N>(p, io, plan, fr, (size_t)(io.T - 1) * p.B + wave_b0);
+    }
+    if (live) env_store<N>(p, b, t, e, false);
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < N; m++) {
+        const int r = 16 * m + srow;
+        if (r < rows_valid)
+            *reinterpret_cast<float4 *>(pio.hidden + ((size_t)b0 * N + r) * H + 4 * kcol) =
+                *reinterpret_cast<const float4 *>(s_h + r * LDW + 4 * kcol);
+    }
+}
+
+// =========================================================================================================
 // Lane-per-env path (flight_easy): one environment per LANE, 64 per wavefront.
 //
 // The 16-lane-group kernels above minimise the latency of one step when the batch is small (every SIMD gets a
@@ -1687,6 +1912,35 @@ int cs_rollout(const cs_config *cfg, void *state_dev, const void *actions_dev, i
                       hipLaunchKernelGGL(k_rollout<N>, dim3(env_blocks(p)), dim3(BLOCK), 0, (hipStream_t)stream, p, io));
     }
     return launched("cs_rollout");
+}
+
+int cs_rollout_policy(const cs_config *cfg, void *state_dev, const float *packed_dev, float *hidden_dev,
+                      const int64_t *last_dev, int T, int flags, float epsilon, uint64_t seed, uint32_t step0,
+                      int64_t *actions_dev, float *reward_dev, uint8_t *terminated_dev, uint8_t *win_dev, float *obs_dev,
+                      float *state_out_dev, void *stream) {
+    DevParams p;
+    int rc = make_params(cfg, state_dev, &p);
+    if (rc) return rc;
+    if (cfg->variant != 0) return fail(CS_E_CONFIG, "cs_rollout_policy: flight_easy only");
+    if (cfg->n_agents > 5) return fail(CS_E_CONFIG, "cs_rollout_policy: at most 5 agents");
+    if (T < 1) return fail(CS_E_ARG, "T must be >= 1");
+    if (!packed_dev || !hidden_dev || !last_dev || !actions_dev || !reward_dev || !terminated_dev || !win_dev)
+        return fail(CS_E_ARG, "null rollout buffer");
+    StepIO io{nullptr, reward_dev, terminated_dev, win_dev, obs_dev, state_out_dev, flags, T};
+    PolicyIO pio{packed_dev, hidden_dev, last_dev, actions_dev, epsilon, seed, step0};
+    const size_t lds = (size_t)3 * 16 * cfg->n_agents * LDW * sizeof(float);
+#define CS_LAUNCH_RP(NN)                                                                                               \
+    case NN: {                                                                                                         \
+        static const bool once = (hipFuncSetAttribute(reinterpret_cast<const void *>(k_rollout_policy<NN>),            \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 16 * NN * LDW * 4), true); \
+        (void)once;                                                                                                    \
+        hipLaunchKernelGGL(k_rollout_policy<NN>, dim3(env_blocks(p)), dim3(BLOCK), lds, (hipStream_t)stream, p, io, pio); \
+    } break;
+    switch (cfg->n_agents) {
+        CS_LAUNCH_RP(1) CS_LAUNCH_RP(2) CS_LAUNCH_RP(3) CS_LAUNCH_RP(4) CS_LAUNCH_RP(5)
+    }
+#undef CS_LAUNCH_RP
+    return launched("cs_rollout_policy");
 }
 
 int cs_emit(const cs_config *cfg, void *state_dev, float *obs_dev, float *state_out_dev, void *stream) {

@@ -263,6 +263,48 @@ class BatchedFlightEnv:
         out["win"] = win.view(torch.bool)
         return out
 
+    def rollout_policy(self, agents, T, epsilon=0.0, evaluate=True, emit=True, out=None, update_views=True):
+        """T closed-loop steps in ONE launch (flight_easy, n <= 5): each step runs `agents`' network (a `FusedAgents`) on
+        the current observation, picks the actions and steps the envs -- exactly what T x
+        `env.step(agents.choose_action(env.get_obs(), epsilon, evaluate))` computes, with the hidden state, the actions
+        and the envs resident on chip in between.  Returns the `rollout` dict plus `actions` (int64 [T, B, n]);
+        `agents.hidden` / `agents.actions` / `agents.calls` advance as if the T calls had been made."""
+        if self.flight:
+            raise _lib.CoopSearchError("rollout_policy: flight_easy only")
+        T = int(T)
+        B, n = self.batch, self.n_agents
+        if agents.rows != B * n or getattr(agents, "conv", False):
+            raise ValueError("rollout_policy: `agents` must be a non-conv FusedAgents for this env's batch")
+        out = dict(out) if out else {}
+        dev = self.device
+        spec = dict(reward=((T, B), torch.float32), terminated=((T, B), torch.uint8), win=((T, B), torch.uint8),
+                    actions=((T, B, n), torch.int64))
+        if emit or out.get("obs") is not None:
+            spec.update(obs=((T, B, n, self.obs_width), torch.float32), state=((T, B, self.state_shape), torch.float32))
+        for k, (shape, dt) in spec.items():
+            if out.get(k) is None:
+                out[k] = torch.empty(shape, dtype=dt, device=dev)
+            elif out[k].numel() * out[k].element_size() != torch.Size(shape).numel() * dt.itemsize or not out[k].is_contiguous():
+                raise ValueError(f"rollout_policy(out=): bad destination for {k!r}")
+        has_obs = out.get("obs") is not None and out.get("state") is not None
+        flags = (_lib.FREEZE_DONE if self.freeze_done else 0) | (_lib.AUTO_RESET if self.auto_reset else 0)
+        _lib.check(self._L.cs_rollout_policy(
+            self._cfgp, self._blob.data_ptr(), agents.packed.data_ptr(), agents.hidden.data_ptr(),
+            agents.actions.data_ptr(), T, flags, 0.0 if evaluate else float(epsilon), agents.seed, agents.calls,
+            out["actions"].data_ptr(), out["reward"].data_ptr(), out["terminated"].data_ptr(), out["win"].data_ptr(),
+            out["obs"].data_ptr() if has_obs else None, out["state"].data_ptr() if has_obs else None, self._stream()))
+        agents.calls += T
+        agents.actions.copy_(out["actions"][-1])
+        if update_views:
+            if has_obs:
+                self._obs.copy_(out["obs"][-1])
+                self._state.copy_(out["state"][-1])
+            else:
+                self.refresh()
+        out["terminated"] = out["terminated"].view(torch.bool)
+        out["win"] = out["win"].view(torch.bool)
+        return out
+
     def refresh(self):
         """Re-emit get_obs()/get_state() from the device state (after editing raw())."""
         _lib.check(self._L.cs_emit(self._cfgp, self._blob.data_ptr(), self._obs.data_ptr(), self._state.data_ptr(),

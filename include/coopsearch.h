@@ -187,6 +187,33 @@ int cs_policy_conv_features(const float *conv1_w_dev, const float *conv1_b_dev, 
                             const float *maps_dev, int64_t map_stride, int n_maps, float *feat_dev, void *stream);
 const char *cs_policy_last_error(void);
 
+/* Fused closed loop (flight_easy, n_agents <= 5): T x (cs_policy_forward -> cs_step) in ONE launch, i.e. the body of
+ * RolloutWorker.generate_episode's loop (common/rollout.py:43-76) for all B envs with the hidden state, the chosen
+ * actions and the envs resident on chip between steps.  Same results, bit for bit, as T pairs of
+ * cs_policy_forward(..., step = step0 + s) and cs_step(flags) calls.
+ *   packed_dev   cs_policy_pack output            hidden_dev  float [B*n][64], in/out
+ *   last_dev     int64 [B][n] action before the first step (< 0 = none)
+ *   actions_dev  int64 [T][B][n] chosen actions (out); the other outputs as in cs_rollout. */
+int cs_rollout_policy(const cs_config *cfg, void *state_dev, const float *packed_dev, float *hidden_dev,
+                      const int64_t *last_dev, int T, int flags, float epsilon, uint64_t seed, uint32_t step0,
+                      int64_t *actions_dev, float *reward_dev, uint8_t *terminated_dev, uint8_t *win_dev, float *obs_dev,
+                      float *state_out_dev, void *stream);
+
+/* ---- caller-side rows f1 / f2: episode batch assembly ------------------------------------------------------------
+ * common/rollout.py:66-76,105-132 (the eleven per-episode arrays and their padding: steps after termination are zero
+ * rows with padded = 1, terminated = 1) and common/replay_buffer.py:41-61 (store_episode) in one pass over the
+ * collector's step-major tables.  All destinations are float32 [slots][T][...] arrays (a fresh [B][T][...] batch, or
+ * the ring of a replay buffer); env b's episode goes to slot slot_dev[b] (NULL: slot b).
+ *   o_tab [T+1][B][n][obs_w]   s_tab [T+1][B][state_w]   u_tab int64 [T][B][n]   r_tab [T][B]   term_tab u8 [T][B] */
+typedef struct cs_episode_out {
+    float *o, *u, *s, *r, *o_next, *s_next, *avail_u, *avail_u_next, *u_onehot, *padded, *terminated;
+} cs_episode_out;
+
+int cs_store_episodes(int B, int T, int n_agents, int n_actions, int obs_w, int state_w, const float *o_tab_dev,
+                      const float *s_tab_dev, const int64_t *u_tab_dev, const float *r_tab_dev,
+                      const uint8_t *term_tab_dev, const int64_t *slot_dev, const cs_episode_out *out, void *stream);
+const char *cs_episodes_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

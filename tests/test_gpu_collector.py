@@ -90,3 +90,52 @@ def test_closed_loop_collect_store_sample(env_name):
     s = rb.sample(32, generator=g)
     assert s["o"].shape == (32, T, 3, ep["o"].shape[-1]) and s["s"].device.type == "cuda"
     assert torch.equal(rb.buffers["r"][:10], ep["r"][10:20])
+
+
+@pytest.mark.parametrize("T,B,n,w,S", [(200, 64, 3, 4, 57), (50, 7, 5, 4, 65), (20, 5, 3, 2504, 57), (9, 3, 1, 4, 49)])
+def test_episode_assembly_kernel_equals_torch_definition(T, B, n, w, S):
+    """cs_store_episodes (csrc/episodes.hip) against the stock-torch statement of rollout.py:66-76,105-132."""
+    from cooperative_search_amd.collector import assemble_episodes, assemble_episodes_torch
+    g = torch.Generator(device="cuda").manual_seed(T * 1000 + B)
+    o = torch.rand(T + 1, B, n, w, device="cuda", generator=g)
+    s = torch.rand(T + 1, B, S, device="cuda", generator=g)
+    u = torch.randint(0, 3, (T, B, n), device="cuda", generator=g)
+    r = torch.randint(-3, 111, (T, B), device="cuda", generator=g).float()
+    end = torch.randint(1, T + 5, (B,), device="cuda", generator=g)           # some episodes never terminate
+    term = (torch.arange(T, device="cuda")[:, None] >= (end - 1)[None, :])   # monotone, like a frozen env
+    a = assemble_episodes(o, s, u, r, term, 3)
+    b = assemble_episodes_torch(o, s, u, r, term, 3)
+    assert set(a) == set(b)
+    for k in b:
+        assert a[k].shape == b[k].shape and torch.equal(a[k], b[k]), k
+    # scattered slots of a larger ring
+    ring = {k: torch.full((B + 3,) + tuple(v.shape[1:]), -7.0, device="cuda") for k, v in b.items()}
+    slots = torch.randperm(B + 3, device="cuda", generator=g)[:B]
+    assemble_episodes(o, s, u, r, term, 3, out=ring, slots=slots)
+    untouched = torch.ones(B + 3, dtype=torch.bool, device="cuda")
+    untouched[slots] = False
+    for k in b:
+        assert torch.equal(ring[k][slots], b[k]), k
+        assert (ring[k][untouched] == -7.0).all()
+
+
+def test_generate_episodes_straight_into_the_replay_ring():
+    args = cs.make_env_args("flight_easy", n_agents=3)
+    B = 48
+    env = cs.BatchedFlightEnv(args, batch=B, freeze_done=True)
+    cs.apply_env_info(args, env)
+    col = cs.EpisodeCollector(env)
+    rb_a, rb_b = cs.DeviceReplayBuffer(args, 100), cs.DeviceReplayBuffer(args, 100)
+    for rnd in range(3):   # 144 episodes into 100 slots: the third batch wraps
+        acts = torch.randint(0, 3, (args.episode_limit, B, 3), device="cuda",
+                             generator=torch.Generator(device="cuda").manual_seed(rnd))
+        env.seed(np.arange(B) + 100 * rnd)
+        ep, rew, win, found = col.generate_episodes(actions=acts, init=True)
+        rb_a.store_episode(ep)
+        env.seed(np.arange(B) + 100 * rnd)
+        ep2, rew2, win2, found2 = col.generate_episodes(actions=acts, init=True, into=rb_b)
+        assert ep2 is None and torch.equal(rew, rew2) and torch.equal(found, found2)
+        assert (rb_a.current_idx, rb_a.current_size) == (rb_b.current_idx, rb_b.current_size)
+        filled = rb_a.current_size
+        for k in rb_a.buffers:
+            assert torch.equal(rb_a.buffers[k][:filled], rb_b.buffers[k][:filled]), (rnd, k)

@@ -123,9 +123,12 @@ def test_collector_and_evaluate_accept_the_fused_policy():
     env.seed(np.arange(B))
     ep_a, rew_a, win_a, found_a = col.generate_episodes(policy=fused.policy(0.0, True), init=True)
     env.seed(np.arange(B))
-    ep_b, rew_b, win_b, found_b = col.generate_episodes(agents=fused, init=True)
+    ep_b, rew_b, win_b, found_b = col.generate_episodes(agents=fused, init=True)                      # one launch
+    env.seed(np.arange(B))
+    ep_c, rew_c, win_c, found_c = col.generate_episodes(agents=fused, init=True, one_launch=False)   # two per step
     for k in ep_a:
         assert torch.equal(ep_a[k], ep_b[k]), k
+        assert torch.equal(ep_a[k], ep_c[k]), k
     assert torch.equal(rew_a, rew_b) and torch.equal(win_a, win_b) and torch.equal(found_a, found_b)
     assert torch.equal(env.get_obs(), ep_b["o_next"][:, -1]) or bool((ep_b["padded"][:, -1] == 1).any())
     assert ep["u"].shape[:3] == (B, a.episode_limit, 3) and ep["u"].min() >= 0 and ep["u"].max() <= 2
@@ -213,3 +216,41 @@ def test_flight_closed_loop_and_collector_with_fused_agents():
     same = (ep_f["u"] == ep_t["u"]).reshape(B, -1).all(1) & (found_f == found_t)
     assert same.float().mean().item() > 0.9   # a near-tie in q flips an env's whole trajectory; the bulk is identical
     assert torch.equal(ep_f["o"][same], ep_t["o"][same]) and torch.equal(ep_f["r"][same], ep_t["r"][same])
+
+
+# ---- fused closed-loop rollout (k_rollout_policy): T x (network forward -> env.step) in one launch -----------------
+
+@pytest.mark.parametrize("n,B,T,eps,auto_reset", [(3, 64, 60, 0.0, False), (3, 37, 45, 0.25, False), (5, 50, 40, 0.1, False),
+                                                  (1, 16, 30, 0.0, False), (4, 21, 230, 0.05, True)])
+def test_fused_closed_loop_rollout_equals_stepwise(n, B, T, eps, auto_reset):
+    a = _args(n)
+    torch.manual_seed(11 * n + B)
+    net = AgentRNN(rnn_input_shape(a), a).cuda()
+    for p in net.parameters():
+        p.data.mul_(3.0)
+    outs = []
+    for fused_loop in (False, True):
+        env = cs.BatchedFlightEnv(a, batch=B, freeze_done=not auto_reset, auto_reset=auto_reset)
+        env.seed(np.arange(B) + 5)
+        env.reset(init=True)
+        ag = FusedAgents(a, B, net=net, seed=99)
+        if fused_loop:
+            o = env.rollout_policy(ag, T, epsilon=eps, evaluate=False)
+        else:
+            o = dict(actions=[], reward=[], terminated=[], win=[], obs=[], state=[])
+            for t in range(T):
+                act = ag.choose_action(env.get_obs(), epsilon=eps)
+                r, term, win = env.step(act)
+                for k, v in (("actions", act), ("reward", r), ("terminated", term), ("win", win), ("obs", env.get_obs()),
+                             ("state", env.get_state())):
+                    o[k].append(v.clone())
+            o = {k: torch.stack(v) for k, v in o.items()}
+        outs.append((o, ag.hidden.clone(), ag.actions.clone(), ag.calls, env.raw()["hdr"].clone(), env.raw()["agent"].clone(),
+                     env.get_obs().clone()))
+    (oa, ha, la, ca, hdra, aga, obsa), (ob, hb, lb, cb, hdrb, agb, obsb) = outs
+    for k in oa:
+        assert torch.equal(oa[k], ob[k]), k
+    assert torch.equal(ha, hb) and torch.equal(la, lb) and ca == cb
+    assert torch.equal(hdra, hdrb) and torch.equal(aga, agb) and torch.equal(obsa, obsb)
+    if eps > 0:
+        assert (oa["actions"] != oa["actions"][0:1]).any()

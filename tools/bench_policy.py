@@ -61,8 +61,21 @@ def main():
             for _ in range(10):
                 step()
         graphed = run(g.replay, 20) * 10
+        # the whole closed loop in one launch per 100 steps (k_rollout_policy)
+        one = None
+        if n <= 5:
+            out = env.rollout_policy(fused, 100)
+            def fused_loop():
+                env.rollout_policy(fused, 100, out=out, update_views=False)
+            fused_loop(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                fused_loop()
+            torch.cuda.synchronize()
+            one = B * 1000 / (time.perf_counter() - t0)
         print(json.dumps(dict(workload=f"flight_easy {n}a B={B}", rows=B * n, fused_us=round(t_f, 2), torch_us=round(t_t, 2),
-                              fused_tflops=round(flops / t_f / 1e6, 2), closed_loop_eager=eager, closed_loop_hipgraph=graphed)),
+                              fused_tflops=round(flops / t_f / 1e6, 2), closed_loop_eager=eager, closed_loop_hipgraph=graphed,
+                              closed_loop_one_launch=one)),
               flush=True)
         del env, fused, ref
         torch.cuda.empty_cache()
