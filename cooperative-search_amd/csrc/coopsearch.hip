@@ -1931,9 +1931,10 @@ int cs_rollout_policy(const cs_config *cfg, void *state_dev, const float *packed
     const size_t lds = (size_t)3 * 16 * cfg->n_agents * LDW * sizeof(float);
 #define CS_LAUNCH_RP(NN)                                                                                               \
     case NN: {                                                                                                         \
-        static const bool once = (hipFuncSetAttribute(reinterpret_cast<const void *>(k_rollout_policy<NN>),            \
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 16 * NN * LDW * 4), true); \
-        (void)once;                                                                                                    \
+        static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(k_rollout_policy<NN>),           \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize,                     \
+                                                       3 * 16 * NN * LDW * 4) == hipSuccess;                           \
+        if (!lds_ok) return fail(CS_E_LAUNCH, "cs_rollout_policy: cannot reserve the LDS tile");                       \
         hipLaunchKernelGGL(k_rollout_policy<NN>, dim3(env_blocks(p)), dim3(BLOCK), lds, (hipStream_t)stream, p, io, pio); \
     } break;
     switch (cfg->n_agents) {
