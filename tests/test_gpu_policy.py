@@ -221,7 +221,8 @@ def test_flight_closed_loop_and_collector_with_fused_agents():
 # ---- fused closed-loop rollout (k_rollout_policy): T x (network forward -> env.step) in one launch -----------------
 
 @pytest.mark.parametrize("n,B,T,eps,auto_reset", [(3, 64, 60, 0.0, False), (3, 37, 45, 0.25, False), (5, 50, 40, 0.1, False),
-                                                  (1, 16, 30, 0.0, False), (4, 21, 230, 0.05, True)])
+                                                  (1, 16, 30, 0.0, False), (4, 21, 230, 0.05, True),
+                                                  (3, 4096, 200, 0.05, False), (2, 1001, 120, 0.3, True)])
 def test_fused_closed_loop_rollout_equals_stepwise(n, B, T, eps, auto_reset):
     a = _args(n)
     torch.manual_seed(11 * n + B)
