@@ -220,10 +220,10 @@ __global__ __launch_bounds__(PBLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 // ---- flight: conv front end of the agent network (network/base_net.py:9-18,31-36) ---------------------------------
 // Conv2d(1, 4, k=4, s=2) -> ReLU -> Conv2d(4, 1, k=3, s=1, p=1) -> ReLU -> Linear(576, 16) on the 50 x 50 probability
 // map (the reference's flight hyper-parameters, common/arguments.py:256-265; anything else stays on the torch path).
-// One block per map: the map, both conv outputs and the 16 x 576 linear weights live in LDS (60 KB, two blocks per
-// CU); persistent blocks loop over maps.  All agents of an env observe the same map (flight_env.py:223-230), so the
+// One block per map: the map and both conv outputs live in LDS (23 KB), the 16 x 576 linear weights in registers (36
+// per thread); persistent blocks loop over maps.  All agents of an env observe the same map (flight_env.py:223-230), so the
 // batched caller runs this once per ENV and k_policy fans the 16 features out to the env's rows.
-constexpr int MAPW = 50, C1W = 24, C1P = 26, C1CH = 4, NPOS = C1W * C1W, LIN_LD = NPOS + 1;
+constexpr int MAPW = 50, C1W = 24, C1P = 26, C1CH = 4, NPOS = C1W * C1W;
 
 struct ConvParams {
     const float *c1w, *c1b, *c2w, *c2b, *lw, *lb;  // torch layouts: [4][1][4][4], [4], [1][4][3][3], [1], [16][576], [16]
@@ -237,14 +237,17 @@ __global__ __launch_bounds__(PBLOCK) void k_conv_features(ConvParams p) {
     __shared__ float s_map[MAPW * MAPW];
     __shared__ float s_c1[C1CH][C1P * C1P];   // conv1 output with the zero border conv2's padding needs
     __shared__ float s_c2[NPOS];
-    __shared__ float s_lw[NFEAT * LIN_LD];
     const int t = threadIdx.x;
-    float w1[C1CH][16], bias1[C1CH], w2[C1CH * 9], bias2;
+    // two output channels (conv1) / two input channels (conv2) / two terms (linear) per v_pk_fma_f32
+    using v2f = __attribute__((ext_vector_type(2))) float;
+    static_assert(C1CH == 4, "channel pairs (0,1) and (2,3)");
+    v2f w1[2][16], bias1[2], w2[2][9];
+    float bias2;
 #pragma unroll
-    for (int c = 0; c < C1CH; c++) {
+    for (int h = 0; h < 2; h++) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) w1[c][i] = p.c1w[c * 16 + i];
-        bias1[c] = p.c1b[c];
+        for (int i = 0; i < 16; i++) w1[h][i] = v2f{p.c1w[(2 * h) * 16 + i], p.c1w[(2 * h + 1) * 16 + i]};
+        bias1[h] = v2f{p.c1b[2 * h], p.c1b[2 * h + 1]};
     }
     // 105 uniform weights do not fit the ~100 SGPRs a wavefront has: conv2's 37 are parked in VGPRs (the copy through
     // inline asm keeps the compiler from treating them as scalars again), conv1's 68 stay scalar
@@ -254,12 +257,16 @@ __global__ __launch_bounds__(PBLOCK) void k_conv_features(ConvParams p) {
         return vv;
     };
 #pragma unroll
-    for (int i = 0; i < C1CH * 9; i++) w2[i] = to_vgpr(p.c2w[i]);
+    for (int h = 0; h < 2; h++)   // pair h: input channels h and h + 2
+#pragma unroll
+        for (int k = 0; k < 9; k++) w2[h][k] = v2f{to_vgpr(p.c2w[h * 9 + k]), to_vgpr(p.c2w[(h + 2) * 9 + k])};
     bias2 = to_vgpr(p.c2b[0]);
-    for (int i = t; i < NFEAT * NPOS; i += PBLOCK) s_lw[(i / NPOS) * LIN_LD + i % NPOS] = p.lw[i];
     for (int i = t; i < C1CH * C1P * C1P; i += PBLOCK) (&s_c1[0][0])[i] = 0.0f;
-    const int j = t >> 4, sl = t & 15;   // linear: 16 threads per output feature
+    const int j = t >> 4, sl = t & 15;   // linear: 16 threads per output feature, its 36 weights in registers
     const float lbias = p.lb[j];
+    float lwr[NPOS / 16];
+#pragma unroll
+    for (int i = 0; i < NPOS / 16; i++) lwr[i] = p.lw[j * NPOS + sl + 16 * i];
 
     // The next map is fetched into registers while this one computes, and a map's 16 features are stored one
     // iteration late: at the top of an iteration the only memory operations in flight are then the prefetch loads
@@ -298,30 +305,35 @@ __global__ __launch_bounds__(PBLOCK) void k_conv_features(ConvParams p) {
 #pragma unroll
                 for (int kx = 0; kx < 4; kx++) in[ky * 4 + kx] = s_map[(2 * oy + ky) * MAPW + 2 * ox + kx];
 #pragma unroll
-            for (int c = 0; c < C1CH; c++) {
-                float acc = bias1[c];
+            for (int h = 0; h < 2; h++) {
+                v2f acc = bias1[h];
 #pragma unroll
-                for (int i = 0; i < 16; i++) acc = fmaf(w1[c][i], in[i], acc);
-                s_c1[c][(oy + 1) * C1P + ox + 1] = fmaxf(acc, 0.0f);
+                for (int i = 0; i < 16; i++) acc = __builtin_elementwise_fma(w1[h][i], v2f{in[i], in[i]}, acc);
+                s_c1[2 * h][(oy + 1) * C1P + ox + 1] = fmaxf(acc.x, 0.0f);
+                s_c1[2 * h + 1][(oy + 1) * C1P + ox + 1] = fmaxf(acc.y, 0.0f);
             }
         }
         __syncthreads();
-        for (int pos = t; pos < NPOS; pos += PBLOCK) {   // conv2 (pad 1) + ReLU
+        for (int pos = t; pos < NPOS; pos += PBLOCK) {   // conv2 (pad 1) + ReLU: channels (0, 2) then (1, 3), halves added
             const int oy = pos / C1W, ox = pos % C1W;
-            float acc = bias2;
+            v2f acc = {bias2, 0.0f};
 #pragma unroll
-            for (int c = 0; c < C1CH; c++)
+            for (int h = 0; h < 2; h++)
 #pragma unroll
                 for (int ky = 0; ky < 3; ky++)
 #pragma unroll
                     for (int kx = 0; kx < 3; kx++)
-                        acc = fmaf(w2[c * 9 + ky * 3 + kx], s_c1[c][(oy + ky) * C1P + ox + kx], acc);
-            s_c2[pos] = fmaxf(acc, 0.0f);
+                        acc = __builtin_elementwise_fma(w2[h][ky * 3 + kx],
+                                                        v2f{s_c1[h][(oy + ky) * C1P + ox + kx], s_c1[h + 2][(oy + ky) * C1P + ox + kx]},
+                                                        acc);
+            s_c2[pos] = fmaxf(acc.x + acc.y, 0.0f);
         }
         __syncthreads();
-        float acc = 0.0f;   // linear 576 -> 16: feature j by 16 threads, 36 terms each, butterfly over the 16 lanes
-#pragma unroll 4
-        for (int i = 0; i < NPOS / 16; i++) acc = fmaf(s_lw[j * LIN_LD + sl + 16 * i], s_c2[sl + 16 * i], acc);
+        v2f acc2 = {0.0f, 0.0f};   // linear 576 -> 16: feature j by 16 threads, 36 terms each, butterfly over the 16 lanes
+#pragma unroll
+        for (int i = 0; i < NPOS / 16; i += 2)
+            acc2 = __builtin_elementwise_fma(v2f{lwr[i], lwr[i + 1]}, v2f{s_c2[sl + 16 * i], s_c2[sl + 16 * (i + 1)]}, acc2);
+        float acc = acc2.x + acc2.y;
 #pragma unroll
         for (int off = 8; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
         pend = acc + lbias;
