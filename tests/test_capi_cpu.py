@@ -103,9 +103,10 @@ def test_product_never_imports_the_oracle():
                     f"{fn} mentions the oracle"
 
 
-def test_c_example_compiles_and_links_against_the_abi(tmp_path):
-    """examples/c_api_demo.cpp is the non-Python consumer of the boundary: it must compile against include/coopsearch.h
-    and link against the built library (it is executed on the GPU box by tests/test_gpu_parity.py)."""
+@pytest.mark.parametrize("example", ["c_api_demo", "closed_loop_demo"])
+def test_c_example_compiles_and_links_against_the_abi(tmp_path, example):
+    """examples/*.cpp are the non-Python consumers of the boundary: they must compile against include/coopsearch.h
+    and link against the built library (they are executed on the GPU box by the GPU suite)."""
     import shutil
     import subprocess
     from cooperative_search_amd import build
@@ -113,10 +114,10 @@ def test_c_example_compiles_and_links_against_the_abi(tmp_path):
     if hipcc is None:
         pytest.skip("hipcc not available")
     _lib.load()
-    out = tmp_path / "c_api_demo"
+    out = tmp_path / example
     csrc = os.path.dirname(_lib.library_path())
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-I", os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "examples", "c_api_demo.cpp"), "-L", csrc, "-lcoopsearch_hip",
+                           os.path.join(ROOT, "examples", example + ".cpp"), "-L", csrc, "-lcoopsearch_hip",
                            f"-Wl,-rpath,{csrc}", "-o", str(out)])
     assert out.exists()
 

@@ -255,3 +255,20 @@ def test_fused_closed_loop_rollout_equals_stepwise(n, B, T, eps, auto_reset):
     assert torch.equal(hdra, hdrb) and torch.equal(aga, agb) and torch.equal(obsa, obsb)
     if eps > 0:
         assert (oa["actions"] != oa["actions"][0:1]).any()
+
+
+def test_closed_loop_c_example_runs(tmp_path):
+    """examples/closed_loop_demo.cpp: cs_policy_pack -> cs_rollout_policy -> cs_store_episodes from plain C++/HIP."""
+    import re, subprocess
+    from cooperative_search_amd import _lib, build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.dirname(_lib.library_path())
+    exe = tmp_path / "closed_loop_demo"
+    subprocess.check_call([build.hipcc_path(), "--offload-arch=gfx950", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "closed_loop_demo.cpp"), "-L", csrc, "-lcoopsearch_hip",
+                           f"-Wl,-rpath,{csrc}", "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    m = re.search(r"episodes (\d+)\s+mean episode_reward (-?[\d.]+)\s+win rate ([\d.]+)\s+mean targets_find ([\d.]+)", out.stdout)
+    assert m and int(m.group(1)) == 4096, out.stdout
+    assert 0.0 <= float(m.group(4)) <= 15.0 and "yes" in out.stdout
