@@ -10,7 +10,10 @@ import cooperative_search_amd as cs
 
 def main():
     res = []
-    for env_name, n, B in (("flight_easy", 3, 4096), ("flight_easy", 5, 16384), ("flight_easy", 3, 65536), ("flight", 3, 1024)):
+    only = int(sys.argv[1]) if len(sys.argv) > 1 else None   # index of a single workload (for profiling)
+    for idx, (env_name, n, B) in enumerate((("flight_easy", 3, 4096), ("flight_easy", 5, 16384), ("flight_easy", 3, 65536), ("flight", 3, 1024))):
+        if only is not None and idx != only:
+            continue
         args = cs.make_env_args(env_name, n_agents=n)
         env = cs.BatchedFlightEnv(args, batch=B, freeze_done=True)
         cs.apply_env_info(args, env)
