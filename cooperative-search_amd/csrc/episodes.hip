@@ -49,14 +49,24 @@ __global__ __launch_bounds__(256) void k_episode_rows(EpisodeParams p, int t_per
         const bool real = step_is_real(p, t, b);
         const V *src0 = reinterpret_cast<const V *>(p.o_tab + ((size_t)t * p.B + b) * ow);
         const V *src1 = reinterpret_cast<const V *>(p.o_tab + ((size_t)(t + 1) * p.B + b) * ow);
-        reinterpret_cast<V *>(p.out.o + (slot * p.T + t) * ow)[c] = real ? src0[c] : zero;
-        reinterpret_cast<V *>(p.out.o_next + (slot * p.T + t) * ow)[c] = real ? src1[c] : zero;
+        V v0 = zero, v1 = zero;   // (a select between a loaded value and a constant, not between two addresses)
+        if (real) {
+            v0 = src0[c];
+            v1 = src1[c];
+        }
+        reinterpret_cast<V *>(p.out.o + (slot * p.T + t) * ow)[c] = v0;
+        reinterpret_cast<V *>(p.out.o_next + (slot * p.T + t) * ow)[c] = v1;
     }
-    for (int i = threadIdx.x; i < nt * sw; i += blockDim.x) {
-        const int t = t0 + i / sw, c = i % sw;
+    // state rows: wavefront = time step, lane = column (no per-element division)
+    for (int tt = threadIdx.x >> 6; tt < nt; tt += 4) {
+        const int t = t0 + tt;
         const bool real = step_is_real(p, t, b);
-        p.out.s[(slot * p.T + t) * sw + c] = real ? p.s_tab[((size_t)t * p.B + b) * sw + c] : 0.0f;
-        p.out.s_next[(slot * p.T + t) * sw + c] = real ? p.s_tab[((size_t)(t + 1) * p.B + b) * sw + c] : 0.0f;
+        const float *src0 = p.s_tab + ((size_t)t * p.B + b) * sw, *src1 = p.s_tab + ((size_t)(t + 1) * p.B + b) * sw;
+        float *d0 = p.out.s + (slot * p.T + t) * sw, *d1 = p.out.s_next + (slot * p.T + t) * sw;
+        for (int c = threadIdx.x & 63; c < sw; c += 64) {
+            d0[c] = real ? src0[c] : 0.0f;
+            d1[c] = real ? src1[c] : 0.0f;
+        }
     }
 }
 
