@@ -15,11 +15,21 @@ Workloads (BASELINE.json configs):
     c5                            flight_easy, 5 agents, 15 targets, 8192 envs per GPU (65536 over 8 GPUs)
 Modes:
     step     one cs_step launch per step (the closed-loop path a policy drives), replayed from a hipGraph
-    rollout  cs_rollout: T = 100 steps per launch with the env resident in registers (open-loop action table;
+    rollout  cs_rollout: up to 100 steps per launch with the env resident in registers (open-loop action table;
              flight_easy only) -- default for flight_easy
-Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL), the batch is sharded by global env index
-with no data-path collective ("scaling": "weak": per-GPU batch fixed); the only collective is the all-gather of
-the evaluation-metric partials after the timed region.
+
+Timing protocol (one clock): after W warm-up steps, the K-step region -- bracketed by a barrier and
+torch.cuda.synchronize() on both sides -- is repeated until it has accumulated >= MIN_GPU_S of GPU time (at least
+5 times); each repeat is timed with HIP events recorded on the stream the kernels are launched on (torch's current
+stream).  `value`, `ms_per_step` and `roofline.achieved` all derive from the MEDIAN event interval of the K-step
+region (max over ranks); the host wall clock of the same repeats is reported next to it as `wall_ms_per_step`.
+
+Multi-GPU: `--gpus N` with no torchrun environment starts N fresh rank processes itself (python -m
+torch.distributed.run, one rank per GPU, backend nccl = RCCL) BEFORE anything touches the GPU, relays rank 0's JSON
+line and exits with the children's return code; under an external torchrun (RANK / WORLD_SIZE set) it is a rank.
+The batch is sharded by global env index with no data-path collective ("scaling": "weak": per-GPU batch fixed); the
+only collective is the all-gather of the evaluation-metric partials after the timed region (runner.py:86-96), whose
+`eval.envs` = N x batch proves that RCCL saw N ranks.
 
 Prints ONE JSON line on rank 0.
 """
@@ -27,14 +37,14 @@ import argparse
 import json
 import math
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import numpy as np
-import torch
 
 WORKLOADS = {
     "c2": dict(env="flight_easy", n_agents=3, batch=4096),
@@ -43,8 +53,67 @@ WORKLOADS = {
     "c5": dict(env="flight_easy", n_agents=5, batch=8192),
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E
+C5_GLOBAL_BATCH = 65536  # BASELINE.json config 5
+MIN_GPU_S = 1.0          # headline: repeat the K-step region until this much GPU time has been measured
+MIN_GPU_S_ALSO = 0.25    # secondary workloads
+MIN_REPEATS, MAX_REPEATS = 5, 20000
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default=None, choices=["step", "rollout"])
+    ap.add_argument("--batch", type=int, default=None, help="override envs per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads reported under 'also'")
+    ap.add_argument("--kernel", default="auto", choices=["auto", "group", "lane"],
+                    help="flight_easy kernel: 16 lanes per env, one lane per env, or by batch size")
+    ap.add_argument("--min-gpu-s", type=float, default=MIN_GPU_S)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU-only check of the N-rank control flow (launcher, gloo process group, metric all-gather); "
+                         "no kernels run and the line says so")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------- N-rank launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(a, argv):
+    """`--gpus N` outside torchrun: start N fresh rank processes (this process never touches the GPU), relay rank 0's
+    JSON line on stdout and everything else on stderr, return the children's exit code."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True)
+    line = None
+    for out in proc.stdout:
+        s = out.strip()
+        if s.startswith("{") and '"metric"' in s:
+            line = s
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py: the rank processes printed no JSON line\n")
+        rc = 1
+    if line is not None:
+        print(line, flush=True)
+    return rc
+
+
+# -------------------------------------------------------------------------------------------------- byte models
 def algorithmic_bytes_per_env_step(env, n, m, mode):
     """SURVEY.md section 8(d).  flight_easy, one launch per step: 61n + 22m + 22 (535 B at 3a15t, 657 B at 5a15t);
     fused T-step rollout (state resident in registers): 36n + 12m + 6 (294 B / 366 B);
@@ -65,46 +134,146 @@ def largest_divisor_leq(k, cap):
     return 1
 
 
-def cpu_baseline(env_name, n, batch, budget_s=12.0):
-    """The C oracle (a port of the reference's algorithm, parity-pinned by tests/) timed on this host's cores, on a
-    bounded sample of the same workload: same batch, auto-reset, obs+state emission, x*x squares (its fast mode)."""
+def kernel_label(env_name, n, B, mode, kernel):
+    lane = env_name == "flight_easy" and (kernel == "lane" or (kernel == "auto" and B >= 32768))
+    if env_name == "flight":
+        return f"k_step<{n},1> + k_map<{n}>"
+    if lane:
+        return f"k_rollout_lane<{n}>"
+    return {"rollout": f"k_rollout<{n}>", "step": f"k_step<{n},0>"}[mode]
+
+
+def pmc_traffic(label, B, steps_per_launch):
+    """HBM bytes per launch from the committed PMC passes (profiles/traffic.json: FETCH_SIZE / WRITE_SIZE in separate
+    rocprofv3 --pmc passes, per env-step), scaled to THIS run's batch and steps per launch; None when no pass of this
+    kernel is committed."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None
+    ent = (json.load(open(path)).get("kernels") or {}).get(label)
+    if not ent:
+        return None
+    return int(ent["hbm_bytes_per_env_step"] * B * steps_per_launch)
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(env_name, n, batch, budget_s=10.0):
+    """The C oracle (a port of the reference's algorithm, parity-pinned by tests/) timed on this host's cores on a
+    bounded sample of the same workload: same batch, auto-reset, obs+state emission, x*x squares (its fast mode).
+    flight_easy: orc_batch_rollout -- ONE OpenMP region per T = 100 steps, env-major, so the fork/join cost is paid
+    once per 100 steps and an env stays in its core's cache.  The thread-scaling points are in `scaling`."""
+    import numpy as np
     from oracle import oracle as orc
     threads = max(1, min(orc.OracleBatch.max_threads(), os.cpu_count() or 1))
-    B = batch if env_name != "flight" else min(batch, 256)
+    flight = env_name == "flight"
+    B = batch if not flight else min(batch, 256)
+    T = 100 if not flight else 10
     cfg = orc.make_config(variant=env_name, n_agents=n)
     seeds = (20240000 + np.arange(B)).astype(np.uint32)
     orc.set_exact_pow(False)
     try:
         ob = orc.OracleBatch(cfg, B, seeds)
         ob.reset(init=True, threads=threads)
-        rng = np.random.RandomState(1)
-        acts = rng.randint(0, 3, size=(16, B, n)).astype(np.int32)
-        # calibrate, then run ~budget_s
+        acts = np.random.RandomState(1).randint(0, 3, size=(T, B, n)).astype(np.int32)
+        out = ob.rollout(acts, auto_reset=True, freeze_done=False, threads=threads)   # warm-up + buffers
+
+        def run(th, reps):
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                ob.rollout(acts, auto_reset=True, freeze_done=False, threads=th, out=out)
+            return B * T * reps / (time.perf_counter() - t0)
+
         t0 = time.perf_counter()
-        for s in range(4):
-            ob.step(acts[s % 16], auto_reset=True, freeze_done=False, threads=threads)
-        per = (time.perf_counter() - t0) / 4
-        steps = int(max(8, min(20000, budget_s / max(per, 1e-6))))
+        run(threads, 1)
+        per = time.perf_counter() - t0
+        reps = int(max(2, min(2000, 0.6 * budget_s / max(per, 1e-6))))
         t0 = time.perf_counter()
-        for s in range(steps):
-            ob.step(acts[s % 16], auto_reset=True, freeze_done=False, threads=threads)
+        multi = run(threads, reps)
         dt = time.perf_counter() - t0
-        multi = B * steps / dt
-        # single thread, shorter
-        steps1 = max(4, steps // (4 * threads))
-        t0 = time.perf_counter()
-        for s in range(steps1):
-            ob.step(acts[s % 16], auto_reset=True, freeze_done=False, threads=1)
-        single = B * steps1 / (time.perf_counter() - t0)
+        scaling = {}
+        pts = sorted({1, max(1, threads // 8), max(1, threads // 2)} - {threads})
+        for th in pts:                      # ~0.4 budget_s in total for the scaling points
+            est = per * threads / th
+            scaling[str(th)] = run(th, int(max(1, min(reps, 0.4 * budget_s / len(pts) / max(est, 1e-6)))))
+        scaling[str(threads)] = multi
     finally:
         orc.set_exact_pow(True)
+    single = scaling["1"]
     return {"value": multi, "unit": "env-steps/s", "cores": threads, "kind": "port",
-            "sample": f"C oracle (oracle/flight_oracle.c, OpenMP over envs), {B} envs x {steps} steps, auto-reset, "
-                      f"obs+state emitted, {dt:.1f} s wall", "single_thread_value": single}
+            "sample": f"C oracle (oracle/flight_oracle.c orc_batch_rollout: one OpenMP region per {T} steps, env-major), "
+                      f"{B} envs x {T * reps} steps, auto-reset, obs+state emitted, {dt:.1f} s wall on {cpu_model()} "
+                      f"({os.cpu_count()} logical CPUs)",
+            "single_thread_value": single, "speedup_vs_single_thread": multi / single,
+            "thread_scaling_env_steps_per_s": scaling}
 
 
-def measure(cs, dev, env_name, n, B, mode, K, W, kernel, rank=0, no_graph=False, barrier=lambda: None):
-    """Times K steps of one workload on `dev`; returns (seconds wall, event ms, env, S)."""
+# ------------------------------------------------------------------------------------------------ timed region
+class Comm:
+    """Barrier / max-over-ranks for 1..N ranks (gloo on host tensors in the shared-GPU test mode, RCCL otherwise)."""
+
+    def __init__(self, world, dev, share):
+        import torch
+        self.world, self.torch = world, torch
+        self.cdev = torch.device("cpu") if share else dev
+        if world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def max(self, x):
+        if self.world == 1:
+            return float(x)
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.cdev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+def timed_region(region, dev, comm, min_gpu_s):
+    """Repeats `region()` (the K-step region) bracketed by barrier + synchronize on both sides; returns the per-repeat
+    HIP-event seconds and host wall seconds.  Every rank runs the same number of repeats."""
+    import torch
+
+    def once():
+        torch.cuda.synchronize(dev)
+        comm.barrier()
+        torch.cuda.synchronize(dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        region()
+        ev1.record()
+        torch.cuda.synchronize(dev)
+        wall = time.perf_counter() - t0
+        comm.barrier()
+        torch.cuda.synchronize(dev)
+        return ev0.elapsed_time(ev1) / 1e3, wall
+
+    first = once()
+    reps = int(min(MAX_REPEATS, max(MIN_REPEATS, math.ceil(min_gpu_s / max(comm.max(first[0]), 1e-7)))))
+    ev, wall = [first[0]], [first[1]]
+    for _ in range(reps - 1):
+        e, w = once()
+        ev.append(e)
+        wall.append(w)
+    return ev, wall
+
+
+def run_workload(cs, dev, comm, env_name, n, B, mode, K, W, kernel, rank=0, no_graph=False, min_gpu_s=MIN_GPU_S_ALSO):
+    """Measures K steps of one workload on every rank; returns (result dict, env).  Times are max over ranks."""
+    import torch
     m = 15
     S = largest_divisor_leq(K, 100)  # steps per graph replay / per rollout launch
     env = cs.BatchedFlightEnv(cs.make_env_args(env_name, n_agents=n), batch=B, device=dev, env_offset=rank * B,
@@ -116,7 +285,7 @@ def measure(cs, dev, env_name, n, B, mode, K, W, kernel, rank=0, no_graph=False,
             reward=torch.empty(S, B, dtype=torch.float32, device=dev),
             terminated=torch.empty(S, B, dtype=torch.uint8, device=dev),
             win=torch.empty(S, B, dtype=torch.uint8, device=dev),
-            obs=torch.empty(S, B, n, 4, dtype=torch.float32, device=dev),
+            obs=torch.empty(S, B, n, env.obs_width, dtype=torch.float32, device=dev),
             state=torch.empty(S, B, env.state_shape, dtype=torch.float32, device=dev))
 
         def chunk():
@@ -142,39 +311,47 @@ def measure(cs, dev, env_name, n, B, mode, K, W, kernel, rank=0, no_graph=False,
                 graph.replay()
     for _ in range(max(1, math.ceil(W / S))):
         chunk()
-    torch.cuda.synchronize(dev)
-    barrier()
-    torch.cuda.synchronize(dev)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(K // S):
-        chunk()
-    ev1.record()
-    torch.cuda.synchronize(dev)
-    barrier()
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
-    return dt, ev0.elapsed_time(ev1), env, S
+
+    def region():
+        for _ in range(K // S):
+            chunk()
+
+    ev, wall = timed_region(region, dev, comm, min_gpu_s)
+    t_ev = comm.max(statistics.median(ev))
+    t_wall = comm.max(statistics.median(wall))
+    steps_per_launch = S if mode == "rollout" else 1
+    alg = algorithmic_bytes_per_env_step(env_name, n, m, mode)
+    label = kernel_label(env_name, n, B, mode, kernel)
+    achieved = alg * B * K / t_ev / 1e9
+    res = {
+        "value": B * comm.world * K / t_ev, "unit": "env-steps/s", "ms_per_step": t_ev * 1e3 / K,
+        "wall_ms_per_step": t_wall * 1e3 / K, "repeats": len(ev), "timed_gpu_s": sum(ev),
+        "region_ms_min_median_max": [min(ev) * 1e3, statistics.median(ev) * 1e3, max(ev) * 1e3],
+        "steps_per_launch": steps_per_launch,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(label, B, steps_per_launch),
+                     "kernel": label,
+                     "algorithmic_bytes_per_env_step": alg,
+                     "algorithmic_bytes_per_launch": alg * B * steps_per_launch,
+                     "avg_launch_us": t_ev / (K / steps_per_launch) * 1e6,
+                     "timing": "median HIP-event interval of the K-step region on the launch stream / launches"},
+    }
+    return res, env
 
 
-def side_measurement(cs, dev, label, env_name, n, B, mode, K, W, kernel):
-    """Compact entry for the `also` object: other workloads measured in the same run (N = 1 only)."""
-    dt, ev_ms, env, S = measure(cs, dev, env_name, n, B, mode, K, W, kernel)
-    launches = K // S if mode == "rollout" else K
-    alg = algorithmic_bytes_per_env_step(env_name, n, 15, mode)
-    achieved = alg * B * (S if mode == "rollout" else 1) / ((ev_ms / 1e3) / launches) / 1e9
+def side_measurement(cs, dev, comm, label, env_name, n, B, mode, K, W, kernel, rank=0):
+    """Compact entry for the `also` list: another workload measured in the same run with the same protocol."""
+    import torch
+    res, env = run_workload(cs, dev, comm, env_name, n, B, mode, K, W, kernel, rank=rank)
     del env
     torch.cuda.empty_cache()
-    return {"workload": label, "mode": mode, "kernel": kernel, "value": B * K / dt, "unit": "env-steps/s",
-            "ms_per_step": dt * 1e3 / K, "algorithmic_bytes_per_env_step": alg,
-            "roofline_achieved_GBps": achieved, "roofline_frac": achieved / HBM_PEAK_GBPS}
+    return {"workload": label, "mode": mode, "kernel": kernel, "steps": K, "warmup": W, **res}
 
 
 def closed_loop_measurement(cs, dev, n, B, K, W, env_name="flight_easy"):
     """`also` entry: the reference's recurrent agent network (agents.FusedAgents -> csrc/policy.hip) picks every action
-    from the live obs, then env.step: two launches per env step (flight: conv features, policy, step, map), nothing
-    leaves the device."""
+    from the live obs, then env.step, nothing leaves the device."""
+    import torch
     args = cs.make_env_args(env_name, n_agents=n)
     env = cs.BatchedFlightEnv(args, batch=B, device=dev, freeze_done=False, auto_reset=True)
     cs.apply_env_info(args, env)
@@ -196,10 +373,11 @@ def closed_loop_measurement(cs, dev, n, B, K, W, env_name="flight_easy"):
     advance(W)
     torch.cuda.synchronize(dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
+    e0.record()
     advance(K)
+    e1.record()
     torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
+    dt = e0.elapsed_time(e1) / 1e3
     obs = env.get_obs()
     e0.record()
     for _ in range(200):
@@ -211,39 +389,65 @@ def closed_loop_measurement(cs, dev, n, B, K, W, env_name="flight_easy"):
     torch.cuda.empty_cache()
     out = {"workload": f"closed loop: {env_name} {n}a15t B={B}, recurrent policy picks every action"
                        + (" (k_rollout_policy: network + env step fused, 100 steps per launch)" if one_launch
-                          else " (conv features, policy, step, map kernels per step)"),
+                          else " (conv features, policy, env step kernels per step)"),
            "mode": "closed-loop", "value": B * K / dt, "unit": "env-steps/s", "ms_per_step": dt * 1e3 / K,
            "policy_kernels_us": pol_us}
     if env_name == "flight_easy":   # one kernel, GEMM-shaped: price it against the fp32 matrix peak
-        flops = 2.0 * B * n * (16 * 64 + 2 * 192 * 64 + 64 * 64 + 64 * 16)
+        in_dim = 4 + 3 + n          # useful FLOPs only (the kernel pads fc1's input to 16 and fc2's output to 16)
+        flops = 2.0 * B * n * (in_dim * 64 + 2 * 192 * 64 + 64 * 64 + 64 * 3)
         out["policy_roofline"] = {"bound": "mfma", "achieved": flops / pol_us / 1e6, "peak": 157.3, "unit": "TFLOP/s",
                                   "frac": flops / pol_us / 1e6 / 157.3, "dtype": "f32"}
     return out
 
 
+def dry_run(a, rank, world):
+    """No GPU: every rank fabricates the metric partials of its shard and the ranks all-gather them over gloo, so the
+    launcher, the rendezvous and the reduction can be exercised in a CPU-only container.  Not a measurement."""
+    import torch
+    import torch.distributed as dist
+    B = a.batch or WORKLOADS[a.workload]["batch"]
+    if world > 1:
+        dist.init_process_group("gloo")
+    part = torch.tensor([-100.0 * B, 0.0, 3.0 * B, float(B)], dtype=torch.float64)
+    if world > 1:
+        gathered = [torch.zeros_like(part) for _ in range(world)]
+        dist.all_gather(gathered, part)
+        part = torch.stack(gathered).sum(0)
+    if rank == 0:
+        print(json.dumps({"metric": "env-steps/sec", "value": None, "unit": "env-steps/s", "n_gpus": world,
+                          "steps": a.steps, "warmup": a.warmup, "dry_run": True,
+                          "eval": {"envs": int(part[3].item()), "world_size": world}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20000)
-    ap.add_argument("--warmup", type=int, default=2000)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--mode", default=None, choices=["step", "rollout"])
-    ap.add_argument("--batch", type=int, default=None, help="override envs per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads reported under 'also'")
-    ap.add_argument("--kernel", default="auto", choices=["auto", "group", "lane"],
-                    help="flight_easy kernel: 16 lanes per env, one lane per env, or by batch size")
-    a = ap.parse_args()
+    argv = sys.argv[1:]
+    a = parse_args(argv)
+    in_torchrun = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.gpus > 1 and not in_torchrun:
+        sys.exit(launch_ranks(a, argv))     # nothing above this line has touched the GPU
+
+    import numpy as np  # noqa: F401  (oracle / env import it; fail early if missing)
+    import torch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.dry_run:
+        return dry_run(a, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
     # BENCH_SHARE_GPU=1 (tests only): all ranks use cuda:0 and the gloo backend, to exercise the N > 1 control flow on
     # a one-GPU box.  The real multi-GPU run is one process per GPU over RCCL (backend "nccl").
     share = os.environ.get("BENCH_SHARE_GPU") == "1"
+    if not share and local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank} but only {torch.cuda.device_count()} are visible")
     dev_index = 0 if share else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -253,6 +457,7 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    comm = Comm(world, dev, share)
 
     import cooperative_search_amd as cs
 
@@ -265,76 +470,66 @@ def main():
         raise SystemExit("rollout mode is flight_easy only")
     K, W = a.steps, a.warmup
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
-    dt, ev_ms, env, S = measure(cs, dev, env_name, n, B, mode, K, W, a.kernel, rank=rank, no_graph=a.no_graph,
-                                barrier=barrier)
-    cdev = torch.device("cpu") if share else dev  # gloo collectives on host tensors in the shared-GPU test mode
-    tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt_max = float(tmax.item())
+    res, env = run_workload(cs, dev, comm, env_name, n, B, mode, K, W, a.kernel, rank=rank, no_graph=a.no_graph,
+                            min_gpu_s=a.min_gpu_s)
 
     # evaluation-metric reduction (runner.py:86-96): the path's only collective, outside the timed region
-    part = env.metric_partials().clone().to(cdev)
+    part = env.metric_partials().clone().to(comm.cdev)
     if world > 1:
         gathered = [torch.zeros_like(part) for _ in range(world)]
         dist.all_gather(gathered, part)
         part = torch.stack(gathered).sum(0)
     part = part.cpu().numpy()
+    del env
+    torch.cuda.empty_cache()
 
+    line = None
     if rank == 0:
-        launches = K // S if mode == "rollout" else K
-        steps_per_launch = S if mode == "rollout" else 1
-        alg = algorithmic_bytes_per_env_step(env_name, n, m, mode)
-        launch_s = (ev_ms / 1e3) / launches
-        achieved = alg * B * steps_per_launch / launch_s / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            traffic = (json.load(open(tpath)).get(f"{a.workload}:{mode}") or {}).get("per_launch_bytes")
-            if a.batch or a.kernel != "auto":
-                traffic = None  # the committed PMC passes were taken on the default batch / kernel
-        lane = env_name == "flight_easy" and (a.kernel == "lane" or (a.kernel == "auto" and B >= 32768))
-        kernel = {"rollout": f"k_rollout<{n}>", "step": f"k_step<{n},{1 if env_name == 'flight' else 0}>"}[mode]
-        if lane:
-            kernel = f"k_rollout_lane<{n}>"
-        if env_name == "flight":
-            kernel += f" + k_map<{n}>"
         line = {
-            "metric": "env-steps/sec", "value": B * world * K / dt_max, "unit": "env-steps/s", "n_gpus": world,
-            "steps": K, "warmup": W, "ms_per_step": dt_max * 1e3 / K, "higher_is_better": True, "scaling": "weak",
+            "metric": "env-steps/sec", "value": res["value"], "unit": "env-steps/s", "n_gpus": world,
+            "steps": K, "warmup": W, "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{env_name}, {n} agents, {m} targets, batch={B} envs per GPU, agent_mode=0, "
-                                   f"target_mode=0 ({a.workload})", "mode": mode, "steps_per_launch": steps_per_launch,
-                       "auto_reset": True, "emits": "obs+state every step", "kernel": a.kernel, "hip_graph": mode == "step" and not a.no_graph},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": kernel,
-                         "algorithmic_bytes_per_env_step": alg, "avg_launch_us": launch_s * 1e6,
-                         "timing": "HIP events on the launch stream over the timed region / launches"},
+                                   f"target_mode=0 ({a.workload})", "mode": mode,
+                       "steps_per_launch": res["steps_per_launch"], "auto_reset": True, "emits": "obs+state every step",
+                       "kernel": a.kernel, "hip_graph": mode == "step" and not a.no_graph,
+                       "backend": ("gloo (BENCH_SHARE_GPU test mode)" if share else "nccl (RCCL)") if world > 1 else None},
+            "timing": {"clock": "HIP events on the launch stream, median over repeats of the K-step region, max over ranks",
+                       "repeats": res["repeats"], "timed_gpu_s": res["timed_gpu_s"],
+                       "region_ms_min_median_max": res["region_ms_min_median_max"],
+                       "wall_ms_per_step": res["wall_ms_per_step"]},
+            "roofline": res["roofline"],
             "eval": {"mean_episode_reward_so_far": part[0] / part[3], "win_rate_now": part[1] / part[3],
-                     "mean_targets_found_now": part[2] / part[3], "envs": int(part[3])},
+                     "mean_targets_found_now": part[2] / part[3], "envs": int(part[3]), "world_size": world},
         }
+    also = []
+    if not a.no_also and a.workload == "c2" and not a.batch:
+        # c5 (BASELINE config 5: flight_easy 5a15t, 65536 envs over the node) at every N: the weak point (8192 per GPU,
+        # = the 8-GPU configuration's per-GPU share) and the strong point (65536 / N per GPU)
+        also.append(side_measurement(cs, dev, comm, "c5 weak: flight_easy 5a15t, 8192 envs per GPU", "flight_easy", 5,
+                                     8192, "rollout", 1000, 100, "auto", rank=rank))
+        if C5_GLOBAL_BATCH % world == 0:
+            also.append(side_measurement(cs, dev, comm, f"c5 strong: flight_easy 5a15t, 65536 envs over {world} GPU(s)",
+                                         "flight_easy", 5, C5_GLOBAL_BATCH // world, "rollout", 400, 100, "auto", rank=rank))
+        if world == 1:
+            also += [
+                side_measurement(cs, dev, comm, "c2 flight_easy 3a15t B=4096, one launch per step (hipGraph)",
+                                 "flight_easy", 3, 4096, "step", 2000, 200, "auto"),
+                side_measurement(cs, dev, comm, "c3 flight_easy 5a15t B=16384", "flight_easy", 5, 16384, "rollout",
+                                 1000, 100, "auto"),
+                side_measurement(cs, dev, comm, "c4 flight 3a15t B=8192", "flight", 3, 8192, "step", 400, 100, "auto"),
+                side_measurement(cs, dev, comm, "flight_easy 3a15t B=262144 (lane-per-env kernel; batch sweep asymptote)",
+                                 "flight_easy", 3, 262144, "rollout", 200, 100, "lane"),
+                closed_loop_measurement(cs, dev, 3, 4096, 2000, 200),
+                closed_loop_measurement(cs, dev, 3, 65536, 400, 100),
+                closed_loop_measurement(cs, dev, 3, 8192, 400, 100, "flight"),
+            ]
+    if rank == 0:
+        if also:
+            line["also"] = also
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(env_name, n, B)
-        if world == 1 and not a.no_also and a.workload == "c2" and not a.batch:
-            del env
-            torch.cuda.empty_cache()
-            line["also"] = [
-                side_measurement(cs, dev, "c2 flight_easy 3a15t B=4096, one launch per step (hipGraph)", "flight_easy", 3,
-                                 4096, "step", 10000, 1000, "auto"),
-                side_measurement(cs, dev, "c3 flight_easy 5a15t B=16384", "flight_easy", 5, 16384, "rollout", 2000, 200, "auto"),
-                side_measurement(cs, dev, "c4 flight 3a15t B=8192 (k_step + k_map per step)", "flight", 3, 8192, "step",
-                                 2000, 200, "auto"),
-                side_measurement(cs, dev, "flight_easy 3a15t B=262144 (lane-per-env kernel; batch sweep asymptote)",
-                                 "flight_easy", 3, 262144, "rollout", 400, 100, "lane"),
-                closed_loop_measurement(cs, dev, 3, 4096, 4000, 400),
-                closed_loop_measurement(cs, dev, 3, 65536, 1000, 100),
-                closed_loop_measurement(cs, dev, 3, 8192, 1000, 100, "flight"),
-            ]
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -151,6 +151,11 @@ class BatchedFlightEnv:
             d["prob"] = self._view(lay.prob_off, B * self.cells, torch.float32, (B, self.map_size, self.map_size))
         return d
 
+    def mt_canonical(self):
+        """int32 [B, 640]: every env's MT19937 row in a form that depends only on the stream position (the kernels may
+        leave different amounts of the row pre-twisted ahead of the cursor; see cs_mt_canonical)."""
+        return self.raw()["mt"].clone()
+
     def seed(self, seeds):
         """np.random.seed(seeds[b]) for env b's private NumPy-compatible stream."""
         s = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint64) & 0xFFFFFFFF, dtype=np.uint32)

@@ -556,3 +556,33 @@ void orc_batch_step(orc_batch *b, const int32_t *actions, float *reward, uint8_t
         emit_f32(e, obs ? obs + (size_t)i * obs_w : NULL, state ? state + (size_t)i * st_w : NULL);
     }
 }
+
+/* T steps of every env inside ONE parallel region (bench.py's cpu_baseline leg): each thread takes a contiguous
+ * chunk of envs and walks every env of it through all T steps (env-major, so an env's state stays in that core's
+ * cache), writing the same per-step outputs as T orc_batch_step calls: actions [T][B][n]; reward/terminated/win
+ * [T][B]; obs [T][B][n][obs_w]; state [T][B][4n+3m] (any output may be NULL). */
+void orc_batch_rollout(orc_batch *b, const int32_t *actions, int T, float *reward, uint8_t *terminated, uint8_t *win,
+                       float *obs, float *state, int auto_reset, int freeze_done, int threads) {
+    const int n = b->c.n_agents, m = b->c.n_targets;
+    const size_t obs_w = (size_t)n * (b->c.variant == 0 ? 4 : b->c.map_size * b->c.map_size + 4);
+    const size_t st_w = (size_t)(4 * n + 3 * m);
+    const size_t B = (size_t)b->n;
+#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
+    for (int64_t i = 0; i < b->n; i++) {
+        orc_env *e = b->envs[i];
+        for (int s = 0; s < T; s++) {
+            int done = (e->target_find >= m) || (e->time_step >= e->c.time_limit);
+            int32_t r = 0, t = 1, w = e->win;
+            if (done && auto_reset) {
+                orc_reset(e, 0);
+                done = 0;
+            }
+            if (!(done && freeze_done)) orc_step(e, actions + ((size_t)s * B + (size_t)i) * n, &r, &t, &w);
+            const size_t slot = (size_t)s * B + (size_t)i;
+            if (reward) reward[slot] = (float)r;
+            if (terminated) terminated[slot] = (uint8_t)t;
+            if (win) win[slot] = (uint8_t)w;
+            emit_f32(e, obs ? obs + slot * obs_w : NULL, state ? state + slot * st_w : NULL);
+        }
+    }
+}

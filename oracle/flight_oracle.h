@@ -85,6 +85,9 @@ void orc_batch_reset(orc_batch *b, int init, const uint8_t *mask, int threads);
  * auto_reset != 0 resets envs that were terminated on entry (same rule as the HIP path) */
 void orc_batch_step(orc_batch *b, const int32_t *actions, float *reward, uint8_t *terminated, uint8_t *win,
                     float *obs, float *state, int auto_reset, int freeze_done, int threads);
+/* T steps of every env in ONE OpenMP region, env-major; outputs [T][B][...] as T orc_batch_step calls would write */
+void orc_batch_rollout(orc_batch *b, const int32_t *actions, int T, float *reward, uint8_t *terminated, uint8_t *win,
+                       float *obs, float *state, int auto_reset, int freeze_done, int threads);
 orc_env *orc_batch_env(orc_batch *b, int64_t i);
 int orc_max_threads(void);
 

@@ -79,3 +79,44 @@ def test_shard_covers_batch_exactly():
 def test_all_gather_sum_is_identity_without_process_group():
     x = torch.arange(5, dtype=torch.float64)
     assert torch.equal(csd.all_gather_sum(x), x)
+
+
+def _run_bench(args, env_extra=None, timeout=300):
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    env.update(env_extra or {})
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_gpus_flag_spawns_that_many_ranks():
+    """`bench.py --gpus 2` outside torchrun must start two rank processes itself: the dry-run ranks
+    all-gather their shard's env count over gloo, so the line proves the process group had two members."""
+    p, line = _run_bench(["--gpus", "2", "--dry-run", "--steps", "20", "--warmup", "5"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len([ln for ln in p.stdout.splitlines() if ln.startswith("{")]) == 1   # rank 0's line only
+    assert line["n_gpus"] == 2 and line["eval"] == {"envs": 2 * 4096, "world_size": 2}
+    assert line["steps"] == 20 and line["warmup"] == 5
+
+
+def test_bench_launcher_propagates_rank_failure():
+    """No GPU in this container: the real (non-dry) ranks must fail loudly and the launcher must return non-zero
+    without printing a result line."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a GPU-less host")
+    p, line = _run_bench(["--gpus", "2", "--steps", "20", "--warmup", "5"])
+    assert p.returncode != 0 and line is None
+    assert "needs an MI355X" in p.stderr
+
+
+def test_bench_rejects_world_size_mismatch():
+    p, line = _run_bench(["--gpus", "2", "--dry-run"], env_extra={"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    assert p.returncode != 0 and line is None and "WORLD_SIZE=1" in p.stderr
