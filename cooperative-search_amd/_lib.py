@@ -4,6 +4,8 @@ import os
 
 from . import build as _build
 
+ABI_VERSION = 2   # CS_ABI_VERSION of include/coopsearch.h; bumped whenever an export or a struct changes
+MT_STRIDE = 672    # CS_MT_STRIDE
 MAX_AGENTS = 8
 MAX_TARGETS = 16
 H_WORDS = 16
@@ -13,7 +15,7 @@ H_WORDS_LO, H_WORDS_HI, H_CURR_REWARD, H_NEWLY_RESET = 8, 9, 10, 11
 FREEZE_DONE, AUTO_RESET, ACTIONS_I64, KERNEL_GROUP, KERNEL_LANE = 1, 2, 4, 8, 16
 
 EXPORTS = ["cs_abi_version", "cs_last_error", "cs_state_layout", "cs_init", "cs_seed", "cs_reset", "cs_step",
-           "cs_rollout", "cs_rollout_policy", "cs_emit", "cs_metrics", "cs_policy_packed_floats", "cs_policy_pack", "cs_policy_forward",
+           "cs_rollout", "cs_rollout_policy", "cs_emit", "cs_metrics", "cs_mt_canonical", "cs_policy_packed_floats", "cs_policy_pack", "cs_policy_forward",
            "cs_policy_conv_features", "cs_policy_last_error", "cs_store_episodes", "cs_episodes_last_error"]
 
 
@@ -32,7 +34,7 @@ class CsConfig(C.Structure):
 
 class CsLayout(C.Structure):
     _fields_ = [("total_bytes", C.c_size_t), ("tgt_off", C.c_size_t), ("agent_off", C.c_size_t),
-                ("hdr_off", C.c_size_t), ("mt_off", C.c_size_t), ("prob_off", C.c_size_t)]
+                ("hdr_off", C.c_size_t), ("mt_off", C.c_size_t), ("ahead_off", C.c_size_t), ("prob_off", C.c_size_t)]
 
 
 class CsEpisodeOut(C.Structure):
@@ -62,8 +64,10 @@ def load():
             if not os.path.exists(path):
                 raise CoopSearchError(
                     f"{path} is missing and hipcc is not available: the HIP extension is required (no CPU fallback)")
-        else:
-            _build.build_extension()
+            raise CoopSearchError(
+                f"{path} is older than its sources and hipcc is not available to rebuild it: refusing to load a stale "
+                "library (rebuild where hipcc exists; the built .so travels with the tree)")
+        _build.build_extension()
     L = C.CDLL(path)
     vp = C.c_void_p
     L.cs_abi_version.restype = C.c_int
@@ -78,6 +82,7 @@ def load():
                                     vp, vp, vp, vp, vp, vp, vp]
     L.cs_emit.argtypes = [C.POINTER(CsConfig), vp, vp, vp, vp]
     L.cs_metrics.argtypes = [C.POINTER(CsConfig), vp, vp, vp]
+    L.cs_mt_canonical.argtypes = [C.POINTER(CsConfig), vp, vp, vp]
     L.cs_policy_packed_floats.restype = C.c_size_t
     L.cs_policy_last_error.restype = C.c_char_p
     L.cs_episodes_last_error.restype = C.c_char_p
@@ -91,8 +96,9 @@ def load():
         if name not in ("cs_abi_version", "cs_last_error", "cs_policy_packed_floats", "cs_policy_last_error",
                         "cs_episodes_last_error"):
             fn.restype = C.c_int
-    if L.cs_abi_version() != 1:
-        raise CoopSearchError("libcoopsearch_hip.so: ABI version mismatch")
+    if L.cs_abi_version() != ABI_VERSION:
+        raise CoopSearchError(f"{path}: ABI version {L.cs_abi_version()}, this package binds version {ABI_VERSION} "
+                              "(stale library: rebuild with `python -m cooperative_search_amd.build`)")
     _lib = L
     return L
 

@@ -29,8 +29,10 @@ namespace {
 constexpr int G = 16;        // lanes per environment
 constexpr int BLOCK = 256;   // 4 wavefronts, 16 environments
 constexpr int MT_N = 624;
-constexpr int MT_PAD = 16;              // words 0..15 of each env's state are mirrored at 624..639, so a
-constexpr int MT_STRIDE = MT_N + MT_PAD;  // 16-word window starting anywhere in 0..623 never wraps
+constexpr int MT_PAD = CS_MT_PAD;        // words 0..31 of each env's state are mirrored at 624..655, so a 32-word
+constexpr int MT_STRIDE = CS_MT_STRIDE;  // window starting anywhere in 0..623 never wraps (row padded to 21 x 128 B)
+constexpr int MT_CANON = 512;            // cs_mt_canonical: words twisted ahead of the cursor in the canonical form
+static_assert(MT_STRIDE >= MT_N + MT_PAD, "MT row too short for its mirror");
 constexpr int MT_M = 397;
 constexpr int TRIG_ROWS = 37, TRIG_COLS = 7;
 constexpr int FLAG_WIN = 1, FLAG_DIRTY = 2, FLAG_RESET_PASS = 4;
@@ -49,8 +51,10 @@ struct DevParams {
     double *tgt;     // [B][16][2]
     double *agent;   // [B][8][4]
     int *hdr;        // [B][16]
-    unsigned *mt;    // [B][624]
+    unsigned *mt;    // [B][640]
+    int *ahead;      // [B] words at the cursor that are already twisted
     float *prob;     // [B][cells]
+    float thr32, eps32;  // lane kernel's fp32 pre-filter of the sensor test, in normalised coordinates
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -91,7 +95,8 @@ struct AttemptBatch {
     unsigned nw[4];
     double u1, u2;  // np.random.rand() #2l and #2l+1 of the batch
 
-    __device__ __forceinline__ void generate(const unsigned *mt, int pos, int l) {
+    // `ahead` = words at `pos` that are already twisted (their stored value IS the new word)
+    __device__ __forceinline__ void generate(const unsigned *mt, int pos, int l, int ahead) {
         const int i0 = wrap624(pos + 4 * l);
         unsigned cur[5], far[4];
 #pragma unroll
@@ -101,7 +106,7 @@ struct AttemptBatch {
         unsigned tw[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            nw[q] = mt_mix(cur[q], cur[q + 1], far[q]);
+            nw[q] = 4 * l + q < ahead ? cur[q] : mt_mix(cur[q], cur[q + 1], far[q]);
             tw[q] = mt_temper(nw[q]);
         }
         // numpy random_sample: 53-bit double from two words
@@ -168,6 +173,7 @@ struct Env {
     float ntx, nty;                              // its normalised coordinates as get_state emits them
     unsigned found, newly, newly_reset;          // bit masks over targets
     int target_find, flags, time_step, total_reward, mt_pos, episodes, curr_reward;
+    int ahead;                                   // pre-twisted words at mt_pos (cs_layout.ahead_off)
     unsigned long long words;
 };
 
@@ -214,6 +220,7 @@ __device__ __forceinline__ void env_load(const DevParams &p, int b, int t, Env<N
     e.words = (unsigned long long)(unsigned)h2.x | ((unsigned long long)(unsigned)h2.y << 32);
     e.curr_reward = h2.z;
     e.newly_reset = (unsigned)h2.w;
+    e.ahead = p.ahead[b];
     const double4 *a4 = reinterpret_cast<const double4 *>(p.agent + (size_t)b * CS_MAX_AGENTS * 4);
 #pragma unroll
     for (int i = 0; i < N; i++) {
@@ -239,6 +246,7 @@ __device__ __forceinline__ void env_store(const DevParams &p, int b, int t, cons
         h4[1] = make_int4(e.time_step, e.total_reward, e.mt_pos, e.episodes);
         h4[2] = make_int4((int)(unsigned)(e.words & 0xffffffffull), (int)(unsigned)(e.words >> 32), e.curr_reward,
                           (int)e.newly_reset);
+        p.ahead[b] = e.ahead;
     }
     double4 *a4 = reinterpret_cast<double4 *>(p.agent + (size_t)b * CS_MAX_AGENTS * 4);
 #pragma unroll
@@ -280,8 +288,9 @@ __device__ __forceinline__ int detect_pass(const DevParams &p, int b, int t, int
         base += __popc(gm);
     }
     // window words 0..14 rebuilt in lanes 0..14
+    // (words below e.ahead were twisted ahead of time by the lane kernel: their stored value is the new word)
     const unsigned nxt = (unsigned)__shfl((int)win.cur, t + 1, G);
-    const unsigned nw = mt_mix(win.cur, nxt, win.far);
+    const unsigned nw = t < e.ahead ? win.cur : mt_mix(win.cur, nxt, win.far);
     const unsigned tw = mt_temper(nw);
     bool hit = false;
 #pragma unroll
@@ -319,8 +328,9 @@ __device__ __forceinline__ int detect_pass(const DevParams &p, int b, int t, int
                 if (i < N && inr[i] && rank[i] >= 7) {
                     int i0 = wrap624(e.mt_pos + 2 * rank[i]);
                     int i1 = wrap624(i0 + 1);
-                    unsigned n0 = mt_mix(w[k][0], w[k][1], w[k][3]);
-                    unsigned n1 = mt_mix(w[k][1], w[k][2], w[k][4]);
+                    const int ah = e.ahead;  // still the value on entry: positions are relative to the pass's cursor
+                    unsigned n0 = 2 * rank[i] < ah ? w[k][0] : mt_mix(w[k][0], w[k][1], w[k][3]);
+                    unsigned n1 = 2 * rank[i] + 1 < ah ? w[k][1] : mt_mix(w[k][1], w[k][2], w[k][4]);
                     mt_store(mt, i0, n0);
                     mt_store(mt, i1, n1);
                     unsigned long long u =
@@ -333,6 +343,7 @@ __device__ __forceinline__ int detect_pass(const DevParams &p, int b, int t, int
     }
     e.mt_pos = wrap624(e.mt_pos + 2 * base);
     e.words += (unsigned long long)(2 * base);
+    e.ahead = e.ahead > 2 * base ? e.ahead - 2 * base : 0;
 
     bool lane_new = hit && !((e.found >> t) & 1u);
     unsigned newly = (unsigned)((__ballot(lane_new) >> gshift) & 0xffffull);
@@ -572,7 +583,7 @@ __device__ __forceinline__ void env_reset(const DevParams &p, const double *T, i
         int taken = 0;
         while (taken < need_total) {  // group-uniform; one batch suffices ~99 % of the time for 9 jittered targets
             AttemptBatch ab;
-            ab.generate(mt, e.mt_pos, t);
+            ab.generate(mt, e.mt_pos, t, e.ahead);
             const double x1 = 2.0 * ab.u1 - 1.0, x2 = 2.0 * ab.u2 - 1.0;
             const double r2 = x1 * x1 + x2 * x2;
             const bool accept = !(r2 >= 1.0 || r2 == 0.0);
@@ -594,18 +605,20 @@ __device__ __forceinline__ void env_reset(const DevParams &p, const double *T, i
             ab.commit(mt, e.mt_pos, t, words);
             e.mt_pos = wrap624(e.mt_pos + words);
             e.words += (unsigned long long)words;
+            e.ahead = e.ahead > words ? e.ahead - words : 0;
             taken += have < want ? have : want;
         }
     } else {
         // x, y = map_size*np.random.rand() per target, flight_env_easy.py:122-127
         AttemptBatch ab;
-        ab.generate(mt, e.mt_pos, t);
+        ab.generate(mt, e.mt_pos, t, e.ahead);
         mx = p.L * ab.u1;
         my = p.L * ab.u2;
         const int words = 4 * p.n_targets;
         ab.commit(mt, e.mt_pos, t, words);
         e.mt_pos = wrap624(e.mt_pos + words);
         e.words += (unsigned long long)words;
+        e.ahead = e.ahead > words ? e.ahead - words : 0;
     }
     e.tx = mx;
     e.ty = my;
@@ -1143,24 +1156,49 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io
 //
 // The 16-lane-group kernels above minimise the latency of one step when the batch is small (every SIMD gets a
 // wave even at B = 4096) but replicate the kinematics 16 times.  For larger batches this path does each env's
-// arithmetic exactly once: agents AND the 16 targets live in the lane's registers, the n*m sensor tests are a
-// per-lane loop with full instruction-level parallelism, the in-range pairs are a per-lane bitmask consumed in
-// agent-major order, and get_state rows are staged through a per-wave LDS tile so the 64 rows leave as one
-// contiguous, coalesced block.  Resets (rare, data-dependent length) are done wave-cooperatively by borrowing
-// lanes 0..15 as the group of the code above.  Results are bit-identical to the group kernels (same per-env
-// arithmetic, same MT19937 word order); tests/test_gpu_parity.py runs both.
+// arithmetic exactly once and is built to keep TWO wavefronts per SIMD resident (<= 256 VGPRs, 2 x 4 staging
+// tiles in LDS) so that one wavefront's memory waits hide behind the other's arithmetic:
+//   * the agents live in the lane's registers; the targets do NOT: their normalised fp32 coordinates sit in the
+//     lane's row of the staging tile anyway (get_state emits them every step), and the n*m sensor tests are
+//     decided from those in fp32 whenever the fp32 distance is clear of the threshold by more than its error
+//     bound -- the few pairs that are not (~2e-6 of them) re-read the fp64 target and run the reference's exact
+//     comparison, so the outcome is the exact one in every case;
+//   * MT19937: the state is regenerated AHEAD of consumption, 192 words of one env at a time by the whole
+//     wavefront (three coalesced 256-byte loads and one store per 64 words instead of per-lane gathers),
+//     `cs_layout.ahead_off` counting the words that are twisted but not yet consumed; a draw is then two loaded
+//     words and a temper, and the 32 words a step may need are requested at the top of the step;
+//   * the in-range pairs form a per-lane bitmask consumed in agent-major order (bit 16*i + j), get_state rows
+//     leave through the per-wave LDS tile as one contiguous block;
+//   * resets (data-dependent length) are done wave-cooperatively, four envs at a time, by the four 16-lane groups
+//     of the wavefront running the group code above.
+// Results are bit-identical to the group kernels (same per-env arithmetic, same MT19937 word order);
+// tests/test_gpu_parity.py runs both.
 // =========================================================================================================
+constexpr int LANE_REFILL = 192;   // words twisted per refill (<= 227: independent of each other)
+constexpr int LANE_PRE = 8;        // 16-byte chunks of the MT row requested at the top of a step (16 draws)
+constexpr int LANE_LOW = 4 * LANE_PRE;  // every lane enters a step with at least this many words twisted ahead
+
 template <int N>
 struct EnvL {
     double ax[N], ay[N], yaw[N], cs[N], sn[N];
-    double tx[CS_MAX_TARGETS], ty[CS_MAX_TARGETS];
     unsigned found, newly, newly_reset;
-    int target_find, flags, time_step, total_reward, mt_pos, episodes, curr_reward;
+    int target_find, flags, time_step, total_reward, mt_pos, episodes, curr_reward, ahead;
     unsigned long long words;
 };
 
 template <int N>
-__device__ __forceinline__ void envl_load(const DevParams &p, int b, const double *T, EnvL<N> &e) {
+__device__ __forceinline__ void envl_zero(EnvL<N> &e) {
+#pragma unroll
+    for (int i = 0; i < N; i++) e.ax[i] = e.ay[i] = e.yaw[i] = e.cs[i] = e.sn[i] = 0.0;
+    e.found = e.newly = e.newly_reset = 0u;
+    e.target_find = e.flags = e.time_step = e.total_reward = e.mt_pos = e.episodes = e.curr_reward = 0;
+    e.ahead = 1 << 20;  // a lane without an env never asks for a refill
+    e.words = 0ull;
+}
+
+// hdr / agents of env b into the lane's registers, its targets (normalised, fp32) into the lane's tile row
+template <int N>
+__device__ __forceinline__ void envl_load(const DevParams &p, int b, const double *T, float *row, EnvL<N> &e) {
     const int4 *h4 = reinterpret_cast<const int4 *>(p.hdr + (size_t)b * CS_H_WORDS);
     int4 h0 = h4[0], h1 = h4[1], h2 = h4[2];
     e.found = (unsigned)h0.x;
@@ -1174,6 +1212,7 @@ __device__ __forceinline__ void envl_load(const DevParams &p, int b, const doubl
     e.words = (unsigned long long)(unsigned)h2.x | ((unsigned long long)(unsigned)h2.y << 32);
     e.curr_reward = h2.z;
     e.newly_reset = (unsigned)h2.w;
+    e.ahead = p.ahead[b];
     const double4 *a4 = reinterpret_cast<const double4 *>(p.agent + (size_t)b * CS_MAX_AGENTS * 4);
 #pragma unroll
     for (int i = 0; i < N; i++) {
@@ -1185,9 +1224,12 @@ __device__ __forceinline__ void envl_load(const DevParams &p, int b, const doubl
     const double2 *t2 = reinterpret_cast<const double2 *>(p.tgt + (size_t)b * G * 2);
 #pragma unroll
     for (int j = 0; j < CS_MAX_TARGETS; j++) {
-        double2 tt = t2[j];
-        e.tx[j] = tt.x;
-        e.ty[j] = tt.y;
+        if (j < p.n_targets) {
+            const double2 tt = t2[j];
+            row[4 * N + 3 * j + 0] = (float)((tt.x - p.mid) * p.inv_half);   // what get_state emits (norm_target)
+            row[4 * N + 3 * j + 1] = (float)((tt.y - p.mid) * p.inv_half);
+            row[4 * N + 3 * j + 2] = ((e.found >> j) & 1u) ? 1.0f : 0.0f;
+        }
     }
 #pragma unroll
     for (int i = 0; i < N; i++) trig_heading(T, e.yaw[i], e.sn[i], e.cs[i]);
@@ -1200,167 +1242,279 @@ __device__ __forceinline__ void envl_store(const DevParams &p, int b, const EnvL
     h4[1] = make_int4(e.time_step, e.total_reward, e.mt_pos, e.episodes);
     h4[2] = make_int4((int)(unsigned)(e.words & 0xffffffffull), (int)(unsigned)(e.words >> 32), e.curr_reward,
                       (int)e.newly_reset);
+    p.ahead[b] = e.ahead;
     double4 *a4 = reinterpret_cast<double4 *>(p.agent + (size_t)b * CS_MAX_AGENTS * 4);
 #pragma unroll
     for (int i = 0; i < N; i++) a4[i] = make_double4(e.ax[i], e.ay[i], e.yaw[i], 0.0);
 }
 
-// Detection pass + reward for one lane's env (same contract as detect_pass).  The in-range pairs form a bitmask
-// with bit 16*i + j for (agent i, target j): popping its set bits low-to-high IS the reference's agent-major
-// order.  Draws are served four at a time from a per-lane window of the circular MT19937 state.
+// Kinematics of one lane's env: same contract as kinematics<> above, organised for 64 DIFFERENT envs per
+// wavefront.  The repulsion of agent i (flight_env_easy.py:293-301) is a loop over the neighbours that ARE within
+// force_dist, in ascending j like the reference's, instead of n-1 predicated copies of the two fp64 divisions:
+// with 64 envs per wavefront some lane has a close pair almost every step, so every predicated copy would run.
 template <int N>
-__device__ __forceinline__ int detect_lane(const DevParams &p, unsigned *mt, EnvL<N> &e) {
-    const unsigned tmask = p.n_targets >= 16 ? 0xffffu : ((1u << p.n_targets) - 1u);
-    unsigned long long lo = 0, hi = 0;  // agents 0..3 / 4..7
+__device__ __forceinline__ void kinematics_lane(const DevParams &p, const double *T, const int (&act)[N], EnvL<N> &e) {
+    const double PI = 3.141592653589793, TWO_PI = 2.0 * 3.141592653589793, THREE_PI = 3.0 * 3.141592653589793;
+    const double DYAW = 3.141592653589793 / 18.0;
+    double yw[N], s1[N], c1[N], yr[N], s2[N], c2[N];
 #pragma unroll
     for (int i = 0; i < N; i++) {
-        unsigned m = 0;
-#pragma unroll
-        for (int j = 0; j < CS_MAX_TARGETS; j++) {
-            const double ddx = e.tx[j] - e.ax[i], ddy = e.ty[j] - e.ay[i];
-            m |= (ddx * ddx + ddy * ddy <= p.view_r2 ? 1u : 0u) << j;  // (t_x-x)**2 + (t_y-y)**2 <= view_range**2
-        }
-        m &= tmask;
-        if (i < 4) lo |= (unsigned long long)m << (16 * i);
-        else hi |= (unsigned long long)m << (16 * (i - 4));
+        double yaw = e.yaw[i];
+        yaw = act[i] == 1 ? yaw + DYAW : (act[i] == 2 ? yaw + -DYAW : yaw);  // dyaw = [0, pi/18, -pi/18][act]
+        yaw = yaw > TWO_PI ? yaw - TWO_PI : (yaw < 0.0 ? yaw + TWO_PI : yaw);
+        yw[i] = yaw;
+        trig_heading(T, yaw, s1[i], c1[i]);
+        yr[i] = (yaw <= PI) ? PI - yaw : THREE_PI - yaw;
+        trig_heading(T, yr[i], s2[i], c2[i]);
     }
-    const int total = __popcll(lo) + (N > 4 ? __popcll(hi) : 0);
-    unsigned hitmask = 0;
-    int pos = e.mt_pos;  // always even: every consumer takes an even number of words
-    for (int r0 = 0; r0 < total; r0 += 8) {  // one np.random.rand() per in-range pair, found or not (quirk Q4)
-        // 17 + 16 words straight from the padded row (no wrap inside a window), as unaligned 16-byte loads
-        unsigned cur[17], far[16];
-        const unsigned *pc = mt + pos, *pf = mt + wrap624(pos + MT_M);
+    unsigned out = 0;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const U4 c4 = *reinterpret_cast<const U4 *>(pc + 4 * q), f4 = *reinterpret_cast<const U4 *>(pf + 4 * q);
-            cur[4 * q] = c4.x; cur[4 * q + 1] = c4.y; cur[4 * q + 2] = c4.z; cur[4 * q + 3] = c4.w;
-            far[4 * q] = f4.x; far[4 * q + 1] = f4.y; far[4 * q + 2] = f4.z; far[4 * q + 3] = f4.w;
+    for (int i = 0; i < N; i++) {
+        const double x0 = e.ax[i], y0 = e.ay[i];
+        unsigned pend = 0;
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            if (j == i) continue;
+            const double xa = e.ax[j], ya = e.ay[j];  // already moved if j < i (quirk Q7)
+            const double d2 = (xa - x0) * (xa - x0) + (ya - y0) * (ya - y0);
+            pend |= (d2 < p.force_d2 && (xa != x0 || ya != y0)) ? (1u << j) : 0u;
         }
-        cur[16] = pc[16 < MT_STRIDE - pos ? 16 : 0];  // word pos+16 exists in the row unless pos == 624 (never)
-        const int take = total - r0 < 8 ? total - r0 : 8;
+        double fx = 0.0, fy = 0.0;
+        while (pend) {
+            const int j = __ffs((int)pend) - 1;
+            pend &= pend - 1;
+            double xa = 0.0, ya = 0.0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            if (k < take) {
-                const unsigned n0 = mt_mix(cur[2 * k], cur[2 * k + 1], far[2 * k]);
-                const unsigned n1 = mt_mix(cur[2 * k + 1], cur[2 * k + 2], far[2 * k + 1]);
-                const int i0 = wrap624(pos + 2 * k);  // even, so the pair never straddles 623|0
-                U2 pr = {n0, n1};
-                *reinterpret_cast<U2 *>(mt + i0) = pr;
-                *reinterpret_cast<U2 *>(mt + (i0 < MT_PAD ? MT_N + i0 : i0)) = pr;
-                int bit;
-                if (N <= 4 || lo) {
-                    bit = __ffsll((long long)lo) - 1;
-                    lo &= lo - 1;
-                } else {
-                    bit = __ffsll((long long)hi) - 1;
-                    hi &= hi - 1;
-                }
-                const unsigned long long u = ((unsigned long long)(mt_temper(n0) >> 5) << 26) | (unsigned long long)(mt_temper(n1) >> 6);
-                hitmask |= (u <= p.detect_K ? 1u : 0u) << (bit & 15);  // prob <= self.detect_prob, exact in integers
+            for (int q = 0; q < N; q++) {
+                xa = q == j ? e.ax[q] : xa;
+                ya = q == j ? e.ay[q] : ya;
+            }
+            const double den = (x0 - xa) * (x0 - xa) + (y0 - ya) * (y0 - ya);
+            fx += p.force_k * (x0 - xa) / den;
+            fy += p.force_k * (y0 - ya) / den;
+        }
+        const double x = (x0 + p.velocity * c1[i]) + fx;
+        const double y = (y0 + p.velocity * s1[i]) + fy;
+        const bool hit = (x < 0.0) | (x > p.L) | (y < 0.0) | (y > p.L);    // flight_env_easy.py:278
+        e.ax[i] = hit ? fmin(fmax(x, 0.0), p.L) : x;
+        e.ay[i] = hit ? fmin(fmax(y, 0.0), p.L) : y;
+        e.yaw[i] = hit ? yr[i] : yw[i];
+        e.cs[i] = hit ? c2[i] : c1[i];
+        e.sn[i] = hit ? s2[i] : s1[i];
+        out |= hit ? (1u << i) : 0u;
+    }
+    e.flags = (e.flags & ~0xff00) | (int)(out << 8);
+}
+
+// Wave-cooperative MT19937 refill: for every lane whose bit is set in `need`, the whole wavefront twists the next
+// LANE_REFILL words of that lane's env (lane l takes words g + l, g + 64 + l, g + 128 + l of the circular state, g =
+// cursor + ahead).  Word j needs the stored words j, j+1 and j+397: none of them is written by this refill (192 <=
+// 227), so all loads are issued before the first store; two envs are in flight per round trip.
+template <int N>
+__device__ __forceinline__ void lane_refill(const DevParams &p, int b0, int lane, unsigned long long need, EnvL<N> &e) {
+    const int my_g = wrap624(e.mt_pos + (e.ahead < MT_N ? e.ahead : 0));
+    while (need) {
+        int src[2];
+        src[0] = __ffsll((long long)need) - 1;
+        need &= need - 1;
+        src[1] = need ? __ffsll((long long)need) - 1 : -1;
+        need &= need ? need - 1 : 0ull;
+        unsigned cur[2][3], nxt[2][3], far[2][3];
+        int idx[2][3];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            if (src[q] < 0) continue;   // wave-uniform
+            const int g = __shfl(my_g, src[q]);
+            const unsigned *m = p.mt + (size_t)(b0 + src[q]) * MT_STRIDE;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const int j = wrap624(g + 64 * c + lane);
+                idx[q][c] = j;
+                cur[q][c] = m[j];
+                nxt[q][c] = m[wrap624(j + 1)];
+                far[q][c] = m[wrap624(j + MT_M)];
             }
         }
-        pos = wrap624(pos + 2 * take);
-    }
-    e.mt_pos = pos;
-    e.words += (unsigned long long)(2 * total);
-    const unsigned newly = hitmask & ~e.found;
-    const int cnt = __popc(newly);
-    int r = -1;     // MOVE_COST
-    r += 10 * cnt;  // FIND_ONE_TGT
-    e.found |= newly;
-    e.newly = newly;
-    e.target_find += cnt;
-    if (cnt > 0 && e.target_find == p.n_targets && !(e.flags & FLAG_WIN)) {
-        r += 100;  // FIND_ALL_TGT
-        e.flags |= FLAG_WIN;
-    }
-    r -= __popc(((unsigned)e.flags >> 8) & 0xffu);  // OUT_PUNISH
-    e.curr_reward = r;
-    e.flags |= FLAG_DIRTY;
-    return r;
-}
-
-// Rows of the per-wave staging tile: [64 lanes][W floats], W = 4n + 3m (odd for m = 15: conflict-free columns).
-template <int N>
-__device__ __forceinline__ void tile_write_targets(const DevParams &p, float *row, const EnvL<N> &e) {
 #pragma unroll
-    for (int j = 0; j < CS_MAX_TARGETS; j++) {
-        if (j < p.n_targets) {
-            row[4 * N + 3 * j + 0] = (float)((e.tx[j] - p.mid) * p.inv_half);
-            row[4 * N + 3 * j + 1] = (float)((e.ty[j] - p.mid) * p.inv_half);
+        for (int q = 0; q < 2; q++) {
+            if (src[q] < 0) continue;
+            unsigned *m = p.mt + (size_t)(b0 + src[q]) * MT_STRIDE;
+#pragma unroll
+            for (int c = 0; c < 3; c++) mt_store(m, idx[q][c], mt_mix(cur[q][c], nxt[q][c], far[q][c]));
+            if (lane == src[q]) e.ahead += LANE_REFILL;
         }
     }
 }
 
 template <int N>
-__global__ __launch_bounds__(BLOCK) void k_rollout_lane(DevParams p, StepIO io) {
+__global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO io) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *T = reinterpret_cast<double *>(smem);                                   // trig table (2072 B)
     const int W = 4 * N + 3 * p.n_targets;
     float *tiles = reinterpret_cast<float *>(smem + ((TRIG_ROWS * TRIG_COLS * 8 + 15) / 16) * 16);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *tile = tiles + (size_t)wave * 64 * W;
-    float *row = tile + (size_t)lane * W;
+    float *row = tile + (size_t)lane * W;   // W is odd for m = 15: conflict-free column accesses
     const int b = blockIdx.x * BLOCK + threadIdx.x;
     const int b0 = b - lane;  // first env of this wavefront
     const bool live = b < p.B;
     load_trig_to_lds(T);
     if (b0 >= p.B) return;  // whole wavefront out of range
+    const int t16 = lane & (G - 1), gshift = lane & ~(G - 1), grp = lane >> 4;
+    const unsigned tmask = p.n_targets >= 16 ? 0xffffu : ((1u << p.n_targets) - 1u);
     EnvL<N> e;
     int act[N];
-    unsigned *mt = p.mt + (size_t)(live ? b : 0) * MT_STRIDE;
+    const unsigned *mt = p.mt + (size_t)(live ? b : 0) * MT_STRIDE;
     if (live) {
-        envl_load<N>(p, b, T, e);
+        envl_load<N>(p, b, T, row, e);
         load_actions<N>(io, (size_t)b, act);
-        tile_write_targets<N>(p, row, e);
+    } else {
+        envl_zero<N>(e);
+#pragma unroll
+        for (int i = 0; i < N; i++) act[i] = 0;
     }
     const bool full_wave = b0 + 64 <= p.B;
     for (int s = 0; s < io.T; s++) {
         const size_t slot = (size_t)s * p.B + (live ? b : 0);
-        int act_next[N];
-        if (live) load_actions<N>(io, (size_t)(s + 1 < io.T ? s + 1 : s) * p.B + b, act_next);
         bool done = live && (e.target_find >= p.n_targets || e.time_step >= p.time_limit);
-        // ---- auto-reset: wave-cooperative, lanes 0..15 act as the group of the resetting env -----------------
+        // ---- auto-reset: the four 16-lane groups of the wavefront each take one resetting env -----------------
         unsigned long long need = __ballot(done && (io.flags & CS_AUTO_RESET));
         if (need) {
-            if ((need >> lane) & 1ull) envl_store<N>(p, b, e);  // publish cursor / counters for the helper group
+            if ((need >> lane) & 1ull) envl_store<N>(p, b, e);  // publish cursor / counters for the helper groups
             while (need) {
-                const int src = __ffsll((long long)need) - 1;
-                need &= need - 1;
-                const int br = b0 + src;
-                if (lane < G) {
+                unsigned long long m = need;
+                for (int q = 0; q < grp; q++) m &= m ? m - 1 : 0ull;   // this group's env: the grp-th pending one
+                const int src = m ? __ffsll((long long)m) - 1 : -1;
+                for (int q = 0; q < 4; q++) need &= need ? need - 1 : 0ull;
+                if (src >= 0) {
+                    const int br = b0 + src;
                     Env<N> g;
-                    env_load<N>(p, br, lane, g);
-                    env_reset<N>(p, T, br, lane, 0, 0, g);
-                    env_store<N>(p, br, lane, g, true);
+                    env_load<N>(p, br, t16, g);
+                    env_reset<N>(p, T, br, t16, gshift, 0, g);
+                    env_store<N>(p, br, t16, g, true);
                 }
             }
             if (done && (io.flags & CS_AUTO_RESET)) {
-                envl_load<N>(p, b, T, e);
-                tile_write_targets<N>(p, row, e);
+                envl_load<N>(p, b, T, row, e);
                 done = false;
             }
         }
+        // ---- MT19937: keep at least LANE_LOW twisted words ahead of every cursor, then request this step's window
+        const unsigned long long low = __ballot(e.ahead < LANE_LOW);
+        if (low) lane_refill<N>(p, b0, lane, low, e);
+        U4 pre[LANE_PRE];
+#pragma unroll
+        for (int q = 0; q < LANE_PRE; q++) pre[q] = *reinterpret_cast<const U4 *>(mt + e.mt_pos + 4 * q);
+        int act_next[N];
+        load_actions<N>(io, (size_t)(s + 1 < io.T ? s + 1 : s) * p.B + (live ? b : 0), act_next);
         int reward = 0;
         bool term = true;
-        if (live) {
-            e.flags &= ~(FLAG_DIRTY | FLAG_RESET_PASS);
-            if (!(done && (io.flags & CS_FREEZE_DONE))) {
-                kinematics<N, 0, EnvL<N>>(p, T, act, e);
-                reward = detect_lane<N>(p, mt, e);
-                e.total_reward += reward;
-                e.time_step += 1;
-                term = e.target_find >= p.n_targets || e.time_step >= p.time_limit;
+        const bool stepping = live && !(done && (io.flags & CS_FREEZE_DONE));
+        e.flags &= ~(FLAG_DIRTY | FLAG_RESET_PASS);
+        if (stepping) kinematics_lane<N>(p, T, act, e);
+        float4 f[N];
+#pragma unroll
+        for (int i = 0; i < N; i++)
+            f[i] = make_float4((float)((e.ax[i] - p.mid) * p.inv_half), (float)((e.ay[i] - p.mid) * p.inv_half),
+                               (float)e.cs[i], (float)e.sn[i]);
+        // ---- sensor tests (flight_env_easy.py:237): fp32 pre-filter on the normalised coordinates, exact fp64
+        //      comparison for the pairs it cannot decide; bit 16*i + j = (agent i, target j) in range
+        unsigned long long lo = 0, hi = 0;  // agents 0..3 / 4..7
+        if (stepping) {
+            float ntx[CS_MAX_TARGETS], nty[CS_MAX_TARGETS];
+#pragma unroll
+            for (int j = 0; j < CS_MAX_TARGETS; j++) {
+                ntx[j] = j < p.n_targets ? row[4 * N + 3 * j + 0] : 0.0f;
+                nty[j] = j < p.n_targets ? row[4 * N + 3 * j + 1] : 0.0f;
             }
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                unsigned m = 0, fz = 0;
+#pragma unroll
+                for (int j = 0; j < CS_MAX_TARGETS; j++) {
+                    const float dx = ntx[j] - f[i].x, dy = nty[j] - f[i].y;
+                    const float d2 = __builtin_fmaf(dx, dx, dy * dy);
+                    m |= (d2 < p.thr32 - p.eps32 ? 1u : 0u) << j;
+                    fz |= (!(d2 < p.thr32 - p.eps32) && !(d2 > p.thr32 + p.eps32) ? 1u : 0u) << j;
+                }
+                m &= tmask;
+                fz &= tmask;
+                while (fz) {  // (t_x-x)**2 + (t_y-y)**2 <= view_range**2 on the fp64 values
+                    const int j = __ffs((int)fz) - 1;
+                    fz &= fz - 1;
+                    const double2 tt = reinterpret_cast<const double2 *>(p.tgt + (size_t)b * G * 2)[j];
+                    const double ddx = tt.x - e.ax[i], ddy = tt.y - e.ay[i];
+                    m |= (ddx * ddx + ddy * ddy <= p.view_r2 ? 1u : 0u) << j;
+                }
+                if (i < 4) lo |= (unsigned long long)m << (16 * i);
+                else hi |= (unsigned long long)m << (16 * (i - 4));
+            }
+        }
+        // ---- one np.random.rand() per in-range pair, found or not (quirk Q4), in agent-major order
+        const int total = __popcll(lo) + (N > 4 ? __popcll(hi) : 0);
+        unsigned hitmask = 0;
+        {
+            int pos = e.mt_pos;  // always even: every consumer takes an even number of words
+            for (int r0 = 0; __ballot(r0 < total); r0 += 2 * LANE_PRE) {
+                if (r0 > 0) {  // more than 16 draws in one step somewhere in the wavefront: fetch the next window
+                    while (const unsigned long long more = __ballot(r0 < total && e.ahead < 2 * total))
+                        lane_refill<N>(p, b0, lane, more, e);
+#pragma unroll
+                    for (int q = 0; q < LANE_PRE; q++) pre[q] = *reinterpret_cast<const U4 *>(mt + pos + 4 * q);
+                }
+                const int take = total - r0 < 2 * LANE_PRE ? total - r0 : 2 * LANE_PRE;   // <= 0: nothing left for this lane
+#pragma unroll
+                for (int k = 0; k < 2 * LANE_PRE; k++) {
+                    if (k < take) {
+                        const U4 c = pre[k / 2];
+                        const unsigned wa = (k & 1) ? c.z : c.x, wb = (k & 1) ? c.w : c.y;
+                        int bit;
+                        if (N <= 4 || lo) {
+                            bit = __ffsll((long long)lo) - 1;
+                            lo &= lo - 1;
+                        } else {
+                            bit = __ffsll((long long)hi) - 1;
+                            hi &= hi - 1;
+                        }
+                        const unsigned long long u = ((unsigned long long)(mt_temper(wa) >> 5) << 26) | (unsigned long long)(mt_temper(wb) >> 6);
+                        hitmask |= (u <= p.detect_K ? 1u : 0u) << (bit & 15);  // prob <= self.detect_prob, exact in integers
+                    }
+                }
+                if (take > 0) pos = wrap624(pos + 2 * take);
+            }
+            e.mt_pos = pos;
+            e.words += (unsigned long long)(2 * total);
+            e.ahead -= 2 * total;
+        }
+        if (stepping) {
+            const unsigned newly = hitmask & ~e.found;
+            const int cnt = __popc(newly);
+            int r = -1;     // MOVE_COST
+            r += 10 * cnt;  // FIND_ONE_TGT
+            e.found |= newly;
+            e.newly = newly;
+            e.target_find += cnt;
+            if (cnt > 0 && e.target_find == p.n_targets && !(e.flags & FLAG_WIN)) {
+                r += 100;  // FIND_ALL_TGT
+                e.flags |= FLAG_WIN;
+            }
+            r -= __popc(((unsigned)e.flags >> 8) & 0xffu);  // OUT_PUNISH
+            e.curr_reward = r;
+            e.flags |= FLAG_DIRTY;
+            reward = r;
+            e.total_reward += reward;
+            e.time_step += 1;
+            term = e.target_find >= p.n_targets || e.time_step >= p.time_limit;
+            if (newly) {
+#pragma unroll
+                for (int j = 0; j < CS_MAX_TARGETS; j++)
+                    if ((newly >> j) & 1u) row[4 * N + 3 * j + 2] = 1.0f;
+            }
+        }
+        if (live) {
             io.reward[slot] = (float)reward;
             io.terminated[slot] = term ? 1 : 0;
             io.win[slot] = (e.flags & FLAG_WIN) ? 1 : 0;
-            float4 f[N];
-#pragma unroll
-            for (int i = 0; i < N; i++)
-                f[i] = make_float4((float)((e.ax[i] - p.mid) * p.inv_half), (float)((e.ay[i] - p.mid) * p.inv_half),
-                                   (float)e.cs[i], (float)e.sn[i]);
             if (io.obs) {
                 float4 *o = reinterpret_cast<float4 *>(io.obs) + slot * N;
 #pragma unroll
@@ -1374,9 +1528,6 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_lane(DevParams p, StepIO io) 
                     row[4 * i + 2] = f[i].z;
                     row[4 * i + 3] = f[i].w;
                 }
-#pragma unroll
-                for (int j = 0; j < CS_MAX_TARGETS; j++)
-                    if (j < p.n_targets) row[4 * N + 3 * j + 2] = ((e.found >> j) & 1u) ? 1.0f : 0.0f;
             }
         }
         if (io.state) {
@@ -1654,6 +1805,30 @@ __global__ void k_seed(DevParams p, const uint32_t *seeds) {
     hdr[CS_H_MT_POS] = 0;
     hdr[CS_H_WORDS_LO] = 0;
     hdr[CS_H_WORDS_HI] = 0;
+    p.ahead[b] = 0;
+}
+
+// One wavefront per env: the env's row in canonical form (MT_CANON words twisted ahead of the cursor), state untouched.
+__global__ __launch_bounds__(64) void k_mt_canonical(DevParams p, unsigned *out) {
+    __shared__ unsigned row[MT_N];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const unsigned *m = p.mt + (size_t)b * MT_STRIDE;
+    for (int i = lane; i < MT_N; i += 64) row[i] = m[i];
+    __syncthreads();
+    const int pos = p.hdr[(size_t)b * CS_H_WORDS + CS_H_MT_POS];
+    int a = p.ahead[b];
+    while (a < MT_CANON) {  // block-uniform; 64 <= 227 words per round are independent of each other
+        const int r = MT_CANON - a < 64 ? MT_CANON - a : 64;
+        const int j = wrap624(wrap624(pos + a) + lane);
+        unsigned nw = 0;
+        if (lane < r) nw = mt_mix(row[j], row[wrap624(j + 1)], row[wrap624(j + MT_M)]);
+        __syncthreads();
+        if (lane < r) row[j] = nw;
+        __syncthreads();
+        a += r;
+    }
+    unsigned *o = out + (size_t)b * MT_STRIDE;
+    for (int i = lane; i < MT_STRIDE; i += 64) o[i] = i < MT_N ? row[i] : (i - MT_N < MT_PAD ? row[i - MT_N] : 0u);
 }
 
 __global__ void k_fill_prob(float *prob, size_t n4) {
@@ -1751,6 +1926,14 @@ int make_params(const cs_config *c, void *state, DevParams *p) {
     p->agent = (double *)(base + lay.agent_off);
     p->hdr = (int *)(base + lay.hdr_off);
     p->mt = (unsigned *)(base + lay.mt_off);
+    p->ahead = (int *)(base + lay.ahead_off);
+    // lane kernel's fp32 pre-filter of `d2 <= view_range**2` in get_state's normalised coordinates: |fp32 d2 - exact| <=
+    // 4.5e-7 sqrt(thr) + 1.2e-7 thr near the threshold; pairs inside +-eps take the fp64 test
+    {
+        const double thr = p->view_r2 * p->inv_half * p->inv_half;
+        p->thr32 = (float)thr;
+        p->eps32 = (float)(1e-6 + 4e-6 * thr);
+    }
     p->prob = (float *)(base + lay.prob_off);
     return CS_OK;
 }
@@ -1814,6 +1997,8 @@ int cs_state_layout(const cs_config *cfg, cs_layout *out) {
     off = align_up(off + B * CS_H_WORDS * sizeof(int32_t), 256);
     out->mt_off = off;
     off = align_up(off + B * MT_STRIDE * sizeof(uint32_t), 256);
+    out->ahead_off = off;
+    off = align_up(off + B * sizeof(int32_t), 256);
     out->prob_off = off;
     if (cfg->variant == 1) off = align_up(off + B * (size_t)cfg->map_size * cfg->map_size * sizeof(float), 256);
     out->total_bytes = off;
@@ -1942,6 +2127,15 @@ int cs_rollout_policy(const cs_config *cfg, void *state_dev, const float *packed
     }
 #undef CS_LAUNCH_RP
     return launched("cs_rollout_policy");
+}
+
+int cs_mt_canonical(const cs_config *cfg, void *state_dev, uint32_t *rows_out_dev, void *stream) {
+    DevParams p;
+    int rc = make_params(cfg, state_dev, &p);
+    if (rc) return rc;
+    if (!rows_out_dev) return fail(CS_E_ARG, "null output rows");
+    hipLaunchKernelGGL(k_mt_canonical, dim3((unsigned)p.B), dim3(64), 0, (hipStream_t)stream, p, rows_out_dev);
+    return launched("cs_mt_canonical");
 }
 
 int cs_emit(const cs_config *cfg, void *state_dev, float *obs_dev, float *state_out_dev, void *stream) {

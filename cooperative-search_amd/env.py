@@ -145,16 +145,19 @@ class BatchedFlightEnv:
             tgt=self._view(lay.tgt_off, B * 32, torch.float64, (B, 16, 2)),
             agent=self._view(lay.agent_off, B * 32, torch.float64, (B, 8, 4)),
             hdr=self._view(lay.hdr_off, B * 16, torch.int32, (B, 16)),
-            mt=self._view(lay.mt_off, B * 640, torch.int32, (B, 640)),
+            mt=self._view(lay.mt_off, B * _lib.MT_STRIDE, torch.int32, (B, _lib.MT_STRIDE)),
+            ahead=self._view(lay.ahead_off, B, torch.int32, (B,)),
         )
         if self.flight:
             d["prob"] = self._view(lay.prob_off, B * self.cells, torch.float32, (B, self.map_size, self.map_size))
         return d
 
     def mt_canonical(self):
-        """int32 [B, 640]: every env's MT19937 row in a form that depends only on the stream position (the kernels may
+        """int32 [B, MT_STRIDE]: every env's MT19937 row in a form that depends only on the stream position (the kernels may
         leave different amounts of the row pre-twisted ahead of the cursor; see cs_mt_canonical)."""
-        return self.raw()["mt"].clone()
+        out = torch.empty(self.batch, _lib.MT_STRIDE, dtype=torch.int32, device=self.device)
+        _lib.check(self._L.cs_mt_canonical(self._cfgp, self._blob.data_ptr(), out.data_ptr(), self._stream()))
+        return out
 
     def seed(self, seeds):
         """np.random.seed(seeds[b]) for env b's private NumPy-compatible stream."""

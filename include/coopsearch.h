@@ -31,10 +31,12 @@
 extern "C" {
 #endif
 
-#define CS_ABI_VERSION 1
+#define CS_ABI_VERSION 2   /* 2: cs_layout.ahead_off (pre-twisted MT words), cs_mt_canonical */
 #define CS_MAX_AGENTS 8
 #define CS_MAX_TARGETS 16
 #define CS_MAX_MAP 64
+#define CS_MT_PAD 32      /* words 0..31 of an env's MT19937 row are mirrored behind word 623 */
+#define CS_MT_STRIDE 672  /* uint32 words per env row: 624 state + 32 mirror + 16 unused (21 x 128 bytes) */
 
 enum { CS_OK = 0, CS_E_CONFIG = -1, CS_E_ARG = -2, CS_E_LAUNCH = -3 };
 
@@ -77,8 +79,11 @@ typedef struct cs_layout {
     size_t tgt_off;    /* double [B][16][2]   target (x, y)                                             */
     size_t agent_off;  /* double [B][8][4]    agent (x, y, yaw, spare)                                   */
     size_t hdr_off;    /* int32  [B][16]      CS_H_* words below                                         */
-    size_t mt_off;     /* uint32 [B][640]     MT19937 state, circular (incremental) form + cursor in hdr;
-                          words 624..639 mirror words 0..15                                          */
+    size_t mt_off;     /* uint32 [B][CS_MT_STRIDE] MT19937 state, circular (incremental) form + cursor in hdr;
+                          words 624..655 mirror words 0..31                                          */
+    size_t ahead_off;  /* int32  [B]          number of words at the cursor that are ALREADY twisted (their outputs
+                          are temper(word)): the lane-per-env kernel regenerates the state 192 words at a time,
+                          coalesced, ahead of consumption; 0 = the plain circular form.  0 <= ahead <= 512   */
     size_t prob_off;   /* float  [B][map*map] probability map, first index = x cell (flight only)        */
 } cs_layout;
 
@@ -138,6 +143,11 @@ int cs_step(const cs_config *cfg, void *state_dev, const void *actions_dev, int 
 int cs_rollout(const cs_config *cfg, void *state_dev, const void *actions_dev, int T, int flags,
                float *reward_dev, uint8_t *terminated_dev, uint8_t *win_dev,
                float *obs_dev, float *state_out_dev, void *stream);
+
+/* Writes every env's MT19937 row in CANONICAL form -- exactly 512 words pre-twisted ahead of the cursor -- to
+ * rows_out_dev (uint32 [B][CS_MT_STRIDE]) without changing the state.  Two states that describe the same position of the same
+ * stream have equal canonical rows (and equal CS_H_MT_POS), however much of the row each kernel had pre-twisted. */
+int cs_mt_canonical(const cs_config *cfg, void *state_dev, uint32_t *rows_out_dev, void *stream);
 
 /* get_obs() + get_state() of every env without stepping. */
 int cs_emit(const cs_config *cfg, void *state_dev, float *obs_dev, float *state_out_dev, void *stream);
