@@ -15,7 +15,7 @@ H_WORDS_LO, H_WORDS_HI, H_CURR_REWARD, H_NEWLY_RESET = 8, 9, 10, 11
 FREEZE_DONE, AUTO_RESET, ACTIONS_I64, KERNEL_GROUP, KERNEL_LANE = 1, 2, 4, 8, 16
 
 EXPORTS = ["cs_abi_version", "cs_last_error", "cs_state_layout", "cs_init", "cs_seed", "cs_reset", "cs_step",
-           "cs_rollout", "cs_rollout_policy", "cs_emit", "cs_metrics", "cs_mt_canonical", "cs_policy_packed_floats", "cs_policy_pack", "cs_policy_forward",
+           "cs_rollout", "cs_rollout_policy", "cs_emit", "cs_metrics", "cs_mt_canonical", "cs_mt_advance", "cs_policy_packed_floats", "cs_policy_pack", "cs_policy_forward",
            "cs_policy_conv_features", "cs_policy_last_error", "cs_store_episodes", "cs_episodes_last_error"]
 
 
@@ -34,7 +34,7 @@ class CsConfig(C.Structure):
 
 class CsLayout(C.Structure):
     _fields_ = [("total_bytes", C.c_size_t), ("tgt_off", C.c_size_t), ("agent_off", C.c_size_t),
-                ("hdr_off", C.c_size_t), ("mt_off", C.c_size_t), ("ahead_off", C.c_size_t), ("prob_off", C.c_size_t)]
+                ("hdr_off", C.c_size_t), ("mt_off", C.c_size_t), ("ahead_off", C.c_size_t), ("tape_off", C.c_size_t), ("prob_off", C.c_size_t)]
 
 
 class CsEpisodeOut(C.Structure):
@@ -83,6 +83,7 @@ def load():
     L.cs_emit.argtypes = [C.POINTER(CsConfig), vp, vp, vp, vp]
     L.cs_metrics.argtypes = [C.POINTER(CsConfig), vp, vp, vp]
     L.cs_mt_canonical.argtypes = [C.POINTER(CsConfig), vp, vp, vp]
+    L.cs_mt_advance.argtypes = [C.POINTER(CsConfig), vp, C.c_int, vp]
     L.cs_policy_packed_floats.restype = C.c_size_t
     L.cs_policy_last_error.restype = C.c_char_p
     L.cs_episodes_last_error.restype = C.c_char_p

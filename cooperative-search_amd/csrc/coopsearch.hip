@@ -31,7 +31,7 @@ constexpr int BLOCK = 256;   // 4 wavefronts, 16 environments
 constexpr int MT_N = 624;
 constexpr int MT_PAD = CS_MT_PAD;        // words 0..31 of each env's state are mirrored at 624..655, so a 32-word
 constexpr int MT_STRIDE = CS_MT_STRIDE;  // window starting anywhere in 0..623 never wraps (row padded to 21 x 128 B)
-constexpr int MT_CANON = 512;            // cs_mt_canonical: words twisted ahead of the cursor in the canonical form
+constexpr int MT_CANON = MT_N;           // cs_mt_canonical: every word twisted ahead of the cursor
 static_assert(MT_STRIDE >= MT_N + MT_PAD, "MT row too short for its mirror");
 constexpr int MT_M = 397;
 constexpr int TRIG_ROWS = 37, TRIG_COLS = 7;
@@ -41,6 +41,8 @@ constexpr int FLAG_WIN = 1, FLAG_DIRTY = 2, FLAG_RESET_PASS = 4;
 __device__ const double g_trig[TRIG_ROWS][TRIG_COLS] = {
 #include "trig_table.inc"
 };
+
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 struct DevParams {
     int B, n_targets, map_size, cells, time_limit, agent_mode, target_mode, variant;
@@ -53,6 +55,7 @@ struct DevParams {
     int *hdr;        // [B][16]
     unsigned *mt;    // [B][640]
     int *ahead;      // [B] words at the cursor that are already twisted
+    unsigned *tape;  // [B][16] hit bits of the twisted words (lane kernel), see k_mt_advance
     float *prob;     // [B][cells]
     float thr32, eps32;  // lane kernel's fp32 pre-filter of the sensor test, in normalised coordinates
 };
@@ -550,6 +553,18 @@ __device__ __forceinline__ void kinematics_group(const DevParams &p, const doubl
     e.flags = (e.flags & ~0xff00) | (int)(out << 8);
 }
 
+// start position / heading of agent i (flight_env_easy.py:139-180): the same for every env
+template <int N>
+__device__ __forceinline__ void start_pose(const DevParams &p, int i, double &x, double &y, double &yaw) {
+    const double s = N != 1 ? (double)(i * p.map_size) / (double)(N - 1) : p.L / 2.0;
+    switch (p.agent_mode) {
+    case 0: x = s; y = 0.0; yaw = 3.141592653589793 / 2.0; break;
+    case 1: x = s; y = p.L / 2.0; yaw = 3.141592653589793 / 2.0; break;
+    case 2: x = 0.0; y = s; yaw = 0.0; break;
+    default: x = p.L; y = s; yaw = 3.141592653589793; break;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // reset: flight_env_easy.py:79-182 / flight_env.py:83-191.  Group-cooperative; ends with the reset-time
 // detection pass (quirk Q3) whose reward is discarded.
@@ -630,20 +645,19 @@ __device__ __forceinline__ void env_reset(const DevParams &p, const double *T, i
     e.total_reward = 0;
     e.flags = 0;
     e.episodes += 1;
+    bool any_in_range = false;
 #pragma unroll
     for (int i = 0; i < N; i++) {
-        double s = N != 1 ? (double)(i * p.map_size) / (double)(N - 1) : p.L / 2.0;
-        double yaw;
-        switch (p.agent_mode) {
-        case 0: e.ax[i] = s; e.ay[i] = 0.0; yaw = 3.141592653589793 / 2.0; break;
-        case 1: e.ax[i] = s; e.ay[i] = p.L / 2.0; yaw = 3.141592653589793 / 2.0; break;
-        case 2: e.ax[i] = 0.0; e.ay[i] = s; yaw = 0.0; break;
-        default: e.ax[i] = p.L; e.ay[i] = s; yaw = 3.141592653589793; break;
-        }
-        e.yaw[i] = yaw;
-        trig_heading(T, yaw, e.sn[i], e.cs[i]);
+        start_pose<N>(p, i, e.ax[i], e.ay[i], e.yaw[i]);
+        trig_heading(T, e.yaw[i], e.sn[i], e.cs[i]);
+        const double ddx = e.tx - e.ax[i], ddy = e.ty - e.ay[i];
+        any_in_range = any_in_range | (t < p.n_targets && ddx * ddx + ddy * ddy <= p.view_r2);
     }
-    detect_pass<N>(p, b, t, gshift, e, mt_prefetch(mt, e.mt_pos, t));
+    // the reset-time pass (quirk Q3) draws nothing unless a target is within view of a start position (never for
+    // agent_mode 0 with the shipped target file): request the MT window only then
+    MtWin win = {0u, 0u};
+    if ((__ballot(any_in_range) >> gshift) & 0xffffull) win = mt_prefetch(mt, e.mt_pos, t);
+    detect_pass<N>(p, b, t, gshift, e, win);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -681,8 +695,10 @@ __device__ __forceinline__ void emit(const DevParams &p, int t, const Env<N> &e,
 __device__ unsigned long long g_stamps[64][16];
 #define CS_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && g_tl_step >= 0 && g_tl_step < 64) g_stamps[g_tl_step][k] = __builtin_readcyclecounter(); } while (0)
 __device__ int g_tl_step_dummy;
+#define LANE_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && s < 64) g_stamps[s][k] = __builtin_readcyclecounter(); } while (0)
 #else
 #define CS_STAMP(k) do {} while (0)
+#define LANE_STAMP(k) do {} while (0)
 #endif
 
 struct StepIO {
@@ -691,6 +707,7 @@ struct StepIO {
     uint8_t *terminated, *win;
     float *obs, *state;   // [T][B][...]
     int flags, T;
+    int env0, env_n;      // lane kernel: this launch covers envs [env0, env0 + env_n)
 };
 
 // int32 actions, or the low dword of little-endian int64 actions (values 0..2): one branch-free strided read
@@ -1175,8 +1192,10 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io
 // tests/test_gpu_parity.py runs both.
 // =========================================================================================================
 constexpr int LANE_REFILL = 192;   // words twisted per refill (<= 227: independent of each other)
-constexpr int LANE_PRE = 8;        // 16-byte chunks of the MT row requested at the top of a step (16 draws)
-constexpr int LANE_LOW = 4 * LANE_PRE;  // every lane enters a step with at least this many words twisted ahead
+constexpr int LANE_REFILL_MAX = 192;
+constexpr int LANE_CHUNK = 64;     // steps per launch of the lane kernel: cs_rollout twists every row ahead in between
+constexpr int TAPE_DW = 10;        // 320 hit bits >= the 312 draw slots (word pairs) of one MT19937 row
+constexpr int TAPE_STRIDE = CS_TAPE_STRIDE;  // dwords per env: 10 of bits | base lo, hi | K lo, hi | 2 unused
 
 template <int N>
 struct EnvL {
@@ -1306,47 +1325,111 @@ __device__ __forceinline__ void kinematics_lane(const DevParams &p, const double
     e.flags = (e.flags & ~0xff00) | (int)(out << 8);
 }
 
-// Wave-cooperative MT19937 refill: for every lane whose bit is set in `need`, the whole wavefront twists the next
-// LANE_REFILL words of that lane's env (lane l takes words g + l, g + 64 + l, g + 128 + l of the circular state, g =
-// cursor + ahead).  Word j needs the stored words j, j+1 and j+397: none of them is written by this refill (192 <=
-// 227), so all loads are issued before the first store; two envs are in flight per round trip.
-template <int N>
-__device__ __forceinline__ void lane_refill(const DevParams &p, int b0, int lane, unsigned long long need, EnvL<N> &e) {
-    const int my_g = wrap624(e.mt_pos + (e.ahead < MT_N ? e.ahead : 0));
-    while (need) {
-        int src[2];
-        src[0] = __ffsll((long long)need) - 1;
-        need &= need - 1;
-        src[1] = need ? __ffsll((long long)need) - 1 : -1;
-        need &= need ? need - 1 : 0ull;
-        unsigned cur[2][3], nxt[2][3], far[2][3];
-        int idx[2][3];
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            if (src[q] < 0) continue;   // wave-uniform
-            const int g = __shfl(my_g, src[q]);
-            const unsigned *m = p.mt + (size_t)(b0 + src[q]) * MT_STRIDE;
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const int j = wrap624(g + 64 * c + lane);
-                idx[q][c] = j;
-                cur[q][c] = m[j];
-                nxt[q][c] = m[wrap624(j + 1)];
-                far[q][c] = m[wrap624(j + MT_M)];
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            if (src[q] < 0) continue;
-            unsigned *m = p.mt + (size_t)(b0 + src[q]) * MT_STRIDE;
-#pragma unroll
-            for (int c = 0; c < 3; c++) mt_store(m, idx[q][c], mt_mix(cur[q][c], nxt[q][c], far[q][c]));
-            if (lane == src[q]) e.ahead += LANE_REFILL;
-        }
-    }
+// np.random.rand() <= detect_prob for the draw made of stream words (wa, wb), exactly, in integers
+__device__ __forceinline__ bool draw_hits(const DevParams &p, unsigned wa, unsigned wb) {
+    const unsigned long long u = ((unsigned long long)(mt_temper(wa) >> 5) << 26) | (unsigned long long)(mt_temper(wb) >> 6);
+    return u <= p.detect_K;
 }
 
+// The hit tape of one lane: bit r = "draw slot r from the cursor hits".  Shift by n slots (n < 320), dword barrel first.
+template <int MAX_DW>
+__device__ __forceinline__ void tape_shift(unsigned (&t)[TAPE_DW], int n) {
+    const int dw = n >> 5, bit = n & 31;
+#pragma unroll
+    for (int st = 1; st <= MAX_DW; st <<= 1) {
+#pragma unroll
+        for (int k = 0; k < TAPE_DW; k++) {
+            const unsigned from = k + st < TAPE_DW ? t[k + st] : 0u;
+            t[k] = (dw & st) ? from : t[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < TAPE_DW; k++)
+        t[k] = __builtin_amdgcn_alignbit(k + 1 < TAPE_DW ? t[k + 1] : 0u, t[k], (unsigned)bit);
+}
+
+// Fallback of the lane kernel (rare once cs_rollout's pre-pass has run): for every lane whose bit is set in `need`,
+// the whole wavefront twists LANE_REFILL more words of that lane's env (when there is room) and rebuilds the env's hit
+// tape from its cursor -- in the state blob and, through the ballots, in the lane's registers.
 template <int N>
+__device__ __forceinline__ void lane_rebuild(const DevParams &p, int b0, int lane, unsigned long long need, EnvL<N> &e,
+                                             unsigned (&tape)[TAPE_DW]) {
+    while (need) {
+        const int src = __ffsll((long long)need) - 1;
+        need &= need - 1;
+        const int pos = __shfl(e.mt_pos, src);
+        int a = __shfl(e.ahead, src);
+        const unsigned wlo = (unsigned)__shfl((int)(unsigned)(e.words & 0xffffffffull), src);
+        const unsigned whi = (unsigned)__shfl((int)(unsigned)(e.words >> 32), src);
+        unsigned *m = p.mt + (size_t)(b0 + src) * MT_STRIDE;
+        if (a <= MT_N - LANE_REFILL) {   // wave-uniform
+            const int g = wrap624(pos + a);
+            unsigned nw[3];
+            int idx[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {   // word j needs stored words j, j+1, j+397: none written by this batch (192 <= 227)
+                const int j = wrap624(g + 64 * c + lane);
+                idx[c] = j;
+                nw[c] = mt_mix(m[j], m[wrap624(j + 1)], m[wrap624(j + MT_M)]);
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) mt_store(m, idx[c], nw[c]);
+            a += LANE_REFILL;
+        }
+        unsigned *tp = p.tape + (size_t)(b0 + src) * TAPE_STRIDE;
+#pragma unroll
+        for (int it = 0; it < TAPE_DW / 2; it++) {
+            const int r = 64 * it + lane;   // draw slot from the cursor: words pos + 2r, pos + 2r + 1 (pos is even)
+            bool hit = false;
+            if (2 * r < a) {
+                const U2 w = *reinterpret_cast<const U2 *>(m + wrap624(pos + 2 * r));
+                hit = draw_hits(p, w.x, w.y);
+            }
+            const unsigned long long bm = __ballot(hit);
+            if (lane == src) {
+                tape[2 * it] = (unsigned)(bm & 0xffffffffull);
+                tape[2 * it + 1] = (unsigned)(bm >> 32);
+            }
+            if (lane == 0) *reinterpret_cast<U2 *>(tp + 2 * it) = U2{(unsigned)(bm & 0xffffffffull), (unsigned)(bm >> 32)};
+        }
+        if (lane == 0) {
+            *reinterpret_cast<U2 *>(tp + 10) = U2{wlo, whi};
+            *reinterpret_cast<U2 *>(tp + 12) = U2{(unsigned)(p.detect_K & 0xffffffffull), (unsigned)(p.detect_K >> 32)};
+        }
+        if (lane == src) e.ahead = a;
+    }
+    drain_vmem();   // rare path: joins the steady-state path with nothing of its own in flight
+}
+
+// The lane's hit tape from the state blob, shifted to the lane's cursor; returns false when the stored tape does not
+// describe the words twisted ahead of this cursor (never built, other detect_prob, ...): the caller rebuilds it.
+template <int N>
+__device__ __forceinline__ bool tape_load(const DevParams &p, int b, const EnvL<N> &e, unsigned (&tape)[TAPE_DW]) {
+    const U4 *tp = reinterpret_cast<const U4 *>(p.tape + (size_t)b * TAPE_STRIDE);
+    const U4 t0 = tp[0], t1 = tp[1], t2 = tp[2], t3 = tp[3];
+    tape[0] = t0.x; tape[1] = t0.y; tape[2] = t0.z; tape[3] = t0.w;
+    tape[4] = t1.x; tape[5] = t1.y; tape[6] = t1.z; tape[7] = t1.w;
+    tape[8] = t2.x; tape[9] = t2.y;
+    const unsigned long long base = (unsigned long long)t2.z | ((unsigned long long)t2.w << 32);
+    const unsigned long long K = (unsigned long long)t3.x | ((unsigned long long)t3.y << 32);
+    const unsigned long long used = e.words - base;   // words consumed since the tape was written
+    const bool ok = K == p.detect_K && e.words >= base && used + (unsigned long long)e.ahead <= (unsigned long long)MT_N;
+    tape_shift<8>(tape, ok ? (int)(used >> 1) : 0);
+    return ok;
+}
+
+// Ordering inside one step (gfx9 has ONE in-order counter for vector loads and stores: waiting for a load also waits
+// for every store issued before it): the only loads of the steady-state loop -- the next step's actions -- are requested
+// before the step's output stores, and the number of stores between any load and its use is a compile-time constant, so
+// no wait of the loop ever needs a store to have been acknowledged by the memory system.  Rare paths (reset, tape
+// rebuild) end with nothing of their own in flight.
+//
+// VEC (every wavefront of the launch is full and every step's block of rows is 16-byte aligned; the host splits a batch
+// into a VEC launch and, for the last < 64 envs or an unaligned tensor, a plain one): the 64 get_state rows of step s
+// leave the tile as float4 chunks DURING step s + 1 -- a third after the kinematics, a third after the sensor tests, a
+// third after the draws -- so the write stream of a wavefront is spread over its arithmetic instead of arriving as
+// one burst per step.
+template <int N, bool VEC>
 __global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO io) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *T = reinterpret_cast<double *>(smem);                                   // trig table (2072 B)
@@ -1355,63 +1438,141 @@ __global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO i
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *tile = tiles + (size_t)wave * 64 * W;
     float *row = tile + (size_t)lane * W;   // W is odd for m = 15: conflict-free column accesses
-    const int b = blockIdx.x * BLOCK + threadIdx.x;
+    const int b = io.env0 + blockIdx.x * BLOCK + threadIdx.x;
     const int b0 = b - lane;  // first env of this wavefront
-    const bool live = b < p.B;
+    const int b_end = io.env0 + io.env_n;
+    const bool live = b < b_end;
     load_trig_to_lds(T);
-    if (b0 >= p.B) return;  // whole wavefront out of range
+    if (b0 >= b_end) return;  // whole wavefront out of range
     const int t16 = lane & (G - 1), gshift = lane & ~(G - 1), grp = lane >> 4;
     const unsigned tmask = p.n_targets >= 16 ? 0xffffu : ((1u << p.n_targets) - 1u);
+    constexpr int LOW = 2 * N * CS_MAX_TARGETS;   // words one step can consume: every lane enters a step with that many twisted
     EnvL<N> e;
     int act[N];
-    const unsigned *mt = p.mt + (size_t)(live ? b : 0) * MT_STRIDE;
+    unsigned tape[TAPE_DW];
+    const size_t arow = live ? (size_t)b : 0;
+    bool tape_ok = true;
     if (live) {
         envl_load<N>(p, b, T, row, e);
-        load_actions<N>(io, (size_t)b, act);
+        tape_ok = tape_load<N>(p, b, e, tape);
     } else {
         envl_zero<N>(e);
 #pragma unroll
-        for (int i = 0; i < N; i++) act[i] = 0;
+        for (int k = 0; k < TAPE_DW; k++) tape[k] = 0u;
     }
-    const bool full_wave = b0 + 64 <= p.B;
+    while (const unsigned long long low = __ballot(live && (!tape_ok || e.ahead < LOW))) {
+        lane_rebuild<N>(p, b0, lane, low, e, tape);
+        tape_ok = true;
+    }
+    load_actions<N>(io, arow, act);
+    const int rows_valid = b_end - b0 < 64 ? b_end - b0 : 64;
+    constexpr int W_MAX = 4 * N + 3 * CS_MAX_TARGETS;
+    constexpr int Q = (16 * W_MAX + 63) / 64;   // float4 chunks per lane of the largest tile
+    // float4 chunks [q0, q1) of the tile -> rows of step `step`.  Chunk k = min(lane + 64 q, last): surplus lanes repeat
+    // the last chunk (same value, same address), so every lane stores every time.
+    auto copy_chunks = [&](int q0, int q1, size_t step) {
+        const float4 *src4 = reinterpret_cast<const float4 *>(tile);
+        float4 *dst4 = reinterpret_cast<float4 *>(io.state + (step * p.B + b0) * W);
+        const int last = 16 * W - 1;
+        int l0 = lane;
+        asm volatile("" : "+v"(l0));   // the address pairs are recomputed at every use (hoisted out of the loop they spill)
+#pragma unroll
+        for (int q = q0; q < q1; q++) {
+            const int k = l0 + 64 * q < last ? l0 + 64 * q : last;
+            dst4[k] = src4[k];
+        }
+    };
+    bool flushed = true;   // VEC: the tile holds no step that still has to be written out
     for (int s = 0; s < io.T; s++) {
-        const size_t slot = (size_t)s * p.B + (live ? b : 0);
+        const size_t slot = (size_t)s * p.B + arow;
+        LANE_STAMP(0);
         bool done = live && (e.target_find >= p.n_targets || e.time_step >= p.time_limit);
-        // ---- auto-reset: the four 16-lane groups of the wavefront each take one resetting env -----------------
-        unsigned long long need = __ballot(done && (io.flags & CS_AUTO_RESET));
+        // ---- auto-reset: the four 16-lane groups of the wavefront each take one resetting env per round.  The env's
+        //      cursor goes to its group by shuffle, the new targets come back through the lane's tile row (fp64 copies
+        //      go to the state blob without anybody waiting for them), the counters by shuffle: the only memory round
+        //      trip of a reset is the MT19937 words of its polar-gaussian attempts.
+        const unsigned long long need = __ballot(done && (io.flags & CS_AUTO_RESET));
         if (need) {
-            if ((need >> lane) & 1ull) envl_store<N>(p, b, e);  // publish cursor / counters for the helper groups
-            while (need) {
-                unsigned long long m = need;
+            if (VEC && !flushed) copy_chunks(0, Q, (size_t)(s - 1));   // the resets rewrite rows of the tile
+            flushed = true;
+            const bool mine = (need >> lane) & 1ull;
+            const int my_rank = __popcll(need & ((1ull << lane) - 1ull));
+            unsigned long long pend = need;
+            for (int round = 0; pend; round++) {
+                unsigned long long m = pend;
                 for (int q = 0; q < grp; q++) m &= m ? m - 1 : 0ull;   // this group's env: the grp-th pending one
                 const int src = m ? __ffsll((long long)m) - 1 : -1;
-                for (int q = 0; q < 4; q++) need &= need ? need - 1 : 0ull;
+                for (int q = 0; q < 4; q++) pend &= pend ? pend - 1 : 0ull;
+                const int sl = src >= 0 ? src : lane;
+                Env<N> g;
+                g.mt_pos = __shfl(e.mt_pos, sl);
+                g.ahead = __shfl(e.ahead, sl);
+                g.episodes = __shfl(e.episodes, sl);
+                g.words = (unsigned long long)(unsigned)__shfl((int)(unsigned)(e.words & 0xffffffffull), sl) |
+                          ((unsigned long long)(unsigned)__shfl((int)(unsigned)(e.words >> 32), sl) << 32);
+                g.newly_reset = 0u;
+                g.curr_reward = 0;
+                g.tx = g.ty = 0.0;
                 if (src >= 0) {
                     const int br = b0 + src;
-                    Env<N> g;
-                    env_load<N>(p, br, t16, g);
                     env_reset<N>(p, T, br, t16, gshift, 0, g);
-                    env_store<N>(p, br, t16, g, true);
+                    reinterpret_cast<double2 *>(p.tgt + (size_t)br * G * 2)[t16] = make_double2(g.tx, g.ty);
+                    if (t16 < p.n_targets) {
+                        float *rs = tile + (size_t)src * W + 4 * N + 3 * t16;
+                        rs[0] = g.ntx;
+                        rs[1] = g.nty;
+                        rs[2] = ((g.found >> t16) & 1u) ? 1.0f : 0.0f;
+                    }
+                }
+                // the q-th pending env of this round was reset by group q: its (group-uniform) counters come back
+                const int q = my_rank - 4 * round;
+                const bool got = mine && q >= 0 && q < 4;
+                const int leader = got ? 16 * q : lane;
+                const int r_pos = __shfl(g.mt_pos, leader), r_ahead = __shfl(g.ahead, leader);
+                const int r_epi = __shfl(g.episodes, leader), r_tf = __shfl(g.target_find, leader);
+                const int r_flags = __shfl(g.flags, leader), r_cr = __shfl(g.curr_reward, leader);
+                const int r_found = __shfl((int)g.found, leader), r_newly = __shfl((int)g.newly, leader);
+                const int r_wlo = __shfl((int)(unsigned)(g.words & 0xffffffffull), leader);
+                const int r_whi = __shfl((int)(unsigned)(g.words >> 32), leader);
+                if (got) {
+                    const unsigned long long w_new = (unsigned long long)(unsigned)r_wlo | ((unsigned long long)(unsigned)r_whi << 32);
+                    // the reset consumed (w_new - words) stream words, twisted ones first: their draw slots leave the tape
+                    const unsigned long long used = w_new - e.words;
+                    tape_shift<8>(tape, used < 2ull * 319ull ? (int)(used >> 1) : 319);
+                    e.mt_pos = r_pos;
+                    e.ahead = r_ahead;
+                    e.episodes = r_epi;
+                    e.target_find = r_tf;
+                    e.flags = r_flags;
+                    e.curr_reward = r_cr;
+                    e.found = (unsigned)r_found;
+                    e.newly = (unsigned)r_newly;
+                    e.words = w_new;
+                    e.time_step = 0;
+                    e.total_reward = 0;
+#pragma unroll
+                    for (int i = 0; i < N; i++) {
+                        start_pose<N>(p, i, e.ax[i], e.ay[i], e.yaw[i]);
+                        trig_heading(T, e.yaw[i], e.sn[i], e.cs[i]);
+                    }
+                    done = false;
                 }
             }
-            if (done && (io.flags & CS_AUTO_RESET)) {
-                envl_load<N>(p, b, T, row, e);
-                done = false;
-            }
+            // a reset that ran past the twisted words leaves its lane without a tape for this step: rebuild
+            while (const unsigned long long low = __ballot(e.ahead < LOW)) lane_rebuild<N>(p, b0, lane, low, e, tape);
+            drain_vmem();
         }
-        // ---- MT19937: keep at least LANE_LOW twisted words ahead of every cursor, then request this step's window
-        const unsigned long long low = __ballot(e.ahead < LANE_LOW);
-        if (low) lane_refill<N>(p, b0, lane, low, e);
-        U4 pre[LANE_PRE];
-#pragma unroll
-        for (int q = 0; q < LANE_PRE; q++) pre[q] = *reinterpret_cast<const U4 *>(mt + e.mt_pos + 4 * q);
-        int act_next[N];
-        load_actions<N>(io, (size_t)(s + 1 < io.T ? s + 1 : s) * p.B + (live ? b : 0), act_next);
+        // rows still to be written out: step s - 1's; after a flush (or at s = 0) the same chunks go to step s's own
+        // slot instead, which this wavefront overwrites with the real rows one step later
+        const size_t cstep = (size_t)(flushed ? s : s - 1);
+        LANE_STAMP(1);
         int reward = 0;
         bool term = true;
         const bool stepping = live && !(done && (io.flags & CS_FREEZE_DONE));
         e.flags &= ~(FLAG_DIRTY | FLAG_RESET_PASS);
         if (stepping) kinematics_lane<N>(p, T, act, e);
+        if (VEC) copy_chunks(0, Q / 3, cstep);
+        LANE_STAMP(2);
         float4 f[N];
 #pragma unroll
         for (int i = 0; i < N; i++)
@@ -1427,18 +1588,21 @@ __global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO i
                 ntx[j] = j < p.n_targets ? row[4 * N + 3 * j + 0] : 0.0f;
                 nty[j] = j < p.n_targets ? row[4 * N + 3 * j + 1] : 0.0f;
             }
+            const float thr_lo = p.thr32 - p.eps32, thr_hi = p.thr32 + p.eps32;
 #pragma unroll
             for (int i = 0; i < N; i++) {
-                unsigned m = 0, fz = 0;
+                // sign bits of d2 - thr_lo / d2 - thr_hi, target 15 first, funnel-shifted into the masks (one
+                // v_alignbit each): bit j of `sure` = (d2 < thr - eps), of `maybe` = (d2 < thr + eps)
+                unsigned sure = 0, maybe = 0;
 #pragma unroll
-                for (int j = 0; j < CS_MAX_TARGETS; j++) {
+                for (int j = CS_MAX_TARGETS - 1; j >= 0; j--) {
                     const float dx = ntx[j] - f[i].x, dy = nty[j] - f[i].y;
                     const float d2 = __builtin_fmaf(dx, dx, dy * dy);
-                    m |= (d2 < p.thr32 - p.eps32 ? 1u : 0u) << j;
-                    fz |= (!(d2 < p.thr32 - p.eps32) && !(d2 > p.thr32 + p.eps32) ? 1u : 0u) << j;
+                    sure = __builtin_amdgcn_alignbit(sure, __float_as_uint(d2 - thr_lo), 31);
+                    maybe = __builtin_amdgcn_alignbit(maybe, __float_as_uint(d2 - thr_hi), 31);
                 }
-                m &= tmask;
-                fz &= tmask;
+                unsigned m = sure & tmask;
+                unsigned fz = maybe & ~sure & tmask;
                 while (fz) {  // (t_x-x)**2 + (t_y-y)**2 <= view_range**2 on the fp64 values
                     const int j = __ffs((int)fz) - 1;
                     fz &= fz - 1;
@@ -1450,24 +1614,19 @@ __global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO i
                 else hi |= (unsigned long long)m << (16 * (i - 4));
             }
         }
-        // ---- one np.random.rand() per in-range pair, found or not (quirk Q4), in agent-major order
+        if (VEC) copy_chunks(Q / 3, 2 * Q / 3, cstep);
+        LANE_STAMP(3);
+        // ---- one np.random.rand() per in-range pair, found or not (quirk Q4), in agent-major order: the r-th set bit
+        //      of (lo, hi) takes draw slot r of the tape
         const int total = __popcll(lo) + (N > 4 ? __popcll(hi) : 0);
         unsigned hitmask = 0;
         {
-            int pos = e.mt_pos;  // always even: every consumer takes an even number of words
-            for (int r0 = 0; __ballot(r0 < total); r0 += 2 * LANE_PRE) {
-                if (r0 > 0) {  // more than 16 draws in one step somewhere in the wavefront: fetch the next window
-                    while (const unsigned long long more = __ballot(r0 < total && e.ahead < 2 * total))
-                        lane_refill<N>(p, b0, lane, more, e);
+            unsigned w16 = tape[0];
+            for (int r0 = 0; __ballot(r0 < total); r0 += 16) {
+                const int take = total - r0;   // <= 0: nothing left for this lane
 #pragma unroll
-                    for (int q = 0; q < LANE_PRE; q++) pre[q] = *reinterpret_cast<const U4 *>(mt + pos + 4 * q);
-                }
-                const int take = total - r0 < 2 * LANE_PRE ? total - r0 : 2 * LANE_PRE;   // <= 0: nothing left for this lane
-#pragma unroll
-                for (int k = 0; k < 2 * LANE_PRE; k++) {
+                for (int k = 0; k < 16; k++) {
                     if (k < take) {
-                        const U4 c = pre[k / 2];
-                        const unsigned wa = (k & 1) ? c.z : c.x, wb = (k & 1) ? c.w : c.y;
                         int bit;
                         if (N <= 4 || lo) {
                             bit = __ffsll((long long)lo) - 1;
@@ -1476,16 +1635,23 @@ __global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO i
                             bit = __ffsll((long long)hi) - 1;
                             hi &= hi - 1;
                         }
-                        const unsigned long long u = ((unsigned long long)(mt_temper(wa) >> 5) << 26) | (unsigned long long)(mt_temper(wb) >> 6);
-                        hitmask |= (u <= p.detect_K ? 1u : 0u) << (bit & 15);  // prob <= self.detect_prob, exact in integers
+                        hitmask |= ((w16 >> k) & 1u) << (bit & 15);
                     }
                 }
-                if (take > 0) pos = wrap624(pos + 2 * take);
+                // slots r0 + 16 ..: (r0 is wave-uniform, so the tape dword is picked with uniform selects)
+                const int nx = r0 + 16;
+                unsigned nxt = 0;
+#pragma unroll
+                for (int d = 0; d < (N * CS_MAX_TARGETS + 31) / 32; d++) nxt = (nx >> 5) == d ? tape[d] : nxt;
+                w16 = nxt >> (nx & 31);
             }
-            e.mt_pos = pos;
+            e.mt_pos = wrap624(e.mt_pos + 2 * total);
             e.words += (unsigned long long)(2 * total);
             e.ahead -= 2 * total;
+            tape_shift<(N * CS_MAX_TARGETS) / 32 < 1 ? 1 : (N * CS_MAX_TARGETS) / 32>(tape, total);
         }
+        if (VEC) copy_chunks(2 * Q / 3, Q, cstep);
+        LANE_STAMP(4);
         if (stepping) {
             const unsigned newly = hitmask & ~e.found;
             const int cnt = __popc(newly);
@@ -1511,6 +1677,21 @@ __global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO i
                     if ((newly >> j) & 1u) row[4 * N + 3 * j + 2] = 1.0f;
             }
         }
+        if (live && io.state) {
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                row[4 * i + 0] = f[i].x;
+                row[4 * i + 1] = f[i].y;
+                row[4 * i + 2] = f[i].z;
+                row[4 * i + 3] = f[i].w;
+            }
+        }
+        LANE_STAMP(5);
+        // ---- what the next step waits for, requested BEFORE this step's stores: the (rare) tape rebuild, the next actions
+        while (const unsigned long long low = __ballot(e.ahead < LOW)) lane_rebuild<N>(p, b0, lane, low, e, tape);
+        load_actions<N>(io, (size_t)(s + 1 < io.T ? s + 1 : s) * p.B + arow, act);
+        LANE_STAMP(6);
+        // ---- this step's outputs
         if (live) {
             io.reward[slot] = (float)reward;
             io.terminated[slot] = term ? 1 : 0;
@@ -1520,32 +1701,15 @@ __global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO i
 #pragma unroll
                 for (int i = 0; i < N; i++) o[i] = f[i];
             }
-            if (io.state) {
-#pragma unroll
-                for (int i = 0; i < N; i++) {
-                    row[4 * i + 0] = f[i].x;
-                    row[4 * i + 1] = f[i].y;
-                    row[4 * i + 2] = f[i].z;
-                    row[4 * i + 3] = f[i].w;
-                }
-            }
         }
-        if (io.state) {
-            // the wave's 64 rows are contiguous in get_state's [B][W] layout: copy the tile out as one block
+        if (!VEC && io.state) {   // plain launch: the wave's rows (contiguous in get_state's [B][W] layout) leave now
             float *dst = io.state + ((size_t)s * p.B + b0) * W;
-            const bool vec = full_wave && ((reinterpret_cast<size_t>(dst) & 15) == 0) && ((64 * W) % 4 == 0);
-            if (vec) {
-                const float4 *src4 = reinterpret_cast<const float4 *>(tile);
-                float4 *dst4 = reinterpret_cast<float4 *>(dst);
-                for (int k = lane; k < 16 * W; k += 64) dst4[k] = src4[k];
-            } else {
-                const int rows = p.B - b0 < 64 ? p.B - b0 : 64;
-                for (int k = lane; k < rows * W; k += 64) dst[k] = tile[k];
-            }
+            for (int k = lane; k < rows_valid * W; k += 64) dst[k] = tile[k];
         }
-#pragma unroll
-        for (int i = 0; i < N; i++) act[i] = act_next[i];
+        flushed = false;
+        LANE_STAMP(7);
     }
+    if (VEC) copy_chunks(0, Q, (size_t)(io.T - 1));
     if (live) envl_store<N>(p, b, e);
 }
 
@@ -1601,8 +1765,6 @@ __global__ __launch_bounds__(BLOCK) void k_emit(DevParams p, float *obs, float *
 // Corner test `(x-ax)**2 + (y-ay)**2 < view_range**2` (strict, flight_env.py:300): decided in fp32 when the
 // fp32 distance is clear of the threshold by more than its error bound, in exact fp64 otherwise.
 // ---------------------------------------------------------------------------------------------------------
-typedef float v4f __attribute__((ext_vector_type(4)));
-
 // Per-pass data of one env in LDS.
 struct MapPassLds {
     unsigned long long rowbits[CS_MAX_MAP + 2];  // bit Y of rowbits[X]: lattice point (X, Y) strictly inside a disc
@@ -1808,6 +1970,73 @@ __global__ void k_seed(DevParams p, const uint32_t *seeds) {
     p.ahead[b] = 0;
 }
 
+// MT19937 pre-pass of the lane-per-env rollout: one wavefront per env twists the WHOLE row ahead of the cursor
+// (ahead -> 624) for every env that has fewer than `min_ahead` twisted words left, and writes the env's HIT TAPE: the
+// detection pass only ever asks of a draw whether `rand() <= detect_prob`, so the 312 draws of a row boil down to 312
+// bits, which the lane kernel keeps in ten registers -- its loop loads no MT19937 word and tempers nothing (resets, which
+// need the uniforms themselves, read the twisted words).  Row in, row out, fully coalesced:
+// 2.5 KB read + the regenerated words written, against 3 loads + 1 store per 64 words for the in-kernel refill, and the
+// rollout's steady-state loop then never waits for a refill (which stays as the fallback for envs that draw more than
+// a row's worth inside one chunk).  Super-batches of 192 words: word j needs stored words j, j+1, j+397, none of which
+// another word of the same super-batch writes (192 <= 227); within a wavefront LDS operations complete in order.
+__global__ __launch_bounds__(256) void k_mt_advance(DevParams p, int min_ahead) {
+    __shared__ unsigned rows[4][MT_N];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= p.B) return;
+    int a = p.ahead[b];
+    if (a >= min_ahead || a >= MT_N) return;   // wave-uniform
+    unsigned *m = p.mt + (size_t)b * MT_STRIDE;
+    unsigned *row = rows[wave];
+    const int pos = p.hdr[(size_t)b * CS_H_WORDS + CS_H_MT_POS];
+    for (int i = lane; i < MT_N; i += 64) row[i] = m[i];
+    while (a < MT_N) {
+        const int r = MT_N - a < LANE_REFILL_MAX ? MT_N - a : LANE_REFILL_MAX;
+        const int g = wrap624(pos + a);
+        unsigned nw[3];
+        int idx[3];
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int j = wrap624(g + 64 * c + lane);
+            idx[c] = j;
+            nw[c] = mt_mix(row[j], row[wrap624(j + 1)], row[wrap624(j + MT_M)]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            if (64 * c + lane < r) {
+                row[idx[c]] = nw[c];
+                mt_store(m, idx[c], nw[c]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        a += r;
+    }
+    // hit tape: bit r = "the draw made of stream words 2r, 2r + 1 from the cursor hits" for all 312 slots of the row
+    unsigned *tp = p.tape + (size_t)b * TAPE_STRIDE;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int it = 0; it < TAPE_DW / 2; it++) {
+        const int r = 64 * it + lane;
+        bool hit = false;
+        if (2 * r < MT_N) {
+            const int i0 = wrap624(pos + 2 * r);   // even, so i0 + 1 <= 623
+            hit = draw_hits(p, row[i0], row[i0 + 1]);
+        }
+        const unsigned long long bm = __ballot(hit);
+        if (lane == 0) *reinterpret_cast<U2 *>(tp + 2 * it) = U2{(unsigned)(bm & 0xffffffffull), (unsigned)(bm >> 32)};
+    }
+    if (lane == 0) {
+        const int *h = p.hdr + (size_t)b * CS_H_WORDS;
+        *reinterpret_cast<U2 *>(tp + 10) = U2{(unsigned)h[CS_H_WORDS_LO], (unsigned)h[CS_H_WORDS_HI]};
+        *reinterpret_cast<U2 *>(tp + 12) = U2{(unsigned)(p.detect_K & 0xffffffffull), (unsigned)(p.detect_K >> 32)};
+        p.ahead[b] = MT_N;
+    }
+}
+
 // One wavefront per env: the env's row in canonical form (MT_CANON words twisted ahead of the cursor), state untouched.
 __global__ __launch_bounds__(64) void k_mt_canonical(DevParams p, unsigned *out) {
     __shared__ unsigned row[MT_N];
@@ -1927,6 +2156,7 @@ int make_params(const cs_config *c, void *state, DevParams *p) {
     p->hdr = (int *)(base + lay.hdr_off);
     p->mt = (unsigned *)(base + lay.mt_off);
     p->ahead = (int *)(base + lay.ahead_off);
+    p->tape = (unsigned *)(base + lay.tape_off);
     // lane kernel's fp32 pre-filter of `d2 <= view_range**2` in get_state's normalised coordinates: |fp32 d2 - exact| <=
     // 4.5e-7 sqrt(thr) + 1.2e-7 thr near the threshold; pairs inside +-eps take the fp64 test
     {
@@ -1949,7 +2179,24 @@ int launched(const char *what) {
 
 inline dim3 map_grid(const DevParams &p) { return dim3((unsigned)p.B, (unsigned)((p.cells / 4 + MAP_BLOCK - 1) / MAP_BLOCK)); }
 
-inline unsigned lane_blocks(const DevParams &p) { return (unsigned)(((size_t)p.B + BLOCK - 1) / BLOCK); }
+// Lane-per-env launch(es) of one chunk: a VEC launch over the full wavefronts when every step's block of get_state
+// rows is 16-byte aligned, a plain launch for the remaining < 64 envs (or for everything otherwise).
+template <int N>
+void launch_lane(const cs_config *cfg, const DevParams &p, StepIO io, size_t smem, hipStream_t s) {
+    const size_t W = 4 * (size_t)cfg->n_agents + 3 * (size_t)cfg->n_targets;
+    const bool aligned = io.state && (reinterpret_cast<size_t>(io.state) & 15) == 0 && ((size_t)p.B * W) % 4 == 0;
+    const int full = aligned ? (p.B / 64) * 64 : 0;
+    if (full > 0) {
+        io.env0 = 0;
+        io.env_n = full;
+        hipLaunchKernelGGL((k_rollout_lane<N, true>), dim3((unsigned)((full + BLOCK - 1) / BLOCK)), dim3(BLOCK), smem, s, p, io);
+    }
+    if (p.B - full > 0) {
+        io.env0 = full;
+        io.env_n = p.B - full;
+        hipLaunchKernelGGL((k_rollout_lane<N, false>), dim3((unsigned)((p.B - full + BLOCK - 1) / BLOCK)), dim3(BLOCK), smem, s, p, io);
+    }
+}
 inline size_t lane_smem(const cs_config *c) {
     const size_t W = 4 * (size_t)c->n_agents + 3 * (size_t)c->n_targets;
     return ((TRIG_ROWS * TRIG_COLS * 8 + 15) / 16) * 16 + (BLOCK / 64) * 64 * W * sizeof(float);
@@ -1964,6 +2211,9 @@ inline bool use_lane_kernel(const cs_config *c, int flags) {
 
 inline unsigned env_blocks(const DevParams &p) { return (unsigned)(((size_t)p.B * G + BLOCK - 1) / BLOCK); }
 
+#ifdef CS_ONLY_N   // experiments only: instantiate one team size (fast compiles)
+#define CS_DISPATCH_N(n, CALL) { constexpr int N = CS_ONLY_N; CALL; }
+#else
 #define CS_DISPATCH_N(n, CALL)                                   \
     switch (n) {                                                 \
     case 1: { constexpr int N = 1; CALL; } break;                \
@@ -1975,6 +2225,7 @@ inline unsigned env_blocks(const DevParams &p) { return (unsigned)(((size_t)p.B 
     case 7: { constexpr int N = 7; CALL; } break;                \
     default: { constexpr int N = 8; CALL; } break;               \
     }
+#endif
 
 }  // namespace
 
@@ -1999,6 +2250,8 @@ int cs_state_layout(const cs_config *cfg, cs_layout *out) {
     off = align_up(off + B * MT_STRIDE * sizeof(uint32_t), 256);
     out->ahead_off = off;
     off = align_up(off + B * sizeof(int32_t), 256);
+    out->tape_off = off;
+    off = align_up(off + B * TAPE_STRIDE * sizeof(uint32_t), 256);
     out->prob_off = off;
     if (cfg->variant == 1) off = align_up(off + B * (size_t)cfg->map_size * cfg->map_size * sizeof(float), 256);
     out->total_bytes = off;
@@ -2054,8 +2307,7 @@ int cs_step(const cs_config *cfg, void *state_dev, const void *actions_dev, int 
     hipStream_t s = (hipStream_t)stream;
     StepIO io{actions_dev, reward_dev, terminated_dev, win_dev, obs_dev, state_out_dev, flags, 1};
     if (cfg->variant == 0 && use_lane_kernel(cfg, flags)) {
-        CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_rollout_lane<N>, dim3(lane_blocks(p)), dim3(BLOCK),
-                                                        lane_smem(cfg), s, p, io));
+        CS_DISPATCH_N(cfg->n_agents, launch_lane<N>(cfg, p, io, lane_smem(cfg), s));
     } else if (cfg->variant == 0) {
         CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL((k_step<N, 0>), dim3(env_blocks(p)), dim3(BLOCK), 0, s, p, io));
     } else {
@@ -2090,8 +2342,21 @@ int cs_rollout(const cs_config *cfg, void *state_dev, const void *actions_dev, i
     }
     StepIO io{actions_dev, reward_dev, terminated_dev, win_dev, obs_dev, state_out_dev, flags, T};
     if (use_lane_kernel(cfg, flags)) {
-        CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_rollout_lane<N>, dim3(lane_blocks(p)), dim3(BLOCK),
-                                                        lane_smem(cfg), (hipStream_t)stream, p, io));
+        // LANE_CHUNK steps per launch; before each chunk every env's MT19937 row is twisted fully ahead of its cursor by
+        // a coalesced pre-pass, so the rollout loop itself (almost) never has to stop for a refill
+        hipStream_t s = (hipStream_t)stream;
+        const size_t n = (size_t)cfg->n_agents, W = 4 * n + 3 * (size_t)cfg->n_targets, B = (size_t)p.B;
+        const size_t act_w = n * ((flags & CS_ACTIONS_I64) ? 8 : 4);
+        for (int t0 = 0; t0 < T; t0 += LANE_CHUNK) {
+            const int tc = T - t0 < LANE_CHUNK ? T - t0 : LANE_CHUNK;
+            if (tc >= 8)
+                hipLaunchKernelGGL(k_mt_advance, dim3((unsigned)((p.B + 3) / 4)), dim3(256), 0, s, p, MT_N - 64);
+            StepIO it{(const char *)actions_dev + (size_t)t0 * B * act_w, reward_dev + (size_t)t0 * B,
+                      terminated_dev + (size_t)t0 * B, win_dev + (size_t)t0 * B,
+                      obs_dev ? obs_dev + (size_t)t0 * B * n * 4 : nullptr,
+                      state_out_dev ? state_out_dev + (size_t)t0 * B * W : nullptr, flags, tc};
+            CS_DISPATCH_N(cfg->n_agents, launch_lane<N>(cfg, p, it, lane_smem(cfg), s));
+        }
     } else {
         CS_DISPATCH_N(cfg->n_agents,
                       hipLaunchKernelGGL(k_rollout<N>, dim3(env_blocks(p)), dim3(BLOCK), 0, (hipStream_t)stream, p, io));
@@ -2127,6 +2392,14 @@ int cs_rollout_policy(const cs_config *cfg, void *state_dev, const float *packed
     }
 #undef CS_LAUNCH_RP
     return launched("cs_rollout_policy");
+}
+
+int cs_mt_advance(const cs_config *cfg, void *state_dev, int min_ahead, void *stream) {
+    DevParams p;
+    int rc = make_params(cfg, state_dev, &p);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_mt_advance, dim3((unsigned)((p.B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, min_ahead);
+    return launched("cs_mt_advance");
 }
 
 int cs_mt_canonical(const cs_config *cfg, void *state_dev, uint32_t *rows_out_dev, void *stream) {

@@ -37,6 +37,7 @@ extern "C" {
 #define CS_MAX_MAP 64
 #define CS_MT_PAD 32      /* words 0..31 of an env's MT19937 row are mirrored behind word 623 */
 #define CS_MT_STRIDE 672  /* uint32 words per env row: 624 state + 32 mirror + 16 unused (21 x 128 bytes) */
+#define CS_TAPE_STRIDE 16 /* uint32 words per env of the lane kernel's hit tape (cs_layout.tape_off) */
 
 enum { CS_OK = 0, CS_E_CONFIG = -1, CS_E_ARG = -2, CS_E_LAUNCH = -3 };
 
@@ -83,7 +84,12 @@ typedef struct cs_layout {
                           words 624..655 mirror words 0..31                                          */
     size_t ahead_off;  /* int32  [B]          number of words at the cursor that are ALREADY twisted (their outputs
                           are temper(word)): the lane-per-env kernel regenerates the state 192 words at a time,
-                          coalesced, ahead of consumption; 0 = the plain circular form.  0 <= ahead <= 512   */
+                          coalesced, ahead of consumption; 0 = the plain circular form.  0 <= ahead <= 624   */
+    size_t tape_off;   /* uint32 [B][CS_TAPE_STRIDE] hit tape of the twisted words: bit r of words 0..9 = "the draw made of
+                          stream words 2r, 2r+1 counted from the stream position `base` satisfies rand() <= detect_prob";
+                          words 10, 11 = base (value of CS_H_WORDS_LO/HI when written), 12, 13 = the integer threshold
+                          it was built for.  Derived data: written by cs_mt_advance / the lane kernel, ignored (and
+                          rebuilt) whenever it does not match the cursor                                        */
     size_t prob_off;   /* float  [B][map*map] probability map, first index = x cell (flight only)        */
 } cs_layout;
 
@@ -144,7 +150,12 @@ int cs_rollout(const cs_config *cfg, void *state_dev, const void *actions_dev, i
                float *reward_dev, uint8_t *terminated_dev, uint8_t *win_dev,
                float *obs_dev, float *state_out_dev, void *stream);
 
-/* Writes every env's MT19937 row in CANONICAL form -- exactly 512 words pre-twisted ahead of the cursor -- to
+/* MT19937 pre-pass: for every env with fewer than `min_ahead` twisted words ahead of its cursor, twist the whole row
+ * ahead (ahead -> 624) in one coalesced sweep.  Does not change any stream: only WHEN its words are regenerated.
+ * cs_rollout's lane-per-env path runs it before every 64-step chunk; exported for callers that drive cs_step. */
+int cs_mt_advance(const cs_config *cfg, void *state_dev, int min_ahead, void *stream);
+
+/* Writes every env's MT19937 row in CANONICAL form -- all 624 words twisted ahead of the cursor -- to
  * rows_out_dev (uint32 [B][CS_MT_STRIDE]) without changing the state.  Two states that describe the same position of the same
  * stream have equal canonical rows (and equal CS_H_MT_POS), however much of the row each kernel had pre-twisted. */
 int cs_mt_canonical(const cs_config *cfg, void *state_dev, uint32_t *rows_out_dev, void *stream);

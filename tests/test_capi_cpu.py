@@ -50,11 +50,12 @@ def test_state_layout_host_only():
     B = 4096
     assert lay.tgt_off == 0 and lay.agent_off == B * 256 and lay.hdr_off == lay.agent_off + B * 256
     assert lay.mt_off == lay.hdr_off + B * 64 and lay.ahead_off == lay.mt_off + B * _lib.MT_STRIDE * 4
-    assert lay.prob_off == lay.ahead_off + B * 4 and lay.total_bytes == lay.prob_off   # flight_easy: no map
+    assert lay.tape_off == lay.ahead_off + B * 4 and lay.prob_off == lay.tape_off + B * 64
+    assert lay.total_bytes == lay.prob_off   # flight_easy: no map
     cfg = _cfg(env="flight", n_agents=3, batch=8192)
     assert L.cs_state_layout(C.byref(cfg), C.byref(lay)) == 0
     assert lay.total_bytes == lay.prob_off + 8192 * 2500 * 4
-    for off in (lay.tgt_off, lay.agent_off, lay.hdr_off, lay.mt_off, lay.ahead_off, lay.prob_off):
+    for off in (lay.tgt_off, lay.agent_off, lay.hdr_off, lay.mt_off, lay.ahead_off, lay.tape_off, lay.prob_off):
         assert off % 256 == 0
 
 

@@ -608,3 +608,28 @@ def test_flight_long_horizon_matches_oracle():
                                            err_msg=f"obs (map + feats) step {t}")
         compare_with_oracle(env, ob, B, n, m, "flight long horizon")
         assert hdr(env)[:, _lib.H_EPISODES].min() >= 5
+
+
+def test_mt_advance_changes_when_not_what():
+    """cs_mt_advance (the lane kernel's pre-pass) twists rows ahead of their cursors: canonical rows, cursors and every
+    later draw are unchanged; only `ahead` moves."""
+    B, n = 300, 3
+    args = cs.make_env_args("flight_easy", n_agents=n)
+    seeds = np.arange(B, dtype=np.uint32) + 4242
+    e1 = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, freeze_done=False, auto_reset=True, kernel="group")
+    e2 = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, freeze_done=False, auto_reset=True, kernel="group")
+    g = torch.Generator("cuda").manual_seed(3)
+    for t in range(260):
+        a = torch.randint(0, 3, (B, n), dtype=torch.int32, device="cuda", generator=g)
+        if t % 37 == 5:
+            before = e2.mt_canonical()
+            _lib.check(e2._L.cs_mt_advance(e2._cfgp, e2._blob.data_ptr(), 10 ** 6 if t % 2 else 300, e2._stream()))
+            assert torch.equal(before, e2.mt_canonical())
+            assert int(e2.raw()["ahead"].max().item()) == 624
+        r1, t1, w1 = e1.step(a)
+        r2, t2, w2 = e2.step(a)
+        assert torch.equal(r1, r2) and torch.equal(t1, t2) and torch.equal(w1, w2), f"step {t}"
+    assert int(e1.raw()["ahead"].max().item()) == 0     # the group kernels never twist ahead themselves
+    r1, r2 = raw_state(e1), raw_state(e2)
+    for k in ("tgt", "agent", "hdr", "mt"):
+        assert torch.equal(r1[k], r2[k]), k

@@ -13,7 +13,7 @@ for B in Bs:
     env = cs.BatchedFlightEnv(cs.make_env_args("flight_easy", n_agents=n), batch=B, freeze_done=False, auto_reset=True,
                               kernel=kernel)
     acts = torch.randint(0, 3, (T, B, n), dtype=torch.int32, device="cuda")
-    out = env.rollout(acts)
+    out = env.rollout(acts, emit=os.environ.get("EMIT", "1") == "1")
     for _ in range(2):
         env.rollout(acts, out=out, update_views=False)
     torch.cuda.synchronize()
