@@ -1193,7 +1193,10 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io
 // =========================================================================================================
 constexpr int LANE_REFILL = 192;   // words twisted per refill (<= 227: independent of each other)
 constexpr int LANE_REFILL_MAX = 192;
-constexpr int LANE_CHUNK = 64;     // steps per launch of the lane kernel: cs_rollout twists every row ahead in between
+#ifndef CS_LANE_CHUNK
+#define CS_LANE_CHUNK 64
+#endif
+constexpr int LANE_CHUNK = CS_LANE_CHUNK;     // steps per launch of the lane kernel: cs_rollout twists every row ahead in between
 constexpr int TAPE_DW = 10;        // 320 hit bits >= the 312 draw slots (word pairs) of one MT19937 row
 constexpr int TAPE_STRIDE = CS_TAPE_STRIDE;  // dwords per env: 10 of bits | base lo, hi | K lo, hi | 2 unused
 
@@ -1479,7 +1482,9 @@ __global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO i
 #pragma unroll
         for (int q = q0; q < q1; q++) {
             const int k = l0 + 64 * q < last ? l0 + 64 * q : last;
-            dst4[k] = src4[k];
+            const float4 v = src4[k];
+            const v4f nv = {v.x, v.y, v.z, v.w};   // write-once stream: non-temporal (+6 % on the whole kernel)
+            __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(dst4 + k));
         }
     };
     bool flushed = true;   // VEC: the tile holds no step that still has to be written out
@@ -1699,7 +1704,10 @@ __global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO i
             if (io.obs) {
                 float4 *o = reinterpret_cast<float4 *>(io.obs) + slot * N;
 #pragma unroll
-                for (int i = 0; i < N; i++) o[i] = f[i];
+                for (int i = 0; i < N; i++) {
+                    const v4f nv = {f[i].x, f[i].y, f[i].z, f[i].w};
+                    __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(o + i));
+                }
             }
         }
         if (!VEC && io.state) {   // plain launch: the wave's rows (contiguous in get_state's [B][W] layout) leave now
