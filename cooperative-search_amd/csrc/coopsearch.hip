@@ -136,6 +136,59 @@ __device__ __forceinline__ int kth_set_bit16(unsigned mask, int k) {
     return sel;
 }
 
+struct __attribute__((packed, aligned(4))) U4 { unsigned x, y, z, w; };  // 4-byte-aligned 16-byte access
+struct __attribute__((packed, aligned(4))) U2 { unsigned x, y; };
+
+// ---------------------------------------------------------------------------------------------------------
+// Hit tape.  The detection pass only ever asks of a draw whether `rand() <= detect_prob`, so the 312 draws (word
+// pairs) of an MT19937 row that has been twisted ahead of its cursor boil down to 312 bits.  cs_mt_advance (the pre-pass
+// of the rollout kernels) writes them next to the row (cs_layout.tape_off); the rollout kernels keep the tape of an env
+// in ten registers, read draw r as bit r and shift the tape by the number of draws a step consumed: no MT19937 word
+// is loaded, mixed or tempered inside their loops.  Resets, which need the uniforms themselves, read the twisted words.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int TAPE_DW = 10;        // 320 hit bits >= the 312 draw slots (word pairs) of one MT19937 row
+constexpr int TAPE_STRIDE = CS_TAPE_STRIDE;  // dwords per env: 10 of bits | base lo, hi | K lo, hi | 2 unused
+
+// np.random.rand() <= detect_prob for the draw made of stream words (wa, wb), exactly, in integers
+__device__ __forceinline__ bool draw_hits(const DevParams &p, unsigned wa, unsigned wb) {
+    const unsigned long long u = ((unsigned long long)(mt_temper(wa) >> 5) << 26) | (unsigned long long)(mt_temper(wb) >> 6);
+    return u <= p.detect_K;
+}
+
+// The hit tape of one lane: bit r = "draw slot r from the cursor hits".  Shift by n slots (n < 320), dword barrel first.
+template <int MAX_DW>
+__device__ __forceinline__ void tape_shift(unsigned (&t)[TAPE_DW], int n) {
+    const int dw = n >> 5, bit = n & 31;
+#pragma unroll
+    for (int st = 1; st <= MAX_DW; st <<= 1) {
+#pragma unroll
+        for (int k = 0; k < TAPE_DW; k++) {
+            const unsigned from = k + st < TAPE_DW ? t[k + st] : 0u;
+            t[k] = (dw & st) ? from : t[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < TAPE_DW; k++)
+        t[k] = __builtin_amdgcn_alignbit(k + 1 < TAPE_DW ? t[k + 1] : 0u, t[k], (unsigned)bit);
+}
+
+// An env's hit tape from the state blob, shifted to the env's cursor; returns false when the stored tape does not
+// describe the words twisted ahead of this cursor (never built, other detect_prob, ...): the caller rebuilds it.
+template <class EnvT>
+__device__ __forceinline__ bool tape_load(const DevParams &p, int b, const EnvT &e, unsigned (&tape)[TAPE_DW]) {
+    const U4 *tp = reinterpret_cast<const U4 *>(p.tape + (size_t)b * TAPE_STRIDE);
+    const U4 t0 = tp[0], t1 = tp[1], t2 = tp[2], t3 = tp[3];
+    tape[0] = t0.x; tape[1] = t0.y; tape[2] = t0.z; tape[3] = t0.w;
+    tape[4] = t1.x; tape[5] = t1.y; tape[6] = t1.z; tape[7] = t1.w;
+    tape[8] = t2.x; tape[9] = t2.y;
+    const unsigned long long base = (unsigned long long)t2.z | ((unsigned long long)t2.w << 32);
+    const unsigned long long K = (unsigned long long)t3.x | ((unsigned long long)t3.y << 32);
+    const unsigned long long used = e.words - base;   // words consumed since the tape was written
+    const bool ok = K == p.detect_K && e.words >= base && used + (unsigned long long)e.ahead <= (unsigned long long)MT_N;
+    tape_shift<8>(tape, ok ? (int)(used >> 1) : 0);
+    return ok;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Correctly rounded sin/cos of an accumulated heading (see gen_trig_table.py).  T points at the LDS copy.
 // ---------------------------------------------------------------------------------------------------------
@@ -189,8 +242,6 @@ __device__ __forceinline__ void norm_target(const DevParams &p, Env<N> &e) {
 }
 
 // The group's window into the circular MT19937 state: lane l holds words pos+l and pos+397+l.
-struct __attribute__((packed, aligned(4))) U4 { unsigned x, y, z, w; };  // 4-byte-aligned 16-byte access
-struct __attribute__((packed, aligned(4))) U2 { unsigned x, y; };
 
 struct MtWin {
     unsigned cur, far;
@@ -275,6 +326,9 @@ __device__ __forceinline__ void env_store(const DevParams &p, int b, int t, cons
 // coalesced store.  Ranks >= 7 (more than 7 pairs in range at once) take the direct-load path.
 // ---------------------------------------------------------------------------------------------------------
 template <int N>
+__device__ __forceinline__ int detect_finish(const DevParams &p, int t, int gshift, Env<N> &e, bool hit);
+
+template <int N>
 __device__ __forceinline__ int detect_pass(const DevParams &p, int b, int t, int gshift, Env<N> &e, MtWin win) {
     const bool is_tgt = t < p.n_targets;
     unsigned *mt = p.mt + (size_t)b * MT_STRIDE;
@@ -347,7 +401,12 @@ __device__ __forceinline__ int detect_pass(const DevParams &p, int b, int t, int
     e.mt_pos = wrap624(e.mt_pos + 2 * base);
     e.words += (unsigned long long)(2 * base);
     e.ahead = e.ahead > 2 * base ? e.ahead - 2 * base : 0;
+    return detect_finish<N>(p, t, gshift, e, hit);
+}
 
+// Second half of a detection pass: `hit` = this lane's target was detected by some agent (flight_env_easy.py:238-247).
+template <int N>
+__device__ __forceinline__ int detect_finish(const DevParams &p, int t, int gshift, Env<N> &e, bool hit) {
     bool lane_new = hit && !((e.found >> t) & 1u);
     unsigned newly = (unsigned)((__ballot(lane_new) >> gshift) & 0xffffull);
     int cnt = __popc(newly);
@@ -364,6 +423,48 @@ __device__ __forceinline__ int detect_pass(const DevParams &p, int b, int t, int
     e.curr_reward = r;
     e.flags |= FLAG_DIRTY;
     return r;
+}
+
+// Detection pass of the rollout kernels: same contract as detect_pass, draws read from the env's hit tape (replicated
+// in the 16 lanes of the group).  The pair of rank r takes draw slot r, i.e. bit r of the tape; afterwards the tape
+// is shifted by the number of draws.  When the tape does not cover the pass (no pre-pass ran, or the env has drawn more
+// than a row's worth since), the pass runs the on-demand path above on a freshly loaded window.
+template <int N>
+__device__ __forceinline__ int detect_pass_tape(const DevParams &p, int b, int t, int gshift, Env<N> &e,
+                                                unsigned (&tape)[TAPE_DW], bool tape_ok) {
+    constexpr int MAXDW = (N * CS_MAX_TARGETS) / 32 < 1 ? 1 : (N * CS_MAX_TARGETS) / 32;   // draws of one pass, in dwords
+    const bool is_tgt = t < p.n_targets;
+    bool inr[N];
+    int rank[N];
+    int base = 0;
+    const unsigned below = (1u << t) - 1u;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        double ddx = e.tx - e.ax[i], ddy = e.ty - e.ay[i];
+        inr[i] = is_tgt && (ddx * ddx + ddy * ddy <= p.view_r2);  // (t_x-x)**2 + (t_y-y)**2 <= view_range**2
+        unsigned gm = (unsigned)((__ballot(inr[i]) >> gshift) & 0xffffull);
+        rank[i] = base + __popc(gm & below);  // agent-major order of the reference's double loop
+        base += __popc(gm);
+    }
+    if (!(tape_ok && 2 * base <= e.ahead)) {   // group-uniform
+        const int r = detect_pass<N>(p, b, t, gshift, e, mt_prefetch(p.mt + (size_t)b * MT_STRIDE, e.mt_pos, t));
+        drain_vmem();
+        tape_shift<MAXDW>(tape, base);
+        return r;
+    }
+    bool hit = false;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        unsigned w = tape[0];
+#pragma unroll
+        for (int d = 1; d < (N * CS_MAX_TARGETS + 31) / 32; d++) w = (rank[i] >> 5) == d ? tape[d] : w;
+        hit = hit || (inr[i] && ((w >> (rank[i] & 31)) & 1u));
+    }
+    e.mt_pos = wrap624(e.mt_pos + 2 * base);
+    e.words += (unsigned long long)(2 * base);
+    e.ahead -= 2 * base;
+    tape_shift<MAXDW>(tape, base);
+    return detect_finish<N>(p, t, gshift, e, hit);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -696,7 +797,9 @@ __device__ unsigned long long g_stamps[64][16];
 #define CS_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && g_tl_step >= 0 && g_tl_step < 64) g_stamps[g_tl_step][k] = __builtin_readcyclecounter(); } while (0)
 __device__ int g_tl_step_dummy;
 #define LANE_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && s < 64) g_stamps[s][k] = __builtin_readcyclecounter(); } while (0)
+#define DUO_STAMP(k) do { if (blockIdx.x == 0 && (threadIdx.x & 255) == 0 && s < 64) g_stamps[s][k] = __builtin_readcyclecounter(); } while (0)
 #else
+#define DUO_STAMP(k) do {} while (0)
 #define CS_STAMP(k) do {} while (0)
 #define LANE_STAMP(k) do {} while (0)
 #endif
@@ -762,12 +865,18 @@ template <int N>
 __device__ __forceinline__ void emit_deposit(const DevParams &p, WaveTile &tile, int t, int grp, bool live, const Env<N> &e,
                                              int reward, bool term) {
     if (live) {
+        // lane i < N deposits agent i: picked with selects (an indexed read would put the arrays in scratch)
+        double mx = 0.0, my = 0.0, mc = 0.0, ms = 0.0;
 #pragma unroll
-        for (int i = 0; i < N; i++)
-            if (t == i)
-                *reinterpret_cast<float4 *>(&tile.row[grp][4 * i]) =
-                    make_float4((float)((e.ax[i] - p.mid) * p.inv_half), (float)((e.ay[i] - p.mid) * p.inv_half),
-                                (float)e.cs[i], (float)e.sn[i]);
+        for (int i = 0; i < N; i++) {
+            mx = t == i ? e.ax[i] : mx;
+            my = t == i ? e.ay[i] : my;
+            mc = t == i ? e.cs[i] : mc;
+            ms = t == i ? e.sn[i] : ms;
+        }
+        if (t < N)
+            *reinterpret_cast<float4 *>(&tile.row[grp][4 * t]) =
+                make_float4((float)((mx - p.mid) * p.inv_half), (float)((my - p.mid) * p.inv_half), (float)mc, (float)ms);
         if (t < p.n_targets) {
             tile.row[grp][4 * N + 3 * t + 0] = e.ntx;
             tile.row[grp][4 * N + 3 * t + 1] = e.nty;
@@ -826,7 +935,8 @@ template <int N, int VARIANT>
 __device__ __forceinline__ void step_once(const DevParams &p, const double *T, const StepIO &io, WaveTile &tile, int b,
                                           int lane, size_t slot0, const EmitPlan<N> &plan, bool live, const int (&act)[N],
                                           MtWin &win, bool prefetch_next, bool flush_prev, size_t prev_slot0,
-                                          bool defer_flush, Env<N> &e) {
+                                          bool defer_flush, Env<N> &e, unsigned (*tape)[TAPE_DW] = nullptr,
+                                          bool tape_ok = false) {
     const int t = lane & (G - 1), grp = lane >> 4, gshift = lane & ~(G - 1);
     int reward = 0;
     bool term = true;
@@ -841,13 +951,19 @@ __device__ __forceinline__ void step_once(const DevParams &p, const double *T, c
         bool done = e.target_find >= p.n_targets || e.time_step >= p.time_limit;
         e.flags &= ~(FLAG_DIRTY | FLAG_RESET_PASS);  // pending-map-update flags describe THIS launch only
         if (done && (io.flags & CS_AUTO_RESET)) {
+            const unsigned long long words_before = e.words;
             env_reset<N>(p, T, b, t, gshift, 0, e);
             if (VARIANT == 1) {  // flight: the map kernel must replay the reset-time update before this step's
                 e.newly_reset = e.newly;
                 e.flags |= FLAG_RESET_PASS;
             }
             env_store<N>(p, b, t, e, true);  // targets changed
-            win = mt_prefetch(p.mt + (size_t)b * MT_STRIDE, e.mt_pos, t);
+            if (tape) {   // the draw slots the reset consumed leave the tape
+                const unsigned long long used = e.words - words_before;
+                tape_shift<8>(*tape, used < 2ull * 319ull ? (int)(used >> 1) : 319);
+            } else {
+                win = mt_prefetch(p.mt + (size_t)b * MT_STRIDE, e.mt_pos, t);
+            }
             drain_vmem();
             done = false;
         }
@@ -855,7 +971,7 @@ __device__ __forceinline__ void step_once(const DevParams &p, const double *T, c
             CS_STAMP(1);
             kinematics_group<N, VARIANT>(p, T, tile, act, t, grp, e);
             CS_STAMP(2);
-            reward = detect_pass<N>(p, b, t, gshift, e, win);
+            reward = tape ? detect_pass_tape<N>(p, b, t, gshift, e, *tape, tape_ok) : detect_pass<N>(p, b, t, gshift, e, win);
             CS_STAMP(3);
             e.total_reward += reward;
             e.time_step += 1;
@@ -864,7 +980,7 @@ __device__ __forceinline__ void step_once(const DevParams &p, const double *T, c
             env_trig<N>(T, e);  // frozen env: re-emit the unchanged observation
         }
         // the next step's window does not overlap the words just committed: request it before this step's stores
-        if (prefetch_next) win = mt_prefetch(p.mt + (size_t)b * MT_STRIDE, e.mt_pos, t);
+        if (prefetch_next && !tape) win = mt_prefetch(p.mt + (size_t)b * MT_STRIDE, e.mt_pos, t);
     }
     CS_STAMP(4);
     if (flush_prev) emit_flush_store<N>(p, io, plan, fr, prev_slot0);
@@ -926,14 +1042,20 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(DevParams p, StepIO io) {
     const EmitPlan<N> plan = make_emit_plan<N>(p, lane, nvalid);
     constexpr bool PIPE = N <= 4;
     MtWin win = {0u, 0u};
-    if (live) win = mt_prefetch(p.mt + (size_t)b * MT_STRIDE, e.mt_pos, t);
+    // the env's hit tape (cs_mt_advance), replicated in the group's lanes; teams of 5 and more keep the on-demand
+    // window instead: the ten tape registers would cost them their second wavefront per SIMD
+    constexpr bool USE_TAPE = N <= 4;
+    unsigned tape[TAPE_DW];
+    bool tape_ok = false;
+    if (USE_TAPE && live) tape_ok = tape_load(p, b, e, tape);
+    if (!USE_TAPE && live) win = mt_prefetch(p.mt + (size_t)b * MT_STRIDE, e.mt_pos, t);
     for (int s = 0; s < io.T; s++) {
         int act_next[N];
         const int sn = s + 1 < io.T ? s + 1 : s;
         load_actions<N>(io, (size_t)sn * p.B + (live ? b : 0), act_next);
         // n <= 4: the rows of step s are stored while step s+1 computes (costs ~12 VGPRs; larger teams have none spare)
         step_once<N, 0>(p, T, io, tile, b, lane, (size_t)s * p.B + wave_b0, plan, live, act, win, s + 1 < io.T,
-                        PIPE && s > 0, (size_t)(s - 1) * p.B + wave_b0, PIPE, e);
+                        PIPE && s > 0, (size_t)(s - 1) * p.B + wave_b0, PIPE, e, USE_TAPE ? &tape : nullptr, tape_ok);
 #pragma unroll
         for (int i = 0; i < N; i++) act[i] = act_next[i];
     }
@@ -943,6 +1065,230 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(DevParams p, StepIO io) {
         emit_flush_store<N>(p, io, plan, fr, (size_t)(io.T - 1) * p.B + wave_b0);
     }
     if (live) env_store<N>(p, b, t, e, false);
+}
+
+// =========================================================================================================
+// Two-role rollout (flight_easy): the default T-step kernel of the 16-lanes-per-env path.
+//
+// One env.step is a dependent chain -- kinematics (trig lookup, move, wall test), then the detection pass over the
+// new positions, reward, emission -- of ~6000 cycles on one wavefront, and at the batch sizes this path serves
+// (B = 4096: one wavefront per SIMD) nothing else is there to fill its stalls.  But the kinematics of step s + 1
+// need nothing from the detection pass of step s: the actions are an open-loop table, and the only coupling is
+// termination (auto-reset / freeze), which is predictable from the step counter except when an env finds its last
+// target.  So every group of four envs gets TWO wavefronts: wave K runs the kinematics of step s + 1 while its
+// partner wave D runs detection + reward + emission of step s on the positions K left in a two-slot LDS ring; one
+// workgroup barrier per step.  When D sees a termination K could not predict (a win before the time limit) it
+// flags the group, and after the barrier K restores that env from the ring, applies the reset / freeze and redoes
+// the step (one extra barrier, a few times per episode batch).  Arithmetic per env is exactly k_rollout's (same
+// functions), so results are bit-identical; the step time drops from kinematics + detection + emission to
+// max(kinematics, detection + emission), and B = 4096 fills both wave slots of every SIMD.
+// =========================================================================================================
+template <int N>
+struct KinSlot {   // agents of one env after a step: K -> D
+    double x[N], y[N], yaw[N];
+    float cs[N], sn[N];
+    unsigned out;   // out_flag bits (OUT_PUNISH)
+    int pad;
+};
+
+constexpr int DUO_BLOCK = 512;   // 4 K wavefronts + 4 D wavefronts, 16 envs
+
+template <int N>
+__global__ __launch_bounds__(DUO_BLOCK) void k_rollout_duo(DevParams p, StepIO io) {
+    __shared__ double T[TRIG_ROWS * TRIG_COLS];
+    __shared__ WaveTile tiles[DUO_BLOCK / 64];   // K waves use .trig, D waves the emission rows
+    __shared__ KinSlot<N> slots[2][16];
+    __shared__ unsigned fix[2][4];               // [step parity][pair]: groups whose termination K mispredicted
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool is_k = wave < 4;
+    const int pw = wave & 3;                     // wave pair = 4 envs
+    const int t = lane & (G - 1), grp = lane >> 4, gshift = lane & ~(G - 1);
+    const int el = 4 * pw + grp;                 // env within the block
+    const int b = blockIdx.x * 16 + el;
+    const bool live = b < p.B;
+    const int wave_b0 = blockIdx.x * 16 + 4 * pw;
+    const int nvalid = p.B - wave_b0 < 4 ? p.B - wave_b0 : 4;   // <= 0: a pair without envs (it still meets the barriers)
+    const bool auto_reset = io.flags & CS_AUTO_RESET, freeze = io.flags & CS_FREEZE_DONE;
+    Env<N> e;
+    if (live) env_load<N>(p, b, t, e);
+    load_trig_to_lds(T);
+    WaveTile &tile = tiles[wave];
+    const size_t arow = live ? (size_t)b : 0;
+
+    if (is_k) {
+        // ------------------------------------------------------------------------------------------ K: kinematics
+        int act[N], act_next[N];
+        load_actions<N>(io, arow, act);
+        bool k_done = live && (e.target_find >= p.n_targets || e.time_step >= p.time_limit);   // exact at launch
+        int k_time = e.time_step;
+        if (live) env_trig<N>(T, e);   // what a frozen env keeps emitting
+        // produces the state after step `sp` from the state after step sp - 1 and writes it to the ring
+        auto produce = [&](int sp, const int (&a)[N]) __attribute__((always_inline)) {
+            if (live) {
+                bool frozen = false;
+                if (k_done && auto_reset) {
+#pragma unroll
+                    for (int i = 0; i < N; i++) {
+                        start_pose<N>(p, i, e.ax[i], e.ay[i], e.yaw[i]);
+                        trig_heading(T, e.yaw[i], e.sn[i], e.cs[i]);
+                    }
+                    e.flags &= ~0xff00;
+                    k_time = 0;
+                    k_done = false;
+                } else if (k_done && freeze) {
+                    frozen = true;
+                }
+                if (!frozen) {
+                    kinematics_group<N, 0>(p, T, tile, a, t, grp, e);
+                    k_time += 1;
+                    k_done = k_time >= p.time_limit;   // a win is D's knowledge: see the fix-up below
+                }
+                KinSlot<N> &sl = slots[sp & 1][el];
+                double mx = 0.0, my = 0.0, mw = 0.0, mc = 0.0, ms = 0.0;   // lane i < N publishes agent i
+#pragma unroll
+                for (int i = 0; i < N; i++) {
+                    mx = t == i ? e.ax[i] : mx;
+                    my = t == i ? e.ay[i] : my;
+                    mw = t == i ? e.yaw[i] : mw;
+                    mc = t == i ? e.cs[i] : mc;
+                    ms = t == i ? e.sn[i] : ms;
+                }
+                if (t < N) {
+                    sl.x[t] = mx;
+                    sl.y[t] = my;
+                    sl.yaw[t] = mw;
+                    sl.cs[t] = (float)mc;
+                    sl.sn[t] = (float)ms;
+                }
+                if (t == 0) sl.out = ((unsigned)e.flags >> 8) & 0xffu;
+            }
+        };
+        load_actions<N>(io, (size_t)(1 < io.T ? 1 : 0) * p.B + arow, act_next);   // one step ahead of its use
+        produce(0, act);
+        __syncthreads();
+        for (int s = 0; s < io.T; s++) {
+            const bool more = s + 1 < io.T;
+            int act_after[N];
+            DUO_STAMP(0);
+            load_actions<N>(io, (size_t)(s + 2 < io.T ? s + 2 : io.T - 1) * p.B + arow, act_after);
+            if (more) produce(s + 1, act_next);
+            DUO_STAMP(1);
+            __syncthreads();
+            DUO_STAMP(2);
+            const unsigned f0 = fix[s & 1][0], f1 = fix[s & 1][1], f2 = fix[s & 1][2], f3 = fix[s & 1][3];
+            if (f0 | f1 | f2 | f3) {   // block-uniform, rare: an env of the block terminated by finding its last target
+                const unsigned mine = pw == 0 ? f0 : (pw == 1 ? f1 : (pw == 2 ? f2 : f3));
+                if (more && live && ((mine >> grp) & 1u)) {
+                    const KinSlot<N> &sl = slots[s & 1][el];   // the env as it was after step s
+#pragma unroll
+                    for (int i = 0; i < N; i++) {
+                        e.ax[i] = sl.x[i];
+                        e.ay[i] = sl.y[i];
+                        e.yaw[i] = sl.yaw[i];
+                    }
+                    env_trig<N>(T, e);
+                    e.flags = (e.flags & ~0xff00) | (int)(sl.out << 8);
+                    k_done = true;
+                    k_time -= 1;           // the speculative step s + 1 is undone (a frozen env never gets here)
+                    produce(s + 1, act_next);
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int i = 0; i < N; i++) act_next[i] = act_after[i];
+        }
+        if (live) {   // agents are K's part of the state
+            double4 *a4 = reinterpret_cast<double4 *>(p.agent + (size_t)b * CS_MAX_AGENTS * 4);
+#pragma unroll
+            for (int i = 0; i < N; i++)
+                if (t == i) a4[i] = make_double4(e.ax[i], e.ay[i], e.yaw[i], 0.0);
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------------------------------- D: detection
+    const bool wave_valid = nvalid > 0;
+    const EmitPlan<N> plan = make_emit_plan<N>(p, lane, wave_valid ? nvalid : 1);
+    constexpr bool PIPE = N <= 4;
+    unsigned tape[TAPE_DW];   // the env's hit tape (cs_mt_advance), replicated in the group's lanes
+    bool tape_ok = false;
+    if (live) tape_ok = tape_load(p, b, e, tape);
+    if (threadIdx.x == 4 * 64) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) (&fix[0][0])[q] = 0u;
+    }
+    __syncthreads();   // the ring holds step 0
+    for (int s = 0; s < io.T; s++) {
+        const size_t slot0 = (size_t)s * p.B + wave_b0;
+        int reward = 0;
+        bool term = true, mispredicted = false;
+        FlushRegs<N> fr;
+        DUO_STAMP(8);
+        if (PIPE && s > 0 && wave_valid) emit_flush_load<N>(tile, plan, fr);
+        if (live) {
+            bool done = e.target_find >= p.n_targets || e.time_step >= p.time_limit;
+            e.flags &= ~(FLAG_DIRTY | FLAG_RESET_PASS);
+            if (done && auto_reset) {
+                const unsigned long long words_before = e.words;
+                env_reset<N>(p, T, b, t, gshift, 0, e);
+                reinterpret_cast<double2 *>(p.tgt + (size_t)b * G * 2)[t] = make_double2(e.tx, e.ty);
+                const unsigned long long used = e.words - words_before;   // its draw slots leave the tape
+                tape_shift<8>(tape, used < 2ull * 319ull ? (int)(used >> 1) : 319);
+                drain_vmem();
+                done = false;
+            }
+            const KinSlot<N> &sl = slots[s & 1][el];
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                e.ax[i] = sl.x[i];
+                e.ay[i] = sl.y[i];
+                e.yaw[i] = sl.yaw[i];
+                e.cs[i] = (double)sl.cs[i];
+                e.sn[i] = (double)sl.sn[i];
+            }
+            e.flags = (e.flags & ~0xff00) | (int)(sl.out << 8);
+            DUO_STAMP(9);
+            if (!(done && freeze)) {
+                reward = detect_pass_tape<N>(p, b, t, gshift, e, tape, tape_ok);
+                DUO_STAMP(10);
+                e.total_reward += reward;
+                e.time_step += 1;
+                term = e.target_find >= p.n_targets || e.time_step >= p.time_limit;
+                // K steps on unless the step counter says otherwise
+                mispredicted = (auto_reset || freeze) && term && e.time_step < p.time_limit;
+            }
+        }
+        {
+            const unsigned long long mb = __ballot(mispredicted && t == 0);
+            const unsigned m4 = (unsigned)((mb >> 0) & 1ull) | (unsigned)((mb >> 15) & 2ull) | (unsigned)((mb >> 30) & 4ull) |
+                                (unsigned)((mb >> 45) & 8ull);
+            if (lane == 0) fix[s & 1][pw] = m4;
+        }
+        if (PIPE && s > 0 && wave_valid) emit_flush_store<N>(p, io, plan, fr, (size_t)(s - 1) * p.B + wave_b0);
+        emit_deposit<N>(p, tile, t, grp, live, e, reward, term);
+        if (!PIPE && wave_valid) {
+            emit_flush_load<N>(tile, plan, fr);
+            emit_flush_store<N>(p, io, plan, fr, slot0);
+        }
+        DUO_STAMP(11);
+        __syncthreads();
+        DUO_STAMP(12);
+        const unsigned f0 = fix[s & 1][0], f1 = fix[s & 1][1], f2 = fix[s & 1][2], f3 = fix[s & 1][3];
+        if (f0 | f1 | f2 | f3) __syncthreads();   // K redoes step s + 1 of the flagged envs
+    }
+    if (PIPE && wave_valid) {
+        FlushRegs<N> fr;
+        emit_flush_load<N>(tile, plan, fr);
+        emit_flush_store<N>(p, io, plan, fr, (size_t)(io.T - 1) * p.B + wave_b0);
+    }
+    if (live && t == 0) {   // header (and cursor) are D's part of the state; targets were stored at each reset
+        int4 *h4 = reinterpret_cast<int4 *>(p.hdr + (size_t)b * CS_H_WORDS);
+        h4[0] = make_int4((int)e.found, (int)e.newly, e.target_find, e.flags);
+        h4[1] = make_int4(e.time_step, e.total_reward, e.mt_pos, e.episodes);
+        h4[2] = make_int4((int)(unsigned)(e.words & 0xffffffffull), (int)(unsigned)(e.words >> 32), e.curr_reward,
+                          (int)e.newly_reset);
+        p.ahead[b] = e.ahead;
+    }
 }
 
 // =========================================================================================================
@@ -1197,8 +1543,6 @@ constexpr int LANE_REFILL_MAX = 192;
 #define CS_LANE_CHUNK 64
 #endif
 constexpr int LANE_CHUNK = CS_LANE_CHUNK;     // steps per launch of the lane kernel: cs_rollout twists every row ahead in between
-constexpr int TAPE_DW = 10;        // 320 hit bits >= the 312 draw slots (word pairs) of one MT19937 row
-constexpr int TAPE_STRIDE = CS_TAPE_STRIDE;  // dwords per env: 10 of bits | base lo, hi | K lo, hi | 2 unused
 
 template <int N>
 struct EnvL {
@@ -1328,29 +1672,6 @@ __device__ __forceinline__ void kinematics_lane(const DevParams &p, const double
     e.flags = (e.flags & ~0xff00) | (int)(out << 8);
 }
 
-// np.random.rand() <= detect_prob for the draw made of stream words (wa, wb), exactly, in integers
-__device__ __forceinline__ bool draw_hits(const DevParams &p, unsigned wa, unsigned wb) {
-    const unsigned long long u = ((unsigned long long)(mt_temper(wa) >> 5) << 26) | (unsigned long long)(mt_temper(wb) >> 6);
-    return u <= p.detect_K;
-}
-
-// The hit tape of one lane: bit r = "draw slot r from the cursor hits".  Shift by n slots (n < 320), dword barrel first.
-template <int MAX_DW>
-__device__ __forceinline__ void tape_shift(unsigned (&t)[TAPE_DW], int n) {
-    const int dw = n >> 5, bit = n & 31;
-#pragma unroll
-    for (int st = 1; st <= MAX_DW; st <<= 1) {
-#pragma unroll
-        for (int k = 0; k < TAPE_DW; k++) {
-            const unsigned from = k + st < TAPE_DW ? t[k + st] : 0u;
-            t[k] = (dw & st) ? from : t[k];
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < TAPE_DW; k++)
-        t[k] = __builtin_amdgcn_alignbit(k + 1 < TAPE_DW ? t[k + 1] : 0u, t[k], (unsigned)bit);
-}
-
 // Fallback of the lane kernel (rare once cs_rollout's pre-pass has run): for every lane whose bit is set in `need`,
 // the whole wavefront twists LANE_REFILL more words of that lane's env (when there is room) and rebuilds the env's hit
 // tape from its cursor -- in the state blob and, through the ballots, in the lane's registers.
@@ -1404,23 +1725,6 @@ __device__ __forceinline__ void lane_rebuild(const DevParams &p, int b0, int lan
     drain_vmem();   // rare path: joins the steady-state path with nothing of its own in flight
 }
 
-// The lane's hit tape from the state blob, shifted to the lane's cursor; returns false when the stored tape does not
-// describe the words twisted ahead of this cursor (never built, other detect_prob, ...): the caller rebuilds it.
-template <int N>
-__device__ __forceinline__ bool tape_load(const DevParams &p, int b, const EnvL<N> &e, unsigned (&tape)[TAPE_DW]) {
-    const U4 *tp = reinterpret_cast<const U4 *>(p.tape + (size_t)b * TAPE_STRIDE);
-    const U4 t0 = tp[0], t1 = tp[1], t2 = tp[2], t3 = tp[3];
-    tape[0] = t0.x; tape[1] = t0.y; tape[2] = t0.z; tape[3] = t0.w;
-    tape[4] = t1.x; tape[5] = t1.y; tape[6] = t1.z; tape[7] = t1.w;
-    tape[8] = t2.x; tape[9] = t2.y;
-    const unsigned long long base = (unsigned long long)t2.z | ((unsigned long long)t2.w << 32);
-    const unsigned long long K = (unsigned long long)t3.x | ((unsigned long long)t3.y << 32);
-    const unsigned long long used = e.words - base;   // words consumed since the tape was written
-    const bool ok = K == p.detect_K && e.words >= base && used + (unsigned long long)e.ahead <= (unsigned long long)MT_N;
-    tape_shift<8>(tape, ok ? (int)(used >> 1) : 0);
-    return ok;
-}
-
 // Ordering inside one step (gfx9 has ONE in-order counter for vector loads and stores: waiting for a load also waits
 // for every store issued before it): the only loads of the steady-state loop -- the next step's actions -- are requested
 // before the step's output stores, and the number of stores between any load and its use is a compile-time constant, so
@@ -1457,7 +1761,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO i
     bool tape_ok = true;
     if (live) {
         envl_load<N>(p, b, T, row, e);
-        tape_ok = tape_load<N>(p, b, e, tape);
+        tape_ok = tape_load(p, b, e, tape);
     } else {
         envl_zero<N>(e);
 #pragma unroll
@@ -1473,7 +1777,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO i
     constexpr int Q = (16 * W_MAX + 63) / 64;   // float4 chunks per lane of the largest tile
     // float4 chunks [q0, q1) of the tile -> rows of step `step`.  Chunk k = min(lane + 64 q, last): surplus lanes repeat
     // the last chunk (same value, same address), so every lane stores every time.
-    auto copy_chunks = [&](int q0, int q1, size_t step) {
+    auto copy_chunks = [&](int q0, int q1, size_t step) __attribute__((always_inline)) {
         const float4 *src4 = reinterpret_cast<const float4 *>(tile);
         float4 *dst4 = reinterpret_cast<float4 *>(io.state + (step * p.B + b0) * W);
         const int last = 16 * W - 1;
@@ -2217,6 +2521,10 @@ inline bool use_lane_kernel(const cs_config *c, int flags) {
     return c->batch >= 32768;
 }
 
+// 16-lanes-per-env rollout: the kinematics / detection wavefront pair wins while the batch leaves a wave slot per SIMD
+// empty (measured: 3 agents, B = 4096: 1.53e9 vs 1.44e9 env-steps/s; B = 16384: 1.69e9 vs 2.37e9)
+inline bool duo_pays(const cs_config *c) { return c->n_agents <= 4 && c->batch <= 6144; }
+
 inline unsigned env_blocks(const DevParams &p) { return (unsigned)(((size_t)p.B * G + BLOCK - 1) / BLOCK); }
 
 #ifdef CS_ONLY_N   // experiments only: instantiate one team size (fast compiles)
@@ -2365,9 +2673,15 @@ int cs_rollout(const cs_config *cfg, void *state_dev, const void *actions_dev, i
                       state_out_dev ? state_out_dev + (size_t)t0 * B * W : nullptr, flags, tc};
             CS_DISPATCH_N(cfg->n_agents, launch_lane<N>(cfg, p, it, lane_smem(cfg), s));
         }
-    } else {
+    } else if ((flags & CS_KERNEL_SOLO) || ((flags & CS_KERNEL_DUO) == 0 && !duo_pays(cfg))) {
+        if (T >= 8 && cfg->n_agents <= 4)
+            hipLaunchKernelGGL(k_mt_advance, dim3((unsigned)((p.B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, MT_N - 64);
         CS_DISPATCH_N(cfg->n_agents,
                       hipLaunchKernelGGL(k_rollout<N>, dim3(env_blocks(p)), dim3(BLOCK), 0, (hipStream_t)stream, p, io));
+    } else {
+        if (T >= 8) hipLaunchKernelGGL(k_mt_advance, dim3((unsigned)((p.B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, MT_N - 64);
+        CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_rollout_duo<N>, dim3((unsigned)((p.B + 15) / 16)), dim3(DUO_BLOCK),
+                                                        0, (hipStream_t)stream, p, io));
     }
     return launched("cs_rollout");
 }

@@ -60,9 +60,11 @@ class BatchedFlightEnv:
     freeze_done terminated envs ignore step() (reward 0, terminated 1); False reproduces the reference, which has
                 no terminal guard
     auto_reset  terminated envs are reset(init=False) at the start of the next step()
-    kernel      flight_easy only: "group" (16 lanes per env: lowest step latency, fills the chip from B = 4096),
-                "lane" (one env per lane: no replicated arithmetic, for large batches) or "auto" (lane from
-                B >= 32768).  Both produce bit-identical results.
+    kernel      flight_easy only: "group" (16 lanes per env: lowest step latency, fills the chip from B = 4096; its
+                rollout picks between "solo" -- one wavefront per four envs does the whole step -- and "duo" -- a
+                kinematics wavefront and a detection wavefront per four envs, for batches that leave a wave slot per
+                SIMD empty), "lane" (one env per lane: no replicated arithmetic, for large batches) or "auto" (lane
+                from B >= 32768).  All produce bit-identical results.
     """
 
     def __init__(self, args, circle_dict=None, batch=1, device="cuda", seeds=None, env_offset=0, freeze_done=True,
@@ -116,8 +118,8 @@ class BatchedFlightEnv:
             self._state = torch.zeros(B, self.state_shape, dtype=torch.float32, device=self.device)
             self._avail = torch.ones(B, self.n_actions, dtype=torch.float32, device=self.device)
             self._metrics = torch.zeros(4, dtype=torch.float64, device=self.device)
-        if kernel not in ("auto", "group", "lane"):
-            raise ValueError("kernel must be 'auto', 'group' or 'lane'")
+        if kernel not in ("auto", "group", "lane", "solo", "duo"):
+            raise ValueError("kernel must be 'auto', 'group', 'lane', 'solo' or 'duo'")
         self.kernel = kernel
         self.freeze_done = bool(freeze_done)
         self.auto_reset = bool(auto_reset)
@@ -211,6 +213,10 @@ class BatchedFlightEnv:
             f |= _lib.ACTIONS_I64
         if self.kernel == "group":
             f |= _lib.KERNEL_GROUP
+        elif self.kernel == "solo":
+            f |= _lib.KERNEL_GROUP | _lib.KERNEL_SOLO
+        elif self.kernel == "duo":
+            f |= _lib.KERNEL_GROUP | _lib.KERNEL_DUO
         elif self.kernel == "lane":
             f |= _lib.KERNEL_LANE
         return f

@@ -49,7 +49,10 @@ enum {
     CS_AUTO_RESET = 2,   /* an env that was terminated on entry is reset(init=False) first, then stepped */
     CS_ACTIONS_I64 = 4,  /* actions_dev holds int64 (torch.long) instead of int32 */
     CS_KERNEL_GROUP = 8, /* flight_easy: force the 16-lanes-per-env kernels (default for batch < 32768) */
-    CS_KERNEL_LANE = 16  /* flight_easy: force the lane-per-env kernel   (default for batch >= 32768); same results */
+    CS_KERNEL_LANE = 16, /* flight_easy: force the lane-per-env kernel   (default for batch >= 32768); same results */
+    CS_KERNEL_SOLO = 32, /* cs_rollout, 16-lanes-per-env path: one wavefront per four envs does the whole step */
+    CS_KERNEL_DUO = 64   /* ... a kinematics wavefront and a detection wavefront per four envs (default up to 6144 envs
+                            of at most 4 agents, where the batch leaves a wave slot per SIMD empty); same results */
 };
 
 /* Environment constants: common/arguments.py:27-34 (map_size, target_num, target_mode, agent_mode, n_agents,

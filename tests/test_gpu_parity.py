@@ -142,7 +142,7 @@ def compare_with_oracle(env, ob, B, n, m, tag, check_pos=True):
             np.testing.assert_allclose(tg[b], tp, rtol=0, atol=1e-12, err_msg=f"{tag} env {b} targets")
 
 
-@pytest.mark.parametrize("kernel", ["group", "lane"])
+@pytest.mark.parametrize("kernel", ["group", "solo", "duo", "lane"])
 @pytest.mark.parametrize("variant,n,agent_mode,target_mode,B,T", [
     ("flight_easy", 3, 0, 0, 512, 200),
     ("flight_easy", 5, 0, 0, 256, 200),
@@ -179,7 +179,7 @@ def test_batched_step_matches_oracle_bit_exact(variant, n, agent_mode, target_mo
                 compare_with_oracle(env, ob, B, n, m, f"step {t}")
 
 
-@pytest.mark.parametrize("kernel", ["group", "lane"])
+@pytest.mark.parametrize("kernel", ["group", "solo", "duo", "lane"])
 def test_auto_reset_and_unfrozen_modes_match_oracle(kernel):
     B, n, m, T = 128, 5, 15, 420   # > 2 episodes per env
     seeds = np.arange(B, dtype=np.uint32) + 5
@@ -271,7 +271,7 @@ def test_flight_fused_auto_reset_matches_oracle(n, agent_mode):
         assert hdr(env)[:, _lib.H_EPISODES].min() >= 4
 
 
-@pytest.mark.parametrize("kernel", ["group", "lane"])
+@pytest.mark.parametrize("kernel", ["group", "solo", "duo", "lane"])
 def test_rollout_kernel_equals_stepwise(kernel):
     B, n, T = 1000, 3, 200   # not a multiple of 64: exercises the partial last wavefront
     args = cs.make_env_args("flight_easy", n_agents=n)
@@ -396,7 +396,7 @@ def _custom_args(variant, **kw):
     return args
 
 
-@pytest.mark.parametrize("kernel", ["group", "lane"])
+@pytest.mark.parametrize("kernel", ["group", "solo", "duo", "lane"])
 @pytest.mark.parametrize("variant,kw", [
     ("flight_easy", dict(n_agents=8, target_num=16, target_mode=1)),             # maximum sizes: 8 x 16 pairs, 2-phase draws
     ("flight_easy", dict(n_agents=7, target_num=16, target_mode=1, view_range=30)),  # nearly every pair in range: > 7 draws/step
@@ -554,7 +554,7 @@ def test_flight_rollout_call_equals_stepwise():
         assert torch.equal(r1[k], r2[k]), k
 
 
-@pytest.mark.parametrize("kernel", ["group", "lane"])
+@pytest.mark.parametrize("kernel", ["group", "solo", "duo", "lane"])
 def test_long_horizon_matches_oracle(kernel):
     """20 000 steps per env with auto-reset: ~100+ episodes, the circular MT19937 state wraps ~70 times (cursor,
     mirrored head, reset-time batches landing anywhere in the ring).  Rewards are compared every step (in rollout
