@@ -12,6 +12,7 @@ H_WORDS = 16
 # header word indices (enum CS_H_* in coopsearch.h)
 H_FOUND, H_NEWLY, H_TARGET_FIND, H_FLAGS, H_TIME_STEP, H_TOTAL_REWARD, H_MT_POS, H_EPISODES = range(8)
 H_WORDS_LO, H_WORDS_HI, H_CURR_REWARD, H_NEWLY_RESET = 8, 9, 10, 11
+SELECT_SOFTMAX, SELECT_SAMPLE = 1, 2
 FREEZE_DONE, AUTO_RESET, ACTIONS_I64, KERNEL_GROUP, KERNEL_LANE, KERNEL_SOLO, KERNEL_DUO = 1, 2, 4, 8, 16, 32, 64
 
 EXPORTS = ["cs_abi_version", "cs_last_error", "cs_state_layout", "cs_init", "cs_seed", "cs_reset", "cs_step",
@@ -79,7 +80,7 @@ def load():
     L.cs_step.argtypes = [C.POINTER(CsConfig), vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.cs_rollout.argtypes = [C.POINTER(CsConfig), vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
     L.cs_rollout_policy.argtypes = [C.POINTER(CsConfig), vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32,
-                                    vp, vp, vp, vp, vp, vp, vp]
+                                    C.c_uint64, C.c_int, vp, vp, vp, vp, vp, vp, vp]
     L.cs_emit.argtypes = [C.POINTER(CsConfig), vp, vp, vp, vp]
     L.cs_metrics.argtypes = [C.POINTER(CsConfig), vp, vp, vp]
     L.cs_mt_canonical.argtypes = [C.POINTER(CsConfig), vp, vp, vp]
@@ -90,7 +91,7 @@ def load():
     L.cs_store_episodes.argtypes = [C.c_int] * 6 + [vp] * 6 + [C.POINTER(CsEpisodeOut), vp]
     L.cs_policy_pack.argtypes = [vp] * 10 + [C.c_int, C.c_int, vp]
     L.cs_policy_forward.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int,
-                                    C.c_float, C.c_uint64, C.c_uint32, vp]
+                                    C.c_float, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, vp]
     L.cs_policy_conv_features.argtypes = [vp] * 7 + [C.c_int64, C.c_int, vp, vp]
     for name in EXPORTS:
         fn = getattr(L, name)

@@ -109,7 +109,10 @@ class FusedAgents:
     CONV_HYPER = dict(map_size=50, dim_1=4, kernel_size_1=4, stride_1=2, dim_2=1, kernel_size_2=3, stride_2=1, padding_2=1,
                       conv_out_dim=16)
 
-    def __init__(self, args, batch, device="cuda", net=None, seed=0):
+    def __init__(self, args, batch, device="cuda", net=None, seed=0, env_offset=0):
+        """env_offset: global index of this shard's env 0 -- the exploration noise is keyed by the GLOBAL (env, agent)
+        row, so a sharded batch picks the same actions as the whole one.  args.alg == 'reinforce' selects the softmax
+        rule of agent/agent.py:77-97 instead of argmax / epsilon-greedy (:68-75)."""
         import ctypes as C
 
         from . import _lib
@@ -129,6 +132,8 @@ class FusedAgents:
         self.rows = self.batch * self.n_agents
         self.net = (net or AgentRNN(rnn_input_shape(args), args)).to(self.device)
         self.seed, self.calls = int(seed), 0
+        self.row0 = int(env_offset) * self.n_agents
+        self.softmax = getattr(args, "alg", None) == "reinforce"
         self.hidden = torch.zeros(self.rows, 64, device=self.device)
         # previous action on entry (-1 = none), chosen action on return: the kernel updates it in place
         self.actions = torch.full((self.batch, self.n_agents), -1, dtype=torch.int64, device=self.device)
@@ -170,6 +175,15 @@ class FusedAgents:
         self.hidden.zero_()
         self.actions.fill_(-1)
 
+    def selection(self, epsilon, evaluate):
+        """(epsilon, CS_SELECT_* flags) of one choose_action call.  argmax rule (agent.py:68-75): greedy when evaluating.
+        Softmax rule (:77-97): epsilon always enters prob; the draw is replaced by argmax only if epsilon == 0 and
+        evaluate."""
+        if not self.softmax:
+            return (0.0 if evaluate else float(epsilon)), 0
+        sample = not (float(epsilon) == 0.0 and evaluate)
+        return float(epsilon), self._lib.SELECT_SOFTMAX | (self._lib.SELECT_SAMPLE if sample else 0)
+
     def choose_action(self, obs, epsilon=0.0, evaluate=False, want_q=False, last=None, out=None):
         """obs: float32 [B, n, obs_shape] device tensor, contiguous (the env's live obs buffer works directly).
         Returns the int64 [B, n] action buffer (overwritten by the next call); it is also remembered as the
@@ -189,11 +203,11 @@ class FusedAgents:
         vp = lambda t: C.c_void_p(t.data_ptr())
         if self.conv:  # the map of an env's first row stands for all its rows (flight_env.py:223-230)
             self._conv_features(obs, self.n_agents * width, self.batch, self.feat)
-        eps = 0.0 if evaluate else float(epsilon)
+        eps, sel = self.selection(epsilon, evaluate)
         self._check(self._L.cs_policy_forward(vp(self.packed), vp(obs), width, self.cells, vp(last),
                                               vp(self.feat) if self.conv else None, self.n_agents, vp(self.hidden),
                                               vp(self.q) if want_q else None, vp(out), self.rows, self.n_agents,
-                                              self.n_actions, eps, self.seed, self.calls, self._stream()))
+                                              self.n_actions, eps, self.seed, self.calls, self.row0, sel, self._stream()))
         self.calls += 1
         return out
 
@@ -210,7 +224,7 @@ class FusedAgents:
         self._check(self._L.cs_policy_forward(vp(self.packed), vp(x), x.stride(0), self.cells, None,
                                               vp(feat) if self.conv else None, 1, vp(self.hidden),
                                               vp(self.q) if want_q else None, vp(self.actions), self.rows, self.n_agents,
-                                              self.n_actions, 0.0, self.seed, self.calls, self._stream()))
+                                              self.n_actions, 0.0, self.seed, self.calls, self.row0, 0, self._stream()))
         return self.actions
 
     def policy(self, epsilon=0.0, evaluate=True):

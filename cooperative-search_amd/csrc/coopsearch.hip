@@ -1310,6 +1310,8 @@ struct PolicyIO {
     float epsilon;
     unsigned long long seed;
     unsigned step0;          // epsilon-greedy counter of the first step (one per step, as one cs_policy_forward call each)
+    unsigned long long row0; // global index of network row 0 (sharded batches)
+    int select;              // CS_SELECT_*
 };
 
 template <int N>
@@ -1473,18 +1475,12 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io
         }
         __syncthreads();
         for (int r = threadIdx.x; r < ROWS; r += BLOCK) {   // argmax / epsilon-greedy, one thread per row
-            float best = -3.0e38f;
-            int arg = 0;
-            for (int a = 0; a < NA; a++) {
+            auto qf = [&](int a) {
                 const int o = r * 17 + a;
-                const float qv = ((s_q[o] + s_q[ROWS * 17 + o]) + (s_q[2 * ROWS * 17 + o] + s_q[3 * ROWS * 17 + o])) + s_b3[a];
-                if (qv > best) {
-                    best = qv;
-                    arg = a;
-                }
-            }
-            const int grow = b0 * N + r;
-            const int act = epsilon_greedy(arg, pio.epsilon, pio.seed, pio.step0 + (unsigned)s, grow, NA);
+                return ((s_q[o] + s_q[ROWS * 17 + o]) + (s_q[2 * ROWS * 17 + o] + s_q[3 * ROWS * 17 + o])) + s_b3[a];
+            };
+            const unsigned long long grow = pio.row0 + (unsigned long long)(b0 * N + r);
+            const int act = select_action(qf, NA, pio.select, pio.epsilon, pio.seed, pio.step0 + (unsigned)s, grow);
             s_act[r] = act;
             if (r < rows_valid) pio.actions[((size_t)s * p.B + b0) * N + r] = act;
         }
@@ -2688,8 +2684,8 @@ int cs_rollout(const cs_config *cfg, void *state_dev, const void *actions_dev, i
 
 int cs_rollout_policy(const cs_config *cfg, void *state_dev, const float *packed_dev, float *hidden_dev,
                       const int64_t *last_dev, int T, int flags, float epsilon, uint64_t seed, uint32_t step0,
-                      int64_t *actions_dev, float *reward_dev, uint8_t *terminated_dev, uint8_t *win_dev, float *obs_dev,
-                      float *state_out_dev, void *stream) {
+                      uint64_t row0, int select, int64_t *actions_dev, float *reward_dev, uint8_t *terminated_dev,
+                      uint8_t *win_dev, float *obs_dev, float *state_out_dev, void *stream) {
     DevParams p;
     int rc = make_params(cfg, state_dev, &p);
     if (rc) return rc;
@@ -2699,7 +2695,7 @@ int cs_rollout_policy(const cs_config *cfg, void *state_dev, const float *packed
     if (!packed_dev || !hidden_dev || !last_dev || !actions_dev || !reward_dev || !terminated_dev || !win_dev)
         return fail(CS_E_ARG, "null rollout buffer");
     StepIO io{nullptr, reward_dev, terminated_dev, win_dev, obs_dev, state_out_dev, flags, T};
-    PolicyIO pio{packed_dev, hidden_dev, last_dev, actions_dev, epsilon, seed, step0};
+    PolicyIO pio{packed_dev, hidden_dev, last_dev, actions_dev, epsilon, seed, step0, row0, select};
     const size_t lds = (size_t)3 * 16 * cfg->n_agents * LDW * sizeof(float);
 #define CS_LAUNCH_RP(NN)                                                                                               \
     case NN: {                                                                                                         \

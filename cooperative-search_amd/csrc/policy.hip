@@ -36,6 +36,8 @@ struct PolicyParams {
     float epsilon;
     unsigned long long seed;
     unsigned step;
+    unsigned long long row0; // global index of row 0 (sharded batches: env_offset * n_agents)
+    int select;              // CS_SELECT_*
     const float *w;          // packed
     const float *obs;
     const int64_t *last;     // [rows] last action index, < 0 = none (all-zero one-hot); null = raw input rows
@@ -199,18 +201,14 @@ __global__ __launch_bounds__(PBLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         // next tile's staging)
         if (threadIdx.x < 16) {
             const int row = row0 + threadIdx.x;
-            float best = -3.0e38f;
-            int arg = 0;
-            for (int a = 0; a < p.n_actions; a++) {
+            auto qf = [&](int a) {
                 const int o = threadIdx.x * 17 + a;
-                const float qv = ((s_q[0][o] + s_q[1][o]) + (s_q[2][o] + s_q[3][o])) + s_b3[a];
-                if (p.q && row < p.rows) p.q[(size_t)row * p.n_actions + a] = qv;
-                if (qv > best) {   // strict: the first maximum wins, like torch.argmax
-                    best = qv;
-                    arg = a;
-                }
-            }
-            if (row < p.rows) p.actions[row] = epsilon_greedy(arg, p.epsilon, p.seed, p.step, row, p.n_actions);
+                return ((s_q[0][o] + s_q[1][o]) + (s_q[2][o] + s_q[3][o])) + s_b3[a];
+            };
+            if (p.q && row < p.rows)
+                for (int a = 0; a < p.n_actions; a++) p.q[(size_t)row * p.n_actions + a] = qf(a);
+            const int act = select_action(qf, p.n_actions, p.select, p.epsilon, p.seed, p.step, p.row0 + (unsigned long long)row);
+            if (row < p.rows) p.actions[row] = act;
         }
         POL_STAMP(6);
     }
@@ -399,14 +397,15 @@ int cs_policy_pack(const float *fc1_w, const float *fc1_b, const float *w_ih, co
 // hidden_dev [rows][64] is updated in place; q_dev (nullable) [rows][n_actions]; actions_dev [rows] int64.
 int cs_policy_forward(const float *packed_dev, const float *obs_dev, int obs_stride, int obs_offset, const int64_t *last_dev,
                       const float *feat_dev, int rows_per_feat, float *hidden_dev, float *q_dev, int64_t *actions_dev,
-                      int rows, int n_agents, int n_actions, float epsilon, uint64_t seed, uint32_t step, void *stream) {
+                      int rows, int n_agents, int n_actions, float epsilon, uint64_t seed, uint32_t step, uint64_t row0,
+                      int select, void *stream) {
     const int in_dim = (feat_dev ? NFEAT : 0) + 4 + n_actions + n_agents;
     if (!packed_dev || !obs_dev || !hidden_dev || !actions_dev || rows < 1 || n_agents < 1 || n_actions < 1 ||
         in_dim > KIN_MAX || (feat_dev && rows_per_feat < 1)) {
         snprintf(g_perr, sizeof(g_perr), "cs_policy_forward: bad argument (input width %d, limit %d)", in_dim, KIN_MAX);
         return CS_E_ARG;
     }
-    PolicyParams p{rows, n_agents, n_actions, obs_stride, obs_offset, epsilon, seed, step, packed_dev, obs_dev, last_dev,
+    PolicyParams p{rows, n_agents, n_actions, obs_stride, obs_offset, epsilon, seed, step, row0, select, packed_dev, obs_dev, last_dev,
                    feat_dev, rows_per_feat, hidden_dev, q_dev, actions_dev};
     const int tiles = (rows + 15) / 16;
     if (in_dim <= 16) {

@@ -43,14 +43,55 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
 }
 
 
-// epsilon-greedy on top of the greedy choice `arg` (agent/agent.py:70-75): with probability epsilon a uniform action,
-// from a counter-based generator keyed by (seed, step, row)
-__device__ __forceinline__ int epsilon_greedy(int arg, float epsilon, unsigned long long seed, unsigned step, int row,
-                                              int n_actions) {
+// per-row random bits of one selection: counter-based, keyed by (seed, step, GLOBAL row) -- global, so that a sharded
+// batch draws the same exploration noise whatever the split (row = (env_offset + env) * n_agents + agent)
+__device__ __forceinline__ unsigned long long row_bits(unsigned long long seed, unsigned step, unsigned long long grow) {
+    return mix64(seed ^ mix64(((unsigned long long)step << 40) ^ grow));
+}
+
+// epsilon-greedy on top of the greedy choice `arg` (agent/agent.py:70-75): with probability epsilon a uniform action
+__device__ __forceinline__ int epsilon_greedy(int arg, float epsilon, unsigned long long seed, unsigned step,
+                                              unsigned long long grow, int n_actions) {
     if (epsilon > 0.0f) {
-        const unsigned long long h = mix64(seed ^ mix64(((unsigned long long)step << 32) | (unsigned)row));
+        const unsigned long long h = row_bits(seed, step, grow);
         const float u = (float)(h >> 40) * (1.0f / 16777216.0f);
         if (u < epsilon) return (int)((h & 0xffffffull) % (unsigned)n_actions);
     }
     return arg;
+}
+
+// Action of one row from its q values (qf(a) = q value of action a), all actions available (flight_env_easy.py:184-188).
+//   sel = 0                      agent/agent.py:68-75: argmax (first maximum), epsilon-greedy
+//   sel & CS_SELECT_SOFTMAX      agent/agent.py:77-97 (_choose_action_from_softmax, alg == 'reinforce'):
+//                                prob = (1 - eps) * softmax(q) + eps / |A|; argmax(prob) when the caller asked for the
+//                                deterministic choice (epsilon == 0 and evaluate: no CS_SELECT_SAMPLE), otherwise one
+//                                draw from Categorical(prob) by inverse CDF on the row's uniform
+template <class QF>
+__device__ __forceinline__ int select_action(QF qf, int n_actions, int sel, float epsilon, unsigned long long seed,
+                                             unsigned step, unsigned long long grow) {
+    float best = -3.0e38f;
+    int arg = 0;
+    for (int a = 0; a < n_actions; a++) {
+        const float qv = qf(a);
+        if (qv > best) {   // strict: the first maximum wins, like torch.argmax
+            best = qv;
+            arg = a;
+        }
+    }
+    if (!(sel & CS_SELECT_SOFTMAX)) return epsilon_greedy(arg, epsilon, seed, step, grow, n_actions);
+    if (!(sel & CS_SELECT_SAMPLE)) return arg;   // argmax(prob) = argmax(q): prob is increasing in q
+    float sum = 0.0f;
+    for (int a = 0; a < n_actions; a++) sum += __expf(qf(a) - best);
+    const float u = (float)(row_bits(seed, step, grow) >> 40) * (1.0f / 16777216.0f);   // [0, 1)
+    const float inv = (1.0f - epsilon) / sum, uni = epsilon / (float)n_actions;
+    float cum = 0.0f;
+    int pick = n_actions - 1;
+    for (int a = 0; a < n_actions; a++) {
+        cum += __expf(qf(a) - best) * inv + uni;
+        if (u < cum) {
+            pick = a;
+            break;
+        }
+    }
+    return pick;
 }

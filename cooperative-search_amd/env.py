@@ -302,9 +302,10 @@ class BatchedFlightEnv:
                 raise ValueError(f"rollout_policy(out=): bad destination for {k!r}")
         has_obs = out.get("obs") is not None and out.get("state") is not None
         flags = (_lib.FREEZE_DONE if self.freeze_done else 0) | (_lib.AUTO_RESET if self.auto_reset else 0)
+        sel_eps, sel_flags = agents.selection(epsilon, evaluate)
         _lib.check(self._L.cs_rollout_policy(
             self._cfgp, self._blob.data_ptr(), agents.packed.data_ptr(), agents.hidden.data_ptr(),
-            agents.actions.data_ptr(), T, flags, 0.0 if evaluate else float(epsilon), agents.seed, agents.calls,
+            agents.actions.data_ptr(), T, flags, sel_eps, agents.seed, agents.calls, agents.row0, sel_flags,
             out["actions"].data_ptr(), out["reward"].data_ptr(), out["terminated"].data_ptr(), out["win"].data_ptr(),
             out["obs"].data_ptr() if has_obs else None, out["state"].data_ptr() if has_obs else None, self._stream()))
         agents.calls += T

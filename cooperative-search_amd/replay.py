@@ -35,6 +35,10 @@ class DeviceReplayBuffer:
         sits exactly at `size`, which the reference leaves un-wrapped after an exact fill), wraps modulo `size`, and the
         cursor ends one past the last written slot -- again left at `size` rather than 0 after an exact fill."""
         inc = inc or 1
+        if inc > self.size:
+            # the reference's index arithmetic breaks here too (it raises on the assignment); duplicated slots would
+            # make several episodes race for one ring entry
+            raise ValueError(f"cannot store {inc} episodes at once in a buffer of {self.size}")
         start = 0 if self.current_idx >= self.size else self.current_idx
         idx = (start + np.arange(inc)) % self.size
         end = start + inc

@@ -83,7 +83,7 @@ int main() {
         HIP_OK(hipStreamSynchronize(stream));
         const auto t0 = std::chrono::steady_clock::now();
         CS_OK_(cs_reset(&cfg, state, nullptr, 0, o_tab, s_tab, stream));                    // o[0], s[0]
-        CS_OK_(cs_rollout_policy(&cfg, state, packed_dev, hidden, last, T, CS_FREEZE_DONE, 0.1f, 99, (uint32_t)(round * T),
+        CS_OK_(cs_rollout_policy(&cfg, state, packed_dev, hidden, last, T, CS_FREEZE_DONE, 0.1f, 99, (uint32_t)(round * T), /*row0=*/0, /*select=*/0,
                                  u_tab, r_tab, term_tab, win_tab, o_tab + (size_t)B * n * 4, s_tab + (size_t)B * W, stream));
         CS_OK_(cs_store_episodes(B, T, n, A, 4, W, o_tab, s_tab, u_tab, r_tab, term_tab, nullptr, &ep, stream));
         CS_OK_(cs_metrics(&cfg, state, metrics, stream));

@@ -41,6 +41,15 @@ extern "C" {
 
 enum { CS_OK = 0, CS_E_CONFIG = -1, CS_E_ARG = -2, CS_E_LAUNCH = -3 };
 
+/* action selection of cs_policy_forward / cs_rollout_policy */
+enum {
+    CS_SELECT_SOFTMAX = 1, /* agent/agent.py:77-97 (_choose_action_from_softmax, alg == 'reinforce'):
+                              prob = (1 - epsilon) * softmax(q) + epsilon / n_actions; default (0) is :68-75, argmax with
+                              epsilon-greedy exploration */
+    CS_SELECT_SAMPLE = 2   /* with CS_SELECT_SOFTMAX: draw from Categorical(prob); without it argmax(prob) -- the
+                              reference samples unless (epsilon == 0 and evaluate) */
+};
+
 /* cs_step / cs_rollout flags */
 enum {
     CS_FREEZE_DONE = 1,  /* an env that was terminated on entry is left untouched: reward 0, terminated 1.
@@ -194,12 +203,14 @@ int cs_policy_pack(const float *fc1_w, const float *fc1_b, const float *w_ih, co
  * front of the obs columns; rows r*rows_per_feat .. +rows_per_feat-1 share feature row r (rows_per_feat = n_agents
  * when the features were computed once per env);
  * hidden_dev float [rows][64] updated in place; q_dev float [rows][n_actions] or NULL; actions_dev int64 [rows]:
- * argmax_a q (first maximum), or with probability epsilon a uniform action drawn from a counter-based generator
- * keyed by (seed, step, row). */
+ * select = 0: argmax_a q (first maximum), or with probability epsilon a uniform action; CS_SELECT_SOFTMAX: the softmax
+ * rule of agent.py:77-97.  Random choices come from a counter-based generator keyed by (seed, step, row0 + row): row0 =
+ * global index of this call's row 0 (env_offset * n_agents for a sharded batch), so the noise does not depend on the
+ * sharding. */
 int cs_policy_forward(const float *packed_dev, const float *obs_dev, int obs_stride, int obs_offset,
                       const int64_t *last_dev, const float *feat_dev, int rows_per_feat, float *hidden_dev, float *q_dev,
                       int64_t *actions_dev, int rows, int n_agents, int n_actions, float epsilon, uint64_t seed,
-                      uint32_t step, void *stream);
+                      uint32_t step, uint64_t row0, int select, void *stream);
 
 /* flight: the conv front end of base_net.py:9-18,31-36 with the reference's hyper-parameters (common/arguments.py:256-265:
  * Conv2d(1,4,k=4,s=2) -> ReLU -> Conv2d(4,1,k=3,s=1,p=1) -> ReLU -> Linear(576,16)) on n_maps 50x50 probability maps;
@@ -220,8 +231,8 @@ const char *cs_policy_last_error(void);
  *   actions_dev  int64 [T][B][n] chosen actions (out); the other outputs as in cs_rollout. */
 int cs_rollout_policy(const cs_config *cfg, void *state_dev, const float *packed_dev, float *hidden_dev,
                       const int64_t *last_dev, int T, int flags, float epsilon, uint64_t seed, uint32_t step0,
-                      int64_t *actions_dev, float *reward_dev, uint8_t *terminated_dev, uint8_t *win_dev, float *obs_dev,
-                      float *state_out_dev, void *stream);
+                      uint64_t row0, int select, int64_t *actions_dev, float *reward_dev, uint8_t *terminated_dev,
+                      uint8_t *win_dev, float *obs_dev, float *state_out_dev, void *stream);
 
 /* ---- caller-side rows f1 / f2: episode batch assembly ------------------------------------------------------------
  * common/rollout.py:66-76,105-132 (the eleven per-episode arrays and their padding: steps after termination are zero

@@ -272,3 +272,80 @@ def test_closed_loop_c_example_runs(tmp_path):
     m = re.search(r"episodes (\d+)\s+mean episode_reward (-?[\d.]+)\s+win rate ([\d.]+)\s+mean targets_find ([\d.]+)", out.stdout)
     assert m and int(m.group(1)) == 4096, out.stdout
     assert 0.0 <= float(m.group(4)) <= 15.0 and "yes" in out.stdout
+
+
+def _row_uniform(seed, step, rows):
+    """numpy restatement of csrc/policy_dev.h row_bits -> the 24-bit uniform a row's selection uses."""
+    M = (1 << 64) - 1
+
+    def mix64(z):
+        z = (z + 0x9E3779B97F4A7C15) & M
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        return z ^ (z >> 31)
+    return np.array([(mix64(seed ^ mix64(((step << 40) ^ int(r)) & M)) >> 40) / 16777216.0 for r in rows], dtype=np.float64)
+
+
+@pytest.mark.parametrize("eps", [0.0, 0.25])
+def test_softmax_selection_matches_the_reference_statement(eps):
+    """agent/agent.py:77-97 (_choose_action_from_softmax, alg == 'reinforce'): prob = (1 - eps) softmax(q) + eps / |A|,
+    one Categorical draw -- restated with torch on the kernel's own q values and the row's uniform (inverse CDF);
+    rows whose uniform falls within 1e-5 of a CDF step are not compared."""
+    a = _args(3)
+    a.alg = "reinforce"
+    B, off = 3000, 5000
+    torch.manual_seed(11)
+    fused = FusedAgents(a, B, seed=1234, env_offset=off)
+    for p in fused.net.parameters():
+        p.data.mul_(4.0)   # spread the q values so that the distribution is far from uniform
+    fused.load_weights()
+    obs = torch.rand(B, 3, 4, device="cuda") * 2 - 1
+    for call in range(3):
+        act = fused.choose_action(obs, epsilon=eps, evaluate=False, want_q=True).clone()
+        q = fused.q.reshape(B * 3, 3)
+        prob = (1 - eps) * torch.softmax(q, dim=-1) + eps / 3
+        cdf = (prob / prob.sum(-1, keepdim=True)).cumsum(-1).double().cpu().numpy()
+        u = _row_uniform(1234, call, off * 3 + np.arange(B * 3))
+        want = np.minimum((u[:, None] >= cdf).sum(1), 2)
+        clear = np.abs(cdf - u[:, None]).min(1) > 1e-5
+        got = act.reshape(-1).cpu().numpy()
+        assert clear.mean() > 0.99 and np.array_equal(got[clear], want[clear])
+        # and the empirical distribution follows prob
+        assert abs((got == 0).mean() - prob[:, 0].mean().item()) < 0.02
+    # epsilon == 0 and evaluate: argmax(prob) == argmax(q)
+    act = fused.choose_action(obs, epsilon=0.0, evaluate=True, want_q=True).clone()
+    top2 = fused.q.topk(2, dim=2).values
+    clear = (top2[..., 0] - top2[..., 1]) > 1e-4
+    assert (act == fused.q.argmax(2))[clear].all()
+
+
+@pytest.mark.parametrize("softmax", [False, True])
+def test_exploration_noise_does_not_depend_on_the_sharding(softmax):
+    """the per-row generator is keyed on the GLOBAL (env, agent) row.  A batch split into two shards with
+    env_offset picks, with epsilon > 0, exactly the actions of the whole batch -- through cs_policy_forward and through
+    the fused closed-loop kernel."""
+    n, B, T = 3, 512, 40
+    a = _args(n)
+    if softmax:
+        a.alg = "reinforce"
+    torch.manual_seed(5)
+    net = AgentRNN(rnn_input_shape(a), a).cuda()
+    args = cs.make_env_args("flight_easy", n_agents=n)
+    whole_env = cs.BatchedFlightEnv(args, batch=B, freeze_done=True)
+    whole = FusedAgents(a, B, net=net, seed=77)
+    ow = whole_env.rollout_policy(whole, T, epsilon=0.3, evaluate=False)
+    half = B // 2
+    for k in range(2):
+        env = cs.BatchedFlightEnv(args, batch=half, env_offset=k * half, freeze_done=True)
+        ag = FusedAgents(a, half, net=net, seed=77, env_offset=k * half)
+        op = env.rollout_policy(ag, T, epsilon=0.3, evaluate=False)
+        for key in ("actions", "reward", "terminated", "obs"):
+            assert torch.equal(op[key], ow[key][:, k * half:(k + 1) * half]), (k, key)
+        # the two-kernel loop on the shard draws the same noise as well
+        env2 = cs.BatchedFlightEnv(args, batch=half, env_offset=k * half, freeze_done=True)
+        ag2 = FusedAgents(a, half, net=net, seed=77, env_offset=k * half)
+        for t in range(5):
+            act = ag2.choose_action(env2.get_obs(), epsilon=0.3, evaluate=False)
+            assert torch.equal(act, ow["actions"][t, k * half:(k + 1) * half]), (k, t)
+            env2.step(act)
+    assert (ow["actions"] != ow["actions"][0:1]).any()

@@ -92,3 +92,14 @@ def test_batched_choose_action_semantics():
     assert (ag.choose_action(obs, last, avail=avail, evaluate=True) == 0).all()
     ag.init_hidden()
     assert (ag.choose_action(obs, last, avail=avail, epsilon=1.0, evaluate=False) == 0).all()
+
+
+def test_replay_buffer_rejects_more_episodes_than_slots():
+    """`inc > size` would hand out duplicate ring slots (several episodes racing for one entry); the
+    reference's own index arithmetic fails on it as well (replay_buffer.py:84-101)."""
+    import pytest
+    buf = cs.DeviceReplayBuffer(_rb_args(), 4, device="cpu")
+    assert list(buf._get_storage_idx(3)) == [0, 1, 2]
+    with pytest.raises(ValueError):
+        buf._get_storage_idx(5)
+    assert list(buf._get_storage_idx(4)) == [3, 0, 1, 2]
