@@ -326,6 +326,9 @@ def main():
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump(metas, f, indent=1)
     capture_all_episodes()
+    capture_replay_indices()     # replay_indices.json
+    capture_rnn_forward()        # rnn_forward.npz
+    # (the trained-checkpoint fixtures trained_*.npz have their own, slower script: gen_trained.py)
 
 
 def capture_replay_indices():

@@ -349,3 +349,75 @@ def test_exploration_noise_does_not_depend_on_the_sharding(softmax):
             assert torch.equal(act, ow["actions"][t, k * half:(k + 1) * half]), (k, t)
             env2.step(act)
     assert (ow["actions"] != ow["actions"][0:1]).any()
+
+
+def _trained(tag):
+    z = np.load(os.path.join(GOLD, f"trained_{tag}.npz"))
+    n, am = int(z["n_agents"]), int(z["agent_mode"])
+    env_name = "flight" if tag.startswith("flight") else "flight_easy"
+    args = cs.make_env_args(env_name, n_agents=n, agent_mode=am)
+    return z, args, n
+
+
+IDX = [10, 20, 40, 60, 80, 100, 150, 199]   # the indices runner.py:168 prints
+
+
+@pytest.mark.parametrize("tag", ["easy3_qmix", "easy5_qmix", "easy3_reinforce"])
+def test_trained_checkpoint_closed_loop_flight_easy(tag):
+    """Policy-in-the-loop parity with the reference's SHIPPED checkpoints: the checkpoint's weights
+    (tests/golden/trained_*.npz, written by gen_trained.py from model/<run>/<N>_rnn_net_params.pkl) drive 4096 envs through
+    the fused closed-loop kernel (k_rollout_policy: network forward + env step per step, 200 steps in one launch) under
+    generate_replay's protocol (reset(init=True), greedy); the found-fraction curve must agree with the curve the
+    reference's own env + RNN produce with the same weights (100 replays, s.e. <= 2 points) at the printed indices."""
+    z, args, n = _trained(tag)
+    B, T = 4096, 200
+    env = cs.BatchedFlightEnv(args, batch=B, freeze_done=True)
+    cs.apply_env_info(args, env)
+    if "reinforce" in tag:
+        args.alg = "reinforce"   # softmax rule; epsilon = 0 and evaluate -> argmax(prob), agent.py:92-93
+    net = AgentRNN(rnn_input_shape(args), args)
+    net.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w_")})
+    fused = FusedAgents(args, B, net=net)
+    env.reset(init=True)
+    fused.init_hidden()
+    out = env.rollout_policy(fused, T, epsilon=0.0, evaluate=True)
+    found = out["state"][:, :, 4 * n + 2::3].sum(-1)                 # [T, B] targets found after each step
+    curve = (found.double().mean(1) / 15 * 100).cpu().numpy()
+    assert (np.diff(curve) >= -1e-9).all() and found.max().item() <= 15
+    ref = z["ref_curve"]
+    np.testing.assert_allclose(curve[IDX], ref[IDX], rtol=0, atol=4.0,
+                               err_msg=f"{tag}: ours {np.round(curve[IDX], 2)} reference replay {np.round(ref[IDX], 2)} "
+                                       f"shipped result (checkpoint {int(z['shipped_num'])}) {np.round(z['shipped_curve'][IDX], 2)}")
+    # every episode of the trained policy finds all 15 targets in the reference replay; so must (nearly) all of ours
+    assert float(z["ref_found"].mean()) == 15.0 and curve[199] > 99.5
+    # the two-kernel loop (cs_policy_forward + cs_step per step) walks the same trajectories
+    seeds = np.arange(256, dtype=np.uint32) + 5
+    env2 = cs.BatchedFlightEnv(args, batch=256, freeze_done=True, seeds=seeds)
+    env3 = cs.BatchedFlightEnv(args, batch=256, freeze_done=True, seeds=seeds)
+    f2, f3 = FusedAgents(args, 256, net=net), FusedAgents(args, 256, net=net)
+    env2.reset(init=True)
+    env3.reset(init=True)
+    o3 = env3.rollout_policy(f3, 60, evaluate=True)
+    for t in range(60):
+        a = f2.choose_action(env2.get_obs(), evaluate=True)
+        assert torch.equal(a, o3["actions"][t]), t
+        env2.step(a)
+
+
+def test_trained_checkpoint_closed_loop_flight():
+    """flight (probability-map observation, conv front end): checkpoint 70 of the shipped QMIX run, the one its shipped
+    result file average_res_70.npy was made with.  1024 envs through cs_policy_conv_features + cs_policy_forward + cs_step;
+    compared with the reference replay of the same weights (30 episodes) and with the shipped curve (100 episodes)."""
+    z, args, n = _trained("flight3_qmix")
+    B = 1024
+    env = cs.BatchedFlightEnv(args, batch=B, freeze_done=True)
+    cs.apply_env_info(args, env)
+    net = AgentRNN(rnn_input_shape(args), args)
+    net.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w_")})
+    fused = FusedAgents(args, B, net=net)
+    curve = cs.collect_experiment_data(env, fused.policy(evaluate=True))
+    assert int(z["checkpoint"]) == int(z["shipped_num"]) == 70
+    msg = (f"ours {np.round(curve[IDX], 2)} reference replay {np.round(z['ref_curve'][IDX], 2)} "
+           f"shipped {np.round(z['shipped_curve'][IDX], 2)}")
+    np.testing.assert_allclose(curve[IDX], z["shipped_curve"][IDX], rtol=0, atol=5.0, err_msg=msg)
+    np.testing.assert_allclose(curve[IDX], z["ref_curve"][IDX], rtol=0, atol=7.0, err_msg=msg)
