@@ -105,6 +105,29 @@ def load():
     return L
 
 
+_ops = None
+
+
+def torch_ops():
+    """torch.ops.coopsearch (csrc/torch_ops.cpp): tensor-level ops over the same C ABI -- device / dtype / contiguity
+    checks in C++ (TORCH_CHECK), stream = torch's current HIP stream.  Builds coopsearch_torch.so first when it is missing
+    or stale; no fallback: a missing library with no compiler raises."""
+    global _ops
+    if _ops is not None:
+        return _ops
+    import torch
+    load()   # libcoopsearch_hip.so first: coopsearch_torch.so links it
+    if _build.torch_ops_stale():
+        if _build.hipcc_path() is None and not os.path.exists(_build.TORCH_LIB_PATH):
+            raise CoopSearchError(f"{_build.TORCH_LIB_PATH} is missing and there is no compiler to build it")
+        _build.build_torch_ops()
+    torch.ops.load_library(_build.TORCH_LIB_PATH)
+    if int(torch.ops.coopsearch.abi_version()) != ABI_VERSION:
+        raise CoopSearchError(f"{_build.TORCH_LIB_PATH}: ABI version mismatch (stale library)")
+    _ops = torch.ops.coopsearch
+    return _ops
+
+
 def check(rc):
     if rc != 0:
         raise CoopSearchError(f"coopsearch error {rc}: {load().cs_last_error().decode()}")

@@ -9,6 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB_PATH = os.environ.get("COOPSEARCH_LIB") or os.path.join(CSRC, "libcoopsearch_hip.so")  # override: experiments only
+TORCH_LIB_PATH = os.path.join(CSRC, "coopsearch_torch.so")   # torch.ops.coopsearch.*: the op layer over the C ABI
 SOURCES = ["coopsearch.hip", "policy.hip", "episodes.hip", "policy_dev.h", "trig_table.inc"]
 HEADERS = [os.path.join(ROOT, "include", "coopsearch.h")]
 
@@ -63,5 +64,44 @@ def build_extension(force=False, verbose=False):
     return LIB_PATH
 
 
+def torch_ops_stale():
+    if not os.path.exists(TORCH_LIB_PATH):
+        return True
+    t = os.path.getmtime(TORCH_LIB_PATH)
+    deps = [os.path.join(CSRC, "torch_ops.cpp")] + HEADERS
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_torch_ops(force=False, verbose=False):
+    """g++ -> csrc/coopsearch_torch.so: the thin PyTorch-ROCm op layer (csrc/torch_ops.cpp; host code only, it links
+    libcoopsearch_hip.so through an $ORIGIN rpath and torch's libraries)."""
+    if not force and not torch_ops_stale():
+        return TORCH_LIB_PATH
+    build_extension()
+    import torch
+    from torch.utils import cpp_extension as ce
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if cxx is None:
+        raise RuntimeError("g++ not found: cannot build coopsearch_torch.so")
+    tlib = ce.library_paths()[0]
+    with _build_lock():
+        if not force and not torch_ops_stale():
+            return TORCH_LIB_PATH
+        tmp = f"{TORCH_LIB_PATH}.tmp.{os.getpid()}"
+        cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+               f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-w",
+               "-I", os.path.join(ROOT, "include")]
+        for inc in ce.include_paths() + ["/opt/rocm/include"]:
+            cmd += ["-I", inc]
+        cmd += [os.path.join(CSRC, "torch_ops.cpp"), "-o", tmp, "-L", tlib, "-lc10", "-lc10_hip", "-ltorch", "-ltorch_cpu",
+                "-ltorch_hip", "-L", CSRC, "-l:" + os.path.basename(LIB_PATH), "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tlib}"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, cwd=CSRC)
+        os.replace(tmp, TORCH_LIB_PATH)
+    return TORCH_LIB_PATH
+
+
 if __name__ == "__main__":
     print(build_extension(force=True, verbose=True))
+    print(build_torch_ops(force=True, verbose=True))

@@ -60,6 +60,9 @@ class BatchedFlightEnv:
     freeze_done terminated envs ignore step() (reward 0, terminated 1); False reproduces the reference, which has
                 no terminal guard
     auto_reset  terminated envs are reset(init=False) at the start of the next step()
+    binding     "torch" (default): the calls go through torch.ops.coopsearch.* (csrc/torch_ops.cpp: tensor checks in C++,
+                torch's current HIP stream); "ctypes": straight to the C ABI with data_ptr()s -- same library, same
+                kernels, no torch in the call path
     kernel      flight_easy only: "group" (16 lanes per env: lowest step latency, fills the chip from B = 4096; its
                 rollout picks between "solo" -- one wavefront per four envs does the whole step -- and "duo" -- a
                 kinematics wavefront and a detection wavefront per four envs, for batches that leave a wave slot per
@@ -68,10 +71,14 @@ class BatchedFlightEnv:
     """
 
     def __init__(self, args, circle_dict=None, batch=1, device="cuda", seeds=None, env_offset=0, freeze_done=True,
-                 auto_reset=False, variant=None, kernel="auto"):
+                 auto_reset=False, variant=None, kernel="auto", binding="torch"):
         if not torch.cuda.is_available():
             raise RuntimeError("BatchedFlightEnv needs a GPU: the HIP path has no CPU fallback")
         self._L = _lib.load()
+        if binding not in ("torch", "ctypes"):
+            raise ValueError("binding must be 'torch' (torch.ops.coopsearch, csrc/torch_ops.cpp) or 'ctypes'")
+        self.binding = binding
+        self._ops = _lib.torch_ops() if binding == "torch" else None
         self.args = args
         if variant is None:
             variant = "flight" if getattr(args, "env", "flight_easy") == "flight" else "flight_easy"
@@ -103,6 +110,7 @@ class BatchedFlightEnv:
         self.circle_dict = circle_dict if circle_dict is not None else default_circle_dict()
         self.cfg = _cfg_from_args(args, self.circle_dict, self.batch, 1 if self.flight else 0)
         self._cfgp = C.byref(self.cfg)
+        self._cfg_t = torch.frombuffer(bytearray(bytes(self.cfg)), dtype=torch.uint8)   # the struct's bytes, for the ops
         lay = _lib.CsLayout()
         _lib.check(self._L.cs_state_layout(self._cfgp, C.byref(lay)))
         self.layout = lay
@@ -126,7 +134,11 @@ class BatchedFlightEnv:
         if self.freeze_done and self.auto_reset:
             self.freeze_done = False
         self.env_offset = int(env_offset)
-        _lib.check(self._L.cs_init(self._cfgp, self._blob.data_ptr(), self._stream()))
+        if self._ops is not None:
+            assert int(self._ops.state_bytes(self._cfg_t)) == lay.total_bytes
+            self._ops.env_init(self._cfg_t, self._blob)
+        else:
+            _lib.check(self._L.cs_init(self._cfgp, self._blob.data_ptr(), self._stream()))
         if seeds is None:
             seeds = (DEFAULT_BASE_SEED + self.env_offset + np.arange(B, dtype=np.int64)) % (1 << 32)
         self.seed(seeds)
@@ -158,7 +170,10 @@ class BatchedFlightEnv:
         """int32 [B, MT_STRIDE]: every env's MT19937 row in a form that depends only on the stream position (the kernels may
         leave different amounts of the row pre-twisted ahead of the cursor; see cs_mt_canonical)."""
         out = torch.empty(self.batch, _lib.MT_STRIDE, dtype=torch.int32, device=self.device)
-        _lib.check(self._L.cs_mt_canonical(self._cfgp, self._blob.data_ptr(), out.data_ptr(), self._stream()))
+        if self._ops is not None:
+            self._ops.mt_canonical(self._cfg_t, self._blob, out)
+        else:
+            _lib.check(self._L.cs_mt_canonical(self._cfgp, self._blob.data_ptr(), out.data_ptr(), self._stream()))
         return out
 
     def seed(self, seeds):
@@ -167,7 +182,10 @@ class BatchedFlightEnv:
         if s.shape != (self.batch,):
             raise ValueError("seeds must have shape (batch,)")
         t = torch.from_numpy(s.view(np.int32)).to(self.device)
-        _lib.check(self._L.cs_seed(self._cfgp, self._blob.data_ptr(), t.data_ptr(), self._stream()))
+        if self._ops is not None:
+            self._ops.env_seed(self._cfg_t, self._blob, t)
+        else:
+            _lib.check(self._L.cs_seed(self._cfgp, self._blob.data_ptr(), t.data_ptr(), self._stream()))
         self._seeds_keepalive = t
 
     # ------------------------------------------------------------------------------------------- reference API
@@ -187,6 +205,9 @@ class BatchedFlightEnv:
             if mask.shape != (self.batch,):
                 raise ValueError("mask must have shape (batch,)")
             mptr = mask.data_ptr()
+        if self._ops is not None:
+            self._ops.env_reset(self._cfg_t, self._blob, mask, bool(init), self._obs, self._state)
+            return
         _lib.check(self._L.cs_reset(self._cfgp, self._blob.data_ptr(), mptr, 1 if init else 0,
                                     self._obs.data_ptr(), self._state.data_ptr(), self._stream()))
 
@@ -237,9 +258,13 @@ class BatchedFlightEnv:
                         or not v.is_contiguous() or v.device != dst[k].device:
                     raise ValueError(f"step(out=): bad destination for {k!r}")
                 dst[k] = v
-        _lib.check(self._L.cs_step(self._cfgp, self._blob.data_ptr(), a.data_ptr(), self._flags(a),
-                                   dst["reward"].data_ptr(), dst["terminated"].data_ptr(), dst["win"].data_ptr(),
-                                   dst["obs"].data_ptr(), dst["state"].data_ptr(), self._stream()))
+        if self._ops is not None:
+            self._ops.env_step(self._cfg_t, self._blob, a, self._flags(a), dst["reward"], dst["terminated"].view(torch.uint8),
+                               dst["win"].view(torch.uint8), dst["obs"], dst["state"])
+        else:
+            _lib.check(self._L.cs_step(self._cfgp, self._blob.data_ptr(), a.data_ptr(), self._flags(a),
+                                       dst["reward"].data_ptr(), dst["terminated"].data_ptr(), dst["win"].data_ptr(),
+                                       dst["obs"].data_ptr(), dst["state"].data_ptr(), self._stream()))
         return dst["reward"], dst["terminated"].view(torch.bool), dst["win"].view(torch.bool)
 
     def rollout(self, actions, emit=True, out=None, update_views=True):
@@ -263,10 +288,14 @@ class BatchedFlightEnv:
             out = dict(out)
         term = out["terminated"].view(torch.uint8)
         win = out["win"].view(torch.uint8)
-        _lib.check(self._L.cs_rollout(self._cfgp, self._blob.data_ptr(), a.data_ptr(), T, self._flags(a),
-                                      out["reward"].data_ptr(), term.data_ptr(), win.data_ptr(),
-                                      out["obs"].data_ptr() if emit else None,
-                                      out["state"].data_ptr() if emit else None, self._stream()))
+        if self._ops is not None:
+            self._ops.env_rollout(self._cfg_t, self._blob, a, self._flags(a), out["reward"], term, win,
+                                  out["obs"] if emit else None, out["state"] if emit else None)
+        else:
+            _lib.check(self._L.cs_rollout(self._cfgp, self._blob.data_ptr(), a.data_ptr(), T, self._flags(a),
+                                          out["reward"].data_ptr(), term.data_ptr(), win.data_ptr(),
+                                          out["obs"].data_ptr() if emit else None,
+                                          out["state"].data_ptr() if emit else None, self._stream()))
         if update_views:
             if emit:
                 self._obs.copy_(out["obs"][-1])
@@ -322,6 +351,9 @@ class BatchedFlightEnv:
 
     def refresh(self):
         """Re-emit get_obs()/get_state() from the device state (after editing raw())."""
+        if self._ops is not None:
+            self._ops.env_emit(self._cfg_t, self._blob, self._obs, self._state)
+            return
         _lib.check(self._L.cs_emit(self._cfgp, self._blob.data_ptr(), self._obs.data_ptr(), self._state.data_ptr(),
                                    self._stream()))
 
@@ -362,6 +394,9 @@ class BatchedFlightEnv:
     def metric_partials(self):
         """float64[4] on device: sum total_reward, sum win, sum target_find, env count (runner.py:86-96)."""
         self._metrics.zero_()
+        if self._ops is not None:
+            self._ops.env_metrics(self._cfg_t, self._blob, self._metrics)
+            return self._metrics
         _lib.check(self._L.cs_metrics(self._cfgp, self._blob.data_ptr(), self._metrics.data_ptr(), self._stream()))
         return self._metrics
 

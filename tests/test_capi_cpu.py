@@ -157,3 +157,23 @@ def test_policy_pack_layout_host_only():
     assert off == n
     assert L.cs_policy_pack(*[C.c_void_p(w.ctypes.data) for w in ws], 33, nA, C.c_void_p(packed.ctypes.data)) != 0
     assert b"in_dim" in L.cs_policy_last_error()
+
+
+def test_torch_op_library_builds_loads_and_registers_every_op():
+    """The PyTorch-ROCm op layer over the C ABI (csrc/torch_ops.cpp) builds in-tree and registers its ops; host-only
+    entry points work without a GPU."""
+    ops = _lib.torch_ops()
+    for name in ("abi_version", "state_bytes", "env_init", "env_seed", "env_reset", "env_step", "env_rollout", "env_emit",
+                 "env_metrics", "mt_advance", "mt_canonical"):
+        assert hasattr(ops, name), name
+    assert int(ops.abi_version()) == _lib.ABI_VERSION
+    import torch
+    cfg = _cfg(n_agents=3, batch=4096)
+    t = torch.frombuffer(bytearray(bytes(cfg)), dtype=torch.uint8)
+    lay = _lib.CsLayout()
+    assert _lib.load().cs_state_layout(C.byref(cfg), C.byref(lay)) == 0
+    assert int(ops.state_bytes(t)) == lay.total_bytes
+    with pytest.raises(RuntimeError, match="sizeof"):
+        ops.state_bytes(t[:-4].clone())
+    with pytest.raises(RuntimeError, match="GPU"):   # no device here: a CPU state tensor must be refused, not dereferenced
+        ops.env_init(t, torch.zeros(lay.total_bytes, dtype=torch.uint8))
