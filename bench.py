@@ -70,8 +70,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads reported under 'also'")
-    ap.add_argument("--kernel", default="auto", choices=["auto", "group", "lane"],
-                    help="flight_easy kernel: 16 lanes per env, one lane per env, or by batch size")
+    ap.add_argument("--kernel", default="auto", choices=["auto", "group", "solo", "duo", "lane"],
+                    help="flight_easy kernel: 16 lanes per env (solo / duo wavefront roles, or chosen by batch), one lane "
+                         "per env, or everything by batch size")
     ap.add_argument("--min-gpu-s", type=float, default=MIN_GPU_S)
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU-only check of the N-rank control flow (launcher, gloo process group, metric all-gather); "
@@ -135,12 +136,16 @@ def largest_divisor_leq(k, cap):
 
 
 def kernel_label(env_name, n, B, mode, kernel):
+    """The kernel cs_step / cs_rollout dispatches to (csrc/coopsearch.hip: use_lane_kernel, duo_pays)."""
     lane = env_name == "flight_easy" and (kernel == "lane" or (kernel == "auto" and B >= 32768))
     if env_name == "flight":
         return f"k_step<{n},1> + k_map<{n}>"
     if lane:
         return f"k_rollout_lane<{n}>"
-    return {"rollout": f"k_rollout<{n}>", "step": f"k_step<{n},0>"}[mode]
+    if mode == "step":
+        return f"k_step<{n},0>"
+    duo = kernel == "duo" or (kernel in ("auto", "group") and n <= 4 and B <= 6144)
+    return f"k_rollout_duo<{n}>" if duo else f"k_rollout<{n}>"
 
 
 def pmc_traffic(label, B, steps_per_launch):
@@ -150,7 +155,8 @@ def pmc_traffic(label, B, steps_per_launch):
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(path):
         return None
-    ent = (json.load(open(path)).get("kernels") or {}).get(label)
+    kernels = json.load(open(path)).get("kernels") or {}
+    ent = kernels.get(f"{label}@{steps_per_launch}") or kernels.get(label)
     if not ent:
         return None
     return int(ent["hbm_bytes_per_env_step"] * B * steps_per_launch)
@@ -170,50 +176,54 @@ def cpu_model():
 def cpu_baseline(env_name, n, batch, budget_s=10.0):
     """The C oracle (a port of the reference's algorithm, parity-pinned by tests/) timed on this host's cores on a
     bounded sample of the same workload: same batch, auto-reset, obs+state emission, x*x squares (its fast mode).
-    flight_easy: orc_batch_rollout -- ONE OpenMP region per T = 100 steps, env-major, so the fork/join cost is paid
-    once per 100 steps and an env stays in its core's cache.  The thread-scaling points are in `scaling`."""
+    flight_easy: orc_batch_rollout_rep -- ONE OpenMP region per 400 steps (the 100-step action table walked four times),
+    env-major, so the fork/join cost is paid once per 400 steps and an env stays in its core's cache.  Thread counts from
+    1 to all logical CPUs are calibrated first; `value` is the BEST of them (`cores` = that thread count), the others
+    are listed in `thread_scaling_env_steps_per_s`."""
     import numpy as np
     from oracle import oracle as orc
-    threads = max(1, min(orc.OracleBatch.max_threads(), os.cpu_count() or 1))
+    max_threads = max(1, min(orc.OracleBatch.max_threads(), os.cpu_count() or 1))
     flight = env_name == "flight"
     B = batch if not flight else min(batch, 256)
-    T = 100 if not flight else 10
+    T, R = (100, 4) if not flight else (10, 1)
     cfg = orc.make_config(variant=env_name, n_agents=n)
     seeds = (20240000 + np.arange(B)).astype(np.uint32)
     orc.set_exact_pow(False)
     try:
         ob = orc.OracleBatch(cfg, B, seeds)
-        ob.reset(init=True, threads=threads)
+        ob.reset(init=True, threads=max_threads)
         acts = np.random.RandomState(1).randint(0, 3, size=(T, B, n)).astype(np.int32)
-        out = ob.rollout(acts, auto_reset=True, freeze_done=False, threads=threads)   # warm-up + buffers
+        out = ob.rollout(acts, auto_reset=True, freeze_done=False, threads=max_threads)   # warm-up + buffers
 
         def run(th, reps):
             t0 = time.perf_counter()
             for _ in range(reps):
-                ob.rollout(acts, auto_reset=True, freeze_done=False, threads=th, out=out)
-            return B * T * reps / (time.perf_counter() - t0)
+                ob.rollout(acts, auto_reset=True, freeze_done=False, threads=th, out=out, repeat=R)
+            dt = time.perf_counter() - t0
+            return B * T * R * reps / dt, dt
 
-        t0 = time.perf_counter()
-        run(threads, 1)
-        per = time.perf_counter() - t0
-        reps = int(max(2, min(2000, 0.6 * budget_s / max(per, 1e-6))))
-        t0 = time.perf_counter()
-        multi = run(threads, reps)
-        dt = time.perf_counter() - t0
+        cands = sorted({1, 2, 4, 8, 16, 32, 64, max_threads // 2, max_threads} & set(range(1, max_threads + 1)))
         scaling = {}
-        pts = sorted({1, max(1, threads // 8), max(1, threads // 2)} - {threads})
-        for th in pts:                      # ~0.4 budget_s in total for the scaling points
-            est = per * threads / th
-            scaling[str(th)] = run(th, int(max(1, min(reps, 0.4 * budget_s / len(pts) / max(est, 1e-6)))))
-        scaling[str(threads)] = multi
+        for th in cands:   # calibration: one region each, except the slow single thread (a quarter region's worth)
+            if th == 1:
+                t0 = time.perf_counter()
+                ob.rollout(acts, auto_reset=True, freeze_done=False, threads=1, out=out, repeat=1)
+                scaling["1"] = B * T / (time.perf_counter() - t0)
+            else:
+                scaling[str(th)] = run(th, 1)[0]
+        best = max(cands, key=lambda th: scaling[str(th)])
+        per = B * T * R / scaling[str(best)]
+        reps = int(max(2, min(5000, budget_s / max(per, 1e-6))))
+        value, dt = run(best, reps)
+        scaling[str(best)] = value
     finally:
         orc.set_exact_pow(True)
     single = scaling["1"]
-    return {"value": multi, "unit": "env-steps/s", "cores": threads, "kind": "port",
-            "sample": f"C oracle (oracle/flight_oracle.c orc_batch_rollout: one OpenMP region per {T} steps, env-major), "
-                      f"{B} envs x {T * reps} steps, auto-reset, obs+state emitted, {dt:.1f} s wall on {cpu_model()} "
-                      f"({os.cpu_count()} logical CPUs)",
-            "single_thread_value": single, "speedup_vs_single_thread": multi / single,
+    return {"value": value, "unit": "env-steps/s", "cores": best, "kind": "port",
+            "sample": f"C oracle (oracle/flight_oracle.c orc_batch_rollout_rep: one OpenMP region per {T * R} steps, "
+                      f"env-major), {B} envs x {T * R * reps} steps on {best} threads (best of {cands}), auto-reset, "
+                      f"obs+state emitted, {dt:.1f} s wall on {cpu_model()} ({os.cpu_count()} logical CPUs)",
+            "single_thread_value": single, "speedup_vs_single_thread": value / single,
             "thread_scaling_env_steps_per_s": scaling}
 
 

@@ -12,6 +12,7 @@ All environment arithmetic happens in csrc/coopsearch.hip behind the C ABI of in
 owns device memory and the stream.  There is no CPU fallback: without a GPU and the built library this raises.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -71,10 +72,12 @@ class BatchedFlightEnv:
     """
 
     def __init__(self, args, circle_dict=None, batch=1, device="cuda", seeds=None, env_offset=0, freeze_done=True,
-                 auto_reset=False, variant=None, kernel="auto", binding="torch"):
+                 auto_reset=False, variant=None, kernel="auto", binding=None):
         if not torch.cuda.is_available():
             raise RuntimeError("BatchedFlightEnv needs a GPU: the HIP path has no CPU fallback")
         self._L = _lib.load()
+        if binding is None:   # an experimental library (COOPSEARCH_LIB) is only reachable through ctypes
+            binding = "ctypes" if os.environ.get("COOPSEARCH_LIB") else "torch"
         if binding not in ("torch", "ctypes"):
             raise ValueError("binding must be 'torch' (torch.ops.coopsearch, csrc/torch_ops.cpp) or 'ctypes'")
         self.binding = binding

@@ -563,6 +563,13 @@ void orc_batch_step(orc_batch *b, const int32_t *actions, float *reward, uint8_t
  * [T][B]; obs [T][B][n][obs_w]; state [T][B][4n+3m] (any output may be NULL). */
 void orc_batch_rollout(orc_batch *b, const int32_t *actions, int T, float *reward, uint8_t *terminated, uint8_t *win,
                        float *obs, float *state, int auto_reset, int freeze_done, int threads) {
+    orc_batch_rollout_rep(b, actions, T, 1, reward, terminated, win, obs, state, auto_reset, freeze_done, threads);
+}
+
+/* the same with the T-step action table walked `repeat` times inside the one parallel region (outputs overwritten each
+ * time): the timed baseline uses it so that the fork/join is paid once per repeat * T steps */
+void orc_batch_rollout_rep(orc_batch *b, const int32_t *actions, int T, int repeat, float *reward, uint8_t *terminated,
+                           uint8_t *win, float *obs, float *state, int auto_reset, int freeze_done, int threads) {
     const int n = b->c.n_agents, m = b->c.n_targets;
     const size_t obs_w = (size_t)n * (b->c.variant == 0 ? 4 : b->c.map_size * b->c.map_size + 4);
     const size_t st_w = (size_t)(4 * n + 3 * m);
@@ -570,7 +577,8 @@ void orc_batch_rollout(orc_batch *b, const int32_t *actions, int T, float *rewar
 #pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
     for (int64_t i = 0; i < b->n; i++) {
         orc_env *e = b->envs[i];
-        for (int s = 0; s < T; s++) {
+        for (int rs = 0; rs < repeat * T; rs++) {
+            const int s = rs % T;
             int done = (e->target_find >= m) || (e->time_step >= e->c.time_limit);
             int32_t r = 0, t = 1, w = e->win;
             if (done && auto_reset) {

@@ -88,6 +88,8 @@ void orc_batch_step(orc_batch *b, const int32_t *actions, float *reward, uint8_t
 /* T steps of every env in ONE OpenMP region, env-major; outputs [T][B][...] as T orc_batch_step calls would write */
 void orc_batch_rollout(orc_batch *b, const int32_t *actions, int T, float *reward, uint8_t *terminated, uint8_t *win,
                        float *obs, float *state, int auto_reset, int freeze_done, int threads);
+void orc_batch_rollout_rep(orc_batch *b, const int32_t *actions, int T, int repeat, float *reward, uint8_t *terminated,
+                           uint8_t *win, float *obs, float *state, int auto_reset, int freeze_done, int threads);
 orc_env *orc_batch_env(orc_batch *b, int64_t i);
 int orc_max_threads(void);
 

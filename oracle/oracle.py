@@ -96,6 +96,9 @@ def lib():
         L.orc_batch_rollout.argtypes = [vp, i32p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint8),
                                         C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int,
                                         C.c_int, C.c_int]
+        L.orc_batch_rollout_rep.argtypes = [vp, i32p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint8),
+                                            C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int,
+                                            C.c_int, C.c_int]
         L.orc_batch_env.restype = vp
         L.orc_batch_env.argtypes = [vp, C.c_int64]
         L.orc_max_threads.restype = C.c_int
@@ -326,9 +329,10 @@ class OracleBatch:
                              1 if auto_reset else 0, 1 if freeze_done else 0, threads)
         return self.reward, self.terminated, self.win
 
-    def rollout(self, actions, auto_reset=False, freeze_done=True, threads=1, out=None):
+    def rollout(self, actions, auto_reset=False, freeze_done=True, threads=1, out=None, repeat=1):
         """T steps in ONE OpenMP region (env-major): actions [T, B, n] -> dict of [T, B, ...] arrays (reused when
-        `out` is a dict from a previous call)."""
+        `out` is a dict from a previous call).  repeat > 1 walks the action table that many times inside the region
+        (outputs overwritten): the timed baseline's way of paying the fork/join once per repeat * T steps."""
         a = np.ascontiguousarray(actions, dtype=np.int32)
         T = a.shape[0]
         assert a.shape == (T, self.B, self.n)
@@ -336,9 +340,9 @@ class OracleBatch:
             out = dict(reward=np.zeros((T, self.B), np.float32), terminated=np.zeros((T, self.B), np.uint8),
                        win=np.zeros((T, self.B), np.uint8), obs=np.zeros((T, self.B, self.n, self.obs_w), np.float32),
                        state=np.zeros((T, self.B, 4 * self.n + 3 * self.m), np.float32))
-        lib().orc_batch_rollout(self._h, _p(a, C.c_int32), T, _p(out["reward"], C.c_float),
-                                _p(out["terminated"], C.c_uint8), _p(out["win"], C.c_uint8), _p(out["obs"], C.c_float),
-                                _p(out["state"], C.c_float), 1 if auto_reset else 0, 1 if freeze_done else 0, threads)
+        lib().orc_batch_rollout_rep(self._h, _p(a, C.c_int32), T, int(repeat), _p(out["reward"], C.c_float),
+                                    _p(out["terminated"], C.c_uint8), _p(out["win"], C.c_uint8), _p(out["obs"], C.c_float),
+                                    _p(out["state"], C.c_float), 1 if auto_reset else 0, 1 if freeze_done else 0, threads)
         self.reward, self.terminated, self.win = out["reward"][-1], out["terminated"][-1], out["win"][-1]
         self.obs, self.state = out["obs"][-1], out["state"][-1]
         return out

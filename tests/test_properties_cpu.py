@@ -75,3 +75,33 @@ def test_shard_partition(B, world):
     if cnt:
         seeds = csd.seeds_for(off, cnt)
         assert seeds[0] == (20240000 + off) % 2**32 and len(seeds) == cnt
+
+
+def test_oracle_rollout_region_equals_stepwise():
+    """orc_batch_rollout (one OpenMP region per T steps, env-major: bench.py's cpu_baseline leg) writes exactly what T
+    orc_batch_step calls write, whatever the thread count."""
+    import numpy as np
+    from oracle import oracle as orc
+    for variant, n, B, T in (("flight_easy", 3, 96, 60), ("flight", 3, 6, 12)):
+        cfg = orc.make_config(variant=variant, n_agents=n, time_limit=25)
+        seeds = (np.arange(B) + 5).astype(np.uint32)
+        acts = np.random.RandomState(0).randint(0, 3, size=(T, B, n)).astype(np.int32)
+        a, b = orc.OracleBatch(cfg, B, seeds), orc.OracleBatch(cfg, B, seeds)
+        a.reset(init=True)
+        b.reset(init=True)
+        out = b.rollout(acts, auto_reset=True, freeze_done=False, threads=3)
+        for t in range(T):
+            r, te, w = a.step(acts[t], auto_reset=True, freeze_done=False, threads=2)
+            assert np.array_equal(r, out["reward"][t]) and np.array_equal(te, out["terminated"][t])
+            assert np.array_equal(w, out["win"][t])
+            assert np.array_equal(a.state, out["state"][t]) and np.array_equal(a.obs, out["obs"][t])
+        # walking the table twice in one region == two calls
+        c = orc.OracleBatch(cfg, B, seeds)
+        c.reset(init=True)
+        c.rollout(acts, auto_reset=True, freeze_done=False, threads=1)
+        last = c.rollout(acts, auto_reset=True, freeze_done=False, threads=1)
+        d = orc.OracleBatch(cfg, B, seeds)
+        d.reset(init=True)
+        twice = d.rollout(acts, auto_reset=True, freeze_done=False, threads=2, repeat=2)
+        for k in ("reward", "state", "obs"):
+            assert np.array_equal(last[k], twice[k]), k
