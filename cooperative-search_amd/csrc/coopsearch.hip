@@ -151,8 +151,55 @@ constexpr int TAPE_STRIDE = CS_TAPE_STRIDE;  // dwords per env: 10 of bits | bas
 
 // np.random.rand() <= detect_prob for the draw made of stream words (wa, wb), exactly, in integers
 __device__ __forceinline__ bool draw_hits(const DevParams &p, unsigned wa, unsigned wb) {
-    const unsigned long long u = ((unsigned long long)(mt_temper(wa) >> 5) << 26) | (unsigned long long)(mt_temper(wb) >> 6);
-    return u <= p.detect_K;
+    // u = (a >> 5) * 2^26 + (b >> 6) <= K: decided by the first word unless its 27 bits equal K's top 27 (2^-27 of draws)
+    const unsigned hi = mt_temper(wa) >> 5, khi = (unsigned)(p.detect_K >> 26);
+    if (hi != khi) return hi < khi;
+    return (mt_temper(wb) >> 6) <= (unsigned)(p.detect_K & 0x3ffffffull);
+}
+
+// One wavefront, one env's MT19937 row held in LDS (`row`, 624 words): twist every word that is not yet twisted ahead of
+// the cursor -- words pos + a .. pos + 623 -- in place, and store the new words to the state blob `m` (mirror included).
+// Super-batches of 192 words: word j needs the stored words j, j+1, j+397, none of which another word of the same
+// super-batch writes (192 <= 227); within a wavefront LDS operations complete in order.
+__device__ __forceinline__ void row_twist_ahead(unsigned *row, unsigned *m, int pos, int a, int lane) {
+    while (a < MT_N) {   // wave-uniform
+        const int r = MT_N - a < 192 ? MT_N - a : 192;
+        const int g = wrap624(pos + a);
+        unsigned nw[3];
+        int idx[3];
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int j = wrap624(g + 64 * c + lane);
+            idx[c] = j;
+            nw[c] = mt_mix(row[j], row[wrap624(j + 1)], row[wrap624(j + MT_M)]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            if (64 * c + lane < r) {
+                row[idx[c]] = nw[c];
+                mt_store(m, idx[c], nw[c]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        a += r;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// hit bits of draw slots 64 * it .. 64 * it + 63 from the cursor of a fully twisted row in LDS (slot r = words pos + 2r,
+// pos + 2r + 1; pos is even, so the pair never straddles the end of the row)
+__device__ __forceinline__ unsigned long long row_slot_hits(const DevParams &p, const unsigned *row, int pos, int it, int lane) {
+    const int r = 64 * it + lane;
+    bool hit = false;
+    if (2 * r < MT_N) {
+        const int i0 = wrap624(pos + 2 * r);
+        hit = draw_hits(p, row[i0], row[i0 + 1]);
+    }
+    return __ballot(hit);
 }
 
 // The hit tape of one lane: bit r = "draw slot r from the cursor hits".  Shift by n slots (n < 320), dword barrel first.
@@ -1721,6 +1768,58 @@ __device__ __forceinline__ void lane_rebuild(const DevParams &p, int b0, int lan
     drain_vmem();   // rare path: joins the steady-state path with nothing of its own in flight
 }
 
+// In-loop refresh of the lane kernel (teams of up to 3): instead of a separate pre-pass over every row, each wavefront
+// tops up ONE of its 64 envs per step -- the one running lowest on twisted words: the env's row is requested at the end
+// of a step (ten coalesced dwords per lane, held in registers), and after the next step's kinematics the wavefront
+// copies it to LDS, twists everything that is not yet twisted (row_twist_ahead: new words go to the state blob) and
+// rebuilds the env's hit tape straight into its lane's registers (ballots).  Each env comes round about every 64 steps,
+// having consumed ~400 words: the MT19937 traffic (2.5 KB read + ~1.6 KB written per refresh) is spread under the
+// arithmetic of the whole rollout, and no lane waits for words.
+struct RowRegs {
+    unsigned w[10];   // lane l: words l + 64 i of the row
+};
+
+__device__ __forceinline__ void row_load(const unsigned *m, int lane, RowRegs &r) {
+#pragma unroll
+    for (int i = 0; i < 10; i++) r.w[i] = lane + 64 * i < MT_N ? m[lane + 64 * i] : 0u;
+}
+
+template <int N>
+__device__ __forceinline__ void lane_advance_finish(const DevParams &p, int b0, int lane, int src, const RowRegs &rr,
+                                                    unsigned *rowbuf, EnvL<N> &e, unsigned (&tape)[TAPE_DW]) {
+#pragma unroll
+    for (int i = 0; i < 10; i++)
+        if (lane + 64 * i < MT_N) rowbuf[lane + 64 * i] = rr.w[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int pos = __shfl(e.mt_pos, src);
+    const int a = __shfl(e.ahead, src);
+    row_twist_ahead(rowbuf, p.mt + (size_t)(b0 + src) * MT_STRIDE, pos, a < 0 ? 0 : a, lane);
+#pragma unroll
+    for (int it = 0; it < TAPE_DW / 2; it++) {
+        const unsigned long long bm = row_slot_hits(p, rowbuf, pos, it, lane);
+        if (lane == src) {
+            tape[2 * it] = (unsigned)(bm & 0xffffffffull);
+            tape[2 * it + 1] = (unsigned)(bm >> 32);
+        }
+    }
+    if (lane == src) e.ahead = MT_N;
+}
+
+// the same, start to finish, for every lane in `need` (kernel entry, or a lane that could not wait for its turn)
+template <int N>
+__device__ __forceinline__ void lane_advance_now(const DevParams &p, int b0, int lane, unsigned long long need, unsigned *rowbuf,
+                                                 EnvL<N> &e, unsigned (&tape)[TAPE_DW]) {
+    while (need) {
+        const int src = __ffsll((long long)need) - 1;
+        need &= need - 1;
+        RowRegs rr;
+        row_load(p.mt + (size_t)(b0 + src) * MT_STRIDE, lane, rr);
+        lane_advance_finish<N>(p, b0, lane, src, rr, rowbuf, e, tape);
+    }
+    drain_vmem();   // rare path: joins the steady-state path with nothing of its own in flight
+}
+
 // Ordering inside one step (gfx9 has ONE in-order counter for vector loads and stores: waiting for a load also waits
 // for every store issued before it): the only loads of the steady-state loop -- the next step's actions -- are requested
 // before the step's output stores, and the number of stores between any load and its use is a compile-time constant, so
@@ -1750,6 +1849,10 @@ __global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO i
     const int t16 = lane & (G - 1), gshift = lane & ~(G - 1), grp = lane >> 4;
     const unsigned tmask = p.n_targets >= 16 ? 0xffffu : ((1u << p.n_targets) - 1u);
     constexpr int LOW = 2 * N * CS_MAX_TARGETS;   // words one step can consume: every lane enters a step with that many twisted
+    constexpr bool REFRESH = N <= 3;              // in-loop refresh (above); larger teams rely on cs_rollout's pre-pass
+    unsigned *rowbuf = reinterpret_cast<unsigned *>(tiles + (size_t)(BLOCK / 64) * 64 * W) + wave * MT_N;
+    RowRegs rr;
+    int cand = -1;                                // env (lane) whose row is in flight in `rr`
     EnvL<N> e;
     int act[N];
     unsigned tape[TAPE_DW];
@@ -1763,9 +1866,14 @@ __global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO i
 #pragma unroll
         for (int k = 0; k < TAPE_DW; k++) tape[k] = 0u;
     }
-    while (const unsigned long long low = __ballot(live && (!tape_ok || e.ahead < LOW))) {
-        lane_rebuild<N>(p, b0, lane, low, e, tape);
-        tape_ok = true;
+    if (REFRESH) {   // (an advance also rebuilds a tape that does not match the cursor or the detection threshold)
+        const unsigned long long low = __ballot(live && (!tape_ok || e.ahead < LOW));
+        if (low) lane_advance_now<N>(p, b0, lane, low, rowbuf, e, tape);
+    } else {
+        while (const unsigned long long low = __ballot(live && (!tape_ok || e.ahead < LOW))) {
+            lane_rebuild<N>(p, b0, lane, low, e, tape);
+            tape_ok = true;
+        }
     }
     load_actions<N>(io, arow, act);
     const int rows_valid = b_end - b0 < 64 ? b_end - b0 : 64;
@@ -1800,6 +1908,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO i
         if (need) {
             if (VEC && !flushed) copy_chunks(0, Q, (size_t)(s - 1));   // the resets rewrite rows of the tile
             flushed = true;
+            if (REFRESH && cand >= 0 && ((need >> cand) & 1ull)) cand = -1;   // its cursor moves: the row in flight is void
             const bool mine = (need >> lane) & 1ull;
             const int my_rank = __popcll(need & ((1ull << lane) - 1ull));
             unsigned long long pend = need;
@@ -1864,7 +1973,15 @@ __global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO i
                 }
             }
             // a reset that ran past the twisted words leaves its lane without a tape for this step: rebuild
-            while (const unsigned long long low = __ballot(e.ahead < LOW)) lane_rebuild<N>(p, b0, lane, low, e, tape);
+            if (REFRESH) {
+                const unsigned long long low = __ballot(e.ahead < LOW);
+                if (low) {
+                    if (cand >= 0 && ((low >> cand) & 1ull)) cand = -1;
+                    lane_advance_now<N>(p, b0, lane, low, rowbuf, e, tape);
+                }
+            } else {
+                while (const unsigned long long low = __ballot(e.ahead < LOW)) lane_rebuild<N>(p, b0, lane, low, e, tape);
+            }
             drain_vmem();
         }
         // rows still to be written out: step s - 1's; after a flush (or at s = 0) the same chunks go to step s's own
@@ -1877,6 +1994,10 @@ __global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO i
         e.flags &= ~(FLAG_DIRTY | FLAG_RESET_PASS);
         if (stepping) kinematics_lane<N>(p, T, act, e);
         if (VEC) copy_chunks(0, Q / 3, cstep);
+        if (REFRESH && cand >= 0) {   // wave-uniform: the row requested a step ago has long arrived
+            lane_advance_finish<N>(p, b0, lane, cand, rr, rowbuf, e, tape);
+            cand = -1;
+        }
         LANE_STAMP(2);
         float4 f[N];
 #pragma unroll
@@ -1992,8 +2113,17 @@ __global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO i
             }
         }
         LANE_STAMP(5);
-        // ---- what the next step waits for, requested BEFORE this step's stores: the (rare) tape rebuild, the next actions
-        while (const unsigned long long low = __ballot(e.ahead < LOW)) lane_rebuild<N>(p, b0, lane, low, e, tape);
+        // ---- what the next step waits for, requested BEFORE this step's stores: the row of the env to refresh next (or,
+        //      rarely, an immediate advance / tape rebuild), the next actions
+        if (REFRESH) {
+            const unsigned long long low = __ballot(e.ahead < LOW);
+            if (low) lane_advance_now<N>(p, b0, lane, low, rowbuf, e, tape);
+            const unsigned long long urgent = __ballot(e.ahead < 192), normal = __ballot(e.ahead < 352);
+            cand = urgent ? __ffsll((long long)urgent) - 1 : (normal ? __ffsll((long long)normal) - 1 : -1);
+            if (cand >= 0) row_load(p.mt + (size_t)(b0 + cand) * MT_STRIDE, lane, rr);
+        } else {
+            while (const unsigned long long low = __ballot(e.ahead < LOW)) lane_rebuild<N>(p, b0, lane, low, e, tape);
+        }
         load_actions<N>(io, (size_t)(s + 1 < io.T ? s + 1 : s) * p.B + arow, act);
         LANE_STAMP(6);
         // ---- this step's outputs
@@ -2018,7 +2148,16 @@ __global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO i
         LANE_STAMP(7);
     }
     if (VEC) copy_chunks(0, Q, (size_t)(io.T - 1));
-    if (live) envl_store<N>(p, b, e);
+    if (live) {
+        envl_store<N>(p, b, e);
+        if (REFRESH) {   // the tape lives in registers here: leave it, rebased to the cursor, for the next launch
+            U4 *tp = reinterpret_cast<U4 *>(p.tape + (size_t)b * TAPE_STRIDE);
+            tp[0] = U4{tape[0], tape[1], tape[2], tape[3]};
+            tp[1] = U4{tape[4], tape[5], tape[6], tape[7]};
+            tp[2] = U4{tape[8], tape[9], (unsigned)(e.words & 0xffffffffull), (unsigned)(e.words >> 32)};
+            tp[3] = U4{(unsigned)(p.detect_K & 0xffffffffull), (unsigned)(p.detect_K >> 32), 0u, 0u};
+        }
+    }
 }
 
 
@@ -2298,43 +2437,14 @@ __global__ __launch_bounds__(256) void k_mt_advance(DevParams p, int min_ahead) 
     unsigned *row = rows[wave];
     const int pos = p.hdr[(size_t)b * CS_H_WORDS + CS_H_MT_POS];
     for (int i = lane; i < MT_N; i += 64) row[i] = m[i];
-    while (a < MT_N) {
-        const int r = MT_N - a < LANE_REFILL_MAX ? MT_N - a : LANE_REFILL_MAX;
-        const int g = wrap624(pos + a);
-        unsigned nw[3];
-        int idx[3];
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const int j = wrap624(g + 64 * c + lane);
-            idx[c] = j;
-            nw[c] = mt_mix(row[j], row[wrap624(j + 1)], row[wrap624(j + MT_M)]);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            if (64 * c + lane < r) {
-                row[idx[c]] = nw[c];
-                mt_store(m, idx[c], nw[c]);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        a += r;
-    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    row_twist_ahead(row, m, pos, a, lane);
     // hit tape: bit r = "the draw made of stream words 2r, 2r + 1 from the cursor hits" for all 312 slots of the row
     unsigned *tp = p.tape + (size_t)b * TAPE_STRIDE;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (int it = 0; it < TAPE_DW / 2; it++) {
-        const int r = 64 * it + lane;
-        bool hit = false;
-        if (2 * r < MT_N) {
-            const int i0 = wrap624(pos + 2 * r);   // even, so i0 + 1 <= 623
-            hit = draw_hits(p, row[i0], row[i0 + 1]);
-        }
-        const unsigned long long bm = __ballot(hit);
+        const unsigned long long bm = row_slot_hits(p, row, pos, it, lane);
         if (lane == 0) *reinterpret_cast<U2 *>(tp + 2 * it) = U2{(unsigned)(bm & 0xffffffffull), (unsigned)(bm >> 32)};
     }
     if (lane == 0) {
@@ -2507,7 +2617,8 @@ void launch_lane(const cs_config *cfg, const DevParams &p, StepIO io, size_t sme
 }
 inline size_t lane_smem(const cs_config *c) {
     const size_t W = 4 * (size_t)c->n_agents + 3 * (size_t)c->n_targets;
-    return ((TRIG_ROWS * TRIG_COLS * 8 + 15) / 16) * 16 + (BLOCK / 64) * 64 * W * sizeof(float);
+    return ((TRIG_ROWS * TRIG_COLS * 8 + 15) / 16) * 16 + (BLOCK / 64) * 64 * W * sizeof(float) +
+           (BLOCK / 64) * MT_N * sizeof(unsigned);   // + one MT19937 row per wavefront (in-loop refresh)
 }
 // Kernel choice for flight_easy: one env per 16-lane group (lowest latency, fills the chip from B = 4096) or one
 // env per lane (no replicated arithmetic; wins once the batch gives every SIMD a wavefront anyway).
@@ -2659,9 +2770,11 @@ int cs_rollout(const cs_config *cfg, void *state_dev, const void *actions_dev, i
         hipStream_t s = (hipStream_t)stream;
         const size_t n = (size_t)cfg->n_agents, W = 4 * n + 3 * (size_t)cfg->n_targets, B = (size_t)p.B;
         const size_t act_w = n * ((flags & CS_ACTIONS_I64) ? 8 : 4);
-        for (int t0 = 0; t0 < T; t0 += LANE_CHUNK) {
-            const int tc = T - t0 < LANE_CHUNK ? T - t0 : LANE_CHUNK;
-            if (tc >= 8)
+        // (teams of up to 3 refresh their rows inside the kernel, one env per wavefront and step: one launch, no pre-pass)
+        const int chunk = cfg->n_agents <= 3 ? T : LANE_CHUNK;
+        for (int t0 = 0; t0 < T; t0 += chunk) {
+            const int tc = T - t0 < chunk ? T - t0 : chunk;
+            if (tc >= 8 && cfg->n_agents > 3)
                 hipLaunchKernelGGL(k_mt_advance, dim3((unsigned)((p.B + 3) / 4)), dim3(256), 0, s, p, MT_N - 64);
             StepIO it{(const char *)actions_dev + (size_t)t0 * B * act_w, reward_dev + (size_t)t0 * B,
                       terminated_dev + (size_t)t0 * B, win_dev + (size_t)t0 * B,
