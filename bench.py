@@ -144,7 +144,7 @@ def kernel_label(env_name, n, B, mode, kernel):
         return f"k_rollout_lane<{n}>"
     if mode == "step":
         return f"k_step<{n},0>"
-    duo = kernel == "duo" or (kernel in ("auto", "group") and n <= 4 and B <= 6144)
+    duo = kernel == "duo" or (kernel in ("auto", "group") and n <= 6 and B <= 6144)
     return f"k_rollout_duo<{n}>" if duo else f"k_rollout<{n}>"
 
 
@@ -211,11 +211,17 @@ def cpu_baseline(env_name, n, batch, budget_s=10.0):
                 scaling["1"] = B * T / (time.perf_counter() - t0)
             else:
                 scaling[str(th)] = run(th, 1)[0]
-        best = max(cands, key=lambda th: scaling[str(th)])
-        per = B * T * R / scaling[str(best)]
-        reps = int(max(2, min(5000, budget_s / max(per, 1e-6))))
-        value, dt = run(best, reps)
-        scaling[str(best)] = value
+        # the two best calibration points share the budget (one-region calibrations are noisy at high thread counts);
+        # the better sustained rate is the reported value
+        top = sorted(cands, key=lambda th: scaling[str(th)], reverse=True)[:2]
+        value, dt, best, reps = 0.0, 0.0, top[0], 0
+        for th in top:
+            per = B * T * R / scaling[str(th)]
+            n_rep = int(max(2, min(5000, 0.5 * budget_s / max(per, 1e-6))))
+            v, d = run(th, n_rep)
+            scaling[str(th)] = v
+            if v > value:
+                value, dt, best, reps = v, d, th, n_rep
     finally:
         orc.set_exact_pow(True)
     single = scaling["1"]
@@ -528,8 +534,10 @@ def main():
                 side_measurement(cs, dev, comm, "c3 flight_easy 5a15t B=16384", "flight_easy", 5, 16384, "rollout",
                                  1000, 100, "auto"),
                 side_measurement(cs, dev, comm, "c4 flight 3a15t B=8192", "flight", 3, 8192, "step", 400, 100, "auto"),
-                side_measurement(cs, dev, comm, "flight_easy 3a15t B=262144 (lane-per-env kernel; batch sweep asymptote)",
+                side_measurement(cs, dev, comm, "flight_easy 3a15t B=262144 (lane-per-env kernel: the HBM-regime kernel)",
                                  "flight_easy", 3, 262144, "rollout", 200, 100, "lane"),
+                side_measurement(cs, dev, comm, "flight_easy 3a15t B=1048576 (lane-per-env kernel; batch sweep asymptote)",
+                                 "flight_easy", 3, 1048576, "rollout", 100, 100, "lane"),
                 closed_loop_measurement(cs, dev, 3, 4096, 2000, 200),
                 closed_loop_measurement(cs, dev, 3, 65536, 400, 100),
                 closed_loop_measurement(cs, dev, 3, 8192, 400, 100, "flight"),

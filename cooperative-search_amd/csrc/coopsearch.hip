@@ -2629,8 +2629,17 @@ inline bool use_lane_kernel(const cs_config *c, int flags) {
 }
 
 // 16-lanes-per-env rollout: the kinematics / detection wavefront pair wins while the batch leaves a wave slot per SIMD
-// empty (measured: 3 agents, B = 4096: 1.53e9 vs 1.44e9 env-steps/s; B = 16384: 1.69e9 vs 2.37e9)
-inline bool duo_pays(const cs_config *c) { return c->n_agents <= 4 && c->batch <= 6144; }
+// empty (profiles/r02_batch_sweep.md: 3 agents, B = 4096: 1.59e9 vs 1.49e9 env-steps/s, B = 16384: 1.69e9 vs 2.43e9;
+// 5 agents, B = 4096: 1.07e9 vs 0.89e9, B = 16384: 1.14e9 vs 1.43e9; teams of 7 and 8 spill in the pair)
+inline bool duo_pays(const cs_config *c) { return c->n_agents <= 6 && c->batch <= 6144; }
+
+// Rows with at least this many twisted words ahead are left alone by the pre-pass of a T-step rollout: enough for the
+// typical draw rate (two words per draw, a few draws per step) with a step's worst case in reserve.  Short rollouts
+// then advance each row only every few calls instead of touching all of them every time.
+inline int prepass_min_ahead(const cs_config *c, int T) {
+    const long long want = 2ll * c->n_agents * CS_MAX_TARGETS + 64 + 4ll * c->n_agents * T;
+    return (int)(want < MT_N - 64 ? want : MT_N - 64);
+}
 
 inline unsigned env_blocks(const DevParams &p) { return (unsigned)(((size_t)p.B * G + BLOCK - 1) / BLOCK); }
 
@@ -2775,7 +2784,7 @@ int cs_rollout(const cs_config *cfg, void *state_dev, const void *actions_dev, i
         for (int t0 = 0; t0 < T; t0 += chunk) {
             const int tc = T - t0 < chunk ? T - t0 : chunk;
             if (tc >= 8 && cfg->n_agents > 3)
-                hipLaunchKernelGGL(k_mt_advance, dim3((unsigned)((p.B + 3) / 4)), dim3(256), 0, s, p, MT_N - 64);
+                hipLaunchKernelGGL(k_mt_advance, dim3((unsigned)((p.B + 3) / 4)), dim3(256), 0, s, p, prepass_min_ahead(cfg, tc));
             StepIO it{(const char *)actions_dev + (size_t)t0 * B * act_w, reward_dev + (size_t)t0 * B,
                       terminated_dev + (size_t)t0 * B, win_dev + (size_t)t0 * B,
                       obs_dev ? obs_dev + (size_t)t0 * B * n * 4 : nullptr,
@@ -2784,11 +2793,13 @@ int cs_rollout(const cs_config *cfg, void *state_dev, const void *actions_dev, i
         }
     } else if ((flags & CS_KERNEL_SOLO) || ((flags & CS_KERNEL_DUO) == 0 && !duo_pays(cfg))) {
         if (T >= 8 && cfg->n_agents <= 4)
-            hipLaunchKernelGGL(k_mt_advance, dim3((unsigned)((p.B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, MT_N - 64);
+            hipLaunchKernelGGL(k_mt_advance, dim3((unsigned)((p.B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p,
+                               prepass_min_ahead(cfg, T));
         CS_DISPATCH_N(cfg->n_agents,
                       hipLaunchKernelGGL(k_rollout<N>, dim3(env_blocks(p)), dim3(BLOCK), 0, (hipStream_t)stream, p, io));
     } else {
-        if (T >= 8) hipLaunchKernelGGL(k_mt_advance, dim3((unsigned)((p.B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, MT_N - 64);
+        if (T >= 8) hipLaunchKernelGGL(k_mt_advance, dim3((unsigned)((p.B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p,
+                               prepass_min_ahead(cfg, T));
         CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_rollout_duo<N>, dim3((unsigned)((p.B + 15) / 16)), dim3(DUO_BLOCK),
                                                         0, (hipStream_t)stream, p, io));
     }

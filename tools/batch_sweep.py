@@ -1,13 +1,15 @@
 """Batch sweep of the flight_easy rollout kernels (SURVEY.md section 8d asks for 2^12..2^22): env-steps/s and the
-algorithmic-bytes roofline fraction per batch size, group vs lane kernel.  Writes a markdown table."""
+algorithmic-bytes roofline fraction per batch size, solo / duo (16 lanes per env) vs lane kernel.  Writes a markdown table."""
 import json, subprocess, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rows = []
 for n in (3, 5):
     for logb in range(10, 21, 2):
         B = 1 << logb
-        for kernel in ("group", "lane"):
-            if kernel == "group" and B > (1 << 18):
+        for kernel in ("solo", "duo", "lane"):
+            if kernel != "lane" and B > (1 << 18):
+                continue
+            if kernel == "duo" and B > (1 << 14):
                 continue
             steps = 400 if B >= (1 << 18) else 1000
             out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-also",
