@@ -190,6 +190,24 @@ __device__ __forceinline__ void row_twist_ahead(unsigned *row, unsigned *m, int 
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+struct RowRegs {
+    unsigned w[10];   // lane l: words l + 64 i of the row
+};
+
+__device__ __forceinline__ void row_load(const unsigned *m, int lane, RowRegs &r) {
+#pragma unroll
+    for (int i = 0; i < 10; i++) r.w[i] = lane + 64 * i < MT_N ? m[lane + 64 * i] : 0u;
+}
+
+// row registers -> LDS (`row`: 624 words owned by this wavefront)
+__device__ __forceinline__ void row_to_lds(const RowRegs &r, unsigned *row, int lane) {
+#pragma unroll
+    for (int i = 0; i < 10; i++)
+        if (lane + 64 * i < MT_N) row[lane + 64 * i] = r.w[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // hit bits of draw slots 64 * it .. 64 * it + 63 from the cursor of a fully twisted row in LDS (slot r = words pos + 2r,
 // pos + 2r + 1; pos is even, so the pair never straddles the end of the row)
 __device__ __forceinline__ unsigned long long row_slot_hits(const DevParams &p, const unsigned *row, int pos, int it, int lane) {
@@ -512,6 +530,49 @@ __device__ __forceinline__ int detect_pass_tape(const DevParams &p, int b, int t
     e.ahead -= 2 * base;
     tape_shift<MAXDW>(tape, base);
     return detect_finish<N>(p, t, gshift, e, hit);
+}
+
+// Prologue of the 16-lane rollout kernels: the wavefront tops up the MT19937 rows of its (up to) four envs that have
+// fewer than `min_ahead` twisted words left or no matching tape -- whole wavefront on one row at a time, exactly what
+// k_mt_advance does, but without a launch of its own -- and hands the new tape to the env's 16 lanes by ballot.
+template <int N>
+__device__ __forceinline__ void group_wave_advance(const DevParams &p, int wave_b0, int nvalid, int lane, int min_ahead,
+                                                   unsigned *rowbuf, Env<N> &e, unsigned (&tape)[TAPE_DW], bool &tape_ok) {
+    const int grp = lane >> 4;
+#pragma unroll 1
+    for (int g = 0; g < 4; g++) {
+        const int pos = __shfl(e.mt_pos, 16 * g), a = __shfl(e.ahead, 16 * g);
+        const int ok = __shfl(tape_ok ? 1 : 0, 16 * g);
+        if (g >= nvalid || (ok && a >= min_ahead)) continue;   // wave-uniform
+        unsigned *m = p.mt + (size_t)(wave_b0 + g) * MT_STRIDE;
+        RowRegs rr;
+        row_load(m, lane, rr);
+        row_to_lds(rr, rowbuf, lane);
+        row_twist_ahead(rowbuf, m, pos, a < 0 ? 0 : a, lane);
+#pragma unroll
+        for (int it = 0; it < TAPE_DW / 2; it++) {
+            const unsigned long long bm = row_slot_hits(p, rowbuf, pos, it, lane);
+            if (grp == g) {
+                tape[2 * it] = (unsigned)(bm & 0xffffffffull);
+                tape[2 * it + 1] = (unsigned)(bm >> 32);
+            }
+        }
+        if (grp == g) {
+            e.ahead = MT_N;
+            tape_ok = true;
+        }
+    }
+    drain_vmem();
+}
+
+// ... and their epilogue: the tape (in registers, aligned to the cursor) goes back to the state blob for the next launch
+template <int N>
+__device__ __forceinline__ void group_tape_store(const DevParams &p, int b, int t, const Env<N> &e, const unsigned (&tape)[TAPE_DW]) {
+    U4 *tp = reinterpret_cast<U4 *>(p.tape + (size_t)b * TAPE_STRIDE);
+    if (t == 0) tp[0] = U4{tape[0], tape[1], tape[2], tape[3]};
+    if (t == 1) tp[1] = U4{tape[4], tape[5], tape[6], tape[7]};
+    if (t == 2) tp[2] = U4{tape[8], tape[9], (unsigned)(e.words & 0xffffffffull), (unsigned)(e.words >> 32)};
+    if (t == 3) tp[3] = U4{(unsigned)(p.detect_K & 0xffffffffull), (unsigned)(p.detect_K >> 32), 0u, 0u};
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -858,6 +919,7 @@ struct StepIO {
     float *obs, *state;   // [T][B][...]
     int flags, T;
     int env0, env_n;      // lane kernel: this launch covers envs [env0, env0 + env_n)
+    int min_ahead;        // 16-lane rollout kernels: rows with fewer twisted words than this are topped up in the prologue
 };
 
 // int32 actions, or the low dword of little-endian int64 actions (values 0..2): one branch-free strided read
@@ -982,8 +1044,8 @@ template <int N, int VARIANT>
 __device__ __forceinline__ void step_once(const DevParams &p, const double *T, const StepIO &io, WaveTile &tile, int b,
                                           int lane, size_t slot0, const EmitPlan<N> &plan, bool live, const int (&act)[N],
                                           MtWin &win, bool prefetch_next, bool flush_prev, size_t prev_slot0,
-                                          bool defer_flush, Env<N> &e, unsigned (*tape)[TAPE_DW] = nullptr,
-                                          bool tape_ok = false) {
+                                          bool defer_flush, Env<N> &e, unsigned (&tape)[TAPE_DW], const bool use_tape,
+                                          bool tape_ok) {
     const int t = lane & (G - 1), grp = lane >> 4, gshift = lane & ~(G - 1);
     int reward = 0;
     bool term = true;
@@ -1005,9 +1067,9 @@ __device__ __forceinline__ void step_once(const DevParams &p, const double *T, c
                 e.flags |= FLAG_RESET_PASS;
             }
             env_store<N>(p, b, t, e, true);  // targets changed
-            if (tape) {   // the draw slots the reset consumed leave the tape
+            if (use_tape) {   // the draw slots the reset consumed leave the tape
                 const unsigned long long used = e.words - words_before;
-                tape_shift<8>(*tape, used < 2ull * 319ull ? (int)(used >> 1) : 319);
+                tape_shift<8>(tape, used < 2ull * 319ull ? (int)(used >> 1) : 319);
             } else {
                 win = mt_prefetch(p.mt + (size_t)b * MT_STRIDE, e.mt_pos, t);
             }
@@ -1018,7 +1080,7 @@ __device__ __forceinline__ void step_once(const DevParams &p, const double *T, c
             CS_STAMP(1);
             kinematics_group<N, VARIANT>(p, T, tile, act, t, grp, e);
             CS_STAMP(2);
-            reward = tape ? detect_pass_tape<N>(p, b, t, gshift, e, *tape, tape_ok) : detect_pass<N>(p, b, t, gshift, e, win);
+            reward = use_tape ? detect_pass_tape<N>(p, b, t, gshift, e, tape, tape_ok) : detect_pass<N>(p, b, t, gshift, e, win);
             CS_STAMP(3);
             e.total_reward += reward;
             e.time_step += 1;
@@ -1027,7 +1089,7 @@ __device__ __forceinline__ void step_once(const DevParams &p, const double *T, c
             env_trig<N>(T, e);  // frozen env: re-emit the unchanged observation
         }
         // the next step's window does not overlap the words just committed: request it before this step's stores
-        if (prefetch_next && !tape) win = mt_prefetch(p.mt + (size_t)b * MT_STRIDE, e.mt_pos, t);
+        if (prefetch_next && !use_tape) win = mt_prefetch(p.mt + (size_t)b * MT_STRIDE, e.mt_pos, t);
     }
     CS_STAMP(4);
     if (flush_prev) emit_flush_store<N>(p, io, plan, fr, prev_slot0);
@@ -1061,7 +1123,9 @@ __global__ __launch_bounds__(BLOCK) void k_step(DevParams p, StepIO io) {
     MtWin win = {0u, 0u};
     if (live) win = mt_prefetch(p.mt + (size_t)b * MT_STRIDE, e.mt_pos, t);
     const EmitPlan<N> plan = make_emit_plan<N>(p, lane, nvalid);
-    step_once<N, VARIANT>(p, T, io, tiles[threadIdx.x >> 6], b, lane, (size_t)wave_b0, plan, live, act, win, false, false, 0, false, e);
+    unsigned no_tape[TAPE_DW];   // single steps twist their words on demand
+    step_once<N, VARIANT>(p, T, io, tiles[threadIdx.x >> 6], b, lane, (size_t)wave_b0, plan, live, act, win, false, false, 0, false, e,
+                          no_tape, false, false);
     if (live) env_store<N>(p, b, t, e, false);
 }
 
@@ -1071,6 +1135,7 @@ template <int N>
 __global__ __launch_bounds__(BLOCK) void k_rollout(DevParams p, StepIO io) {
     __shared__ double T[TRIG_ROWS * TRIG_COLS];
     __shared__ WaveTile tiles[BLOCK / 64];
+    __shared__ unsigned rowbufs[N <= 4 ? BLOCK / 64 : 1][N <= 4 ? MT_N : 1];   // one MT19937 row per wavefront (prologue)
     const int gid = blockIdx.x * BLOCK + threadIdx.x;
     const int b = gid / G, t = gid % G;
     const int lane = threadIdx.x & 63;
@@ -1094,7 +1159,10 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(DevParams p, StepIO io) {
     constexpr bool USE_TAPE = N <= 4;
     unsigned tape[TAPE_DW];
     bool tape_ok = false;
-    if (USE_TAPE && live) tape_ok = tape_load(p, b, e, tape);
+    if (USE_TAPE) {
+        if (live) tape_ok = tape_load(p, b, e, tape);
+        group_wave_advance<N>(p, wave_b0, nvalid, lane, io.min_ahead, rowbufs[N <= 4 ? threadIdx.x >> 6 : 0], e, tape, tape_ok);
+    }
     if (!USE_TAPE && live) win = mt_prefetch(p.mt + (size_t)b * MT_STRIDE, e.mt_pos, t);
     for (int s = 0; s < io.T; s++) {
         int act_next[N];
@@ -1102,7 +1170,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(DevParams p, StepIO io) {
         load_actions<N>(io, (size_t)sn * p.B + (live ? b : 0), act_next);
         // n <= 4: the rows of step s are stored while step s+1 computes (costs ~12 VGPRs; larger teams have none spare)
         step_once<N, 0>(p, T, io, tile, b, lane, (size_t)s * p.B + wave_b0, plan, live, act, win, s + 1 < io.T,
-                        PIPE && s > 0, (size_t)(s - 1) * p.B + wave_b0, PIPE, e, USE_TAPE ? &tape : nullptr, tape_ok);
+                        PIPE && s > 0, (size_t)(s - 1) * p.B + wave_b0, PIPE, e, tape, USE_TAPE, tape_ok);
 #pragma unroll
         for (int i = 0; i < N; i++) act[i] = act_next[i];
     }
@@ -1111,7 +1179,10 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(DevParams p, StepIO io) {
         emit_flush_load<N>(tile, plan, fr);
         emit_flush_store<N>(p, io, plan, fr, (size_t)(io.T - 1) * p.B + wave_b0);
     }
-    if (live) env_store<N>(p, b, t, e, false);
+    if (live) {
+        env_store<N>(p, b, t, e, false);
+        if (USE_TAPE && tape_ok) group_tape_store<N>(p, b, t, e, tape);
+    }
 }
 
 // =========================================================================================================
@@ -1146,6 +1217,7 @@ __global__ __launch_bounds__(DUO_BLOCK) void k_rollout_duo(DevParams p, StepIO i
     __shared__ WaveTile tiles[DUO_BLOCK / 64];   // K waves use .trig, D waves the emission rows
     __shared__ KinSlot<N> slots[2][16];
     __shared__ unsigned fix[2][4];               // [step parity][pair]: groups whose termination K mispredicted
+    __shared__ unsigned rowbufs[4][MT_N];        // one MT19937 row per D wavefront (prologue top-up)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool is_k = wave < 4;
     const int pw = wave & 3;                     // wave pair = 4 envs
@@ -1257,9 +1329,10 @@ __global__ __launch_bounds__(DUO_BLOCK) void k_rollout_duo(DevParams p, StepIO i
     const bool wave_valid = nvalid > 0;
     const EmitPlan<N> plan = make_emit_plan<N>(p, lane, wave_valid ? nvalid : 1);
     constexpr bool PIPE = N <= 4;
-    unsigned tape[TAPE_DW];   // the env's hit tape (cs_mt_advance), replicated in the group's lanes
+    unsigned tape[TAPE_DW];   // the env's hit tape, replicated in the group's lanes
     bool tape_ok = false;
     if (live) tape_ok = tape_load(p, b, e, tape);
+    group_wave_advance<N>(p, wave_b0, nvalid, lane, io.min_ahead, rowbufs[pw], e, tape, tape_ok);   // while K produces step 0
     if (threadIdx.x == 4 * 64) {
 #pragma unroll
         for (int q = 0; q < 8; q++) (&fix[0][0])[q] = 0u;
@@ -1336,6 +1409,7 @@ __global__ __launch_bounds__(DUO_BLOCK) void k_rollout_duo(DevParams p, StepIO i
                           (int)e.newly_reset);
         p.ahead[b] = e.ahead;
     }
+    if (live && tape_ok) group_tape_store<N>(p, b, t, e, tape);
 }
 
 // =========================================================================================================
@@ -1427,6 +1501,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io
     emit_deposit<N>(p, tile, t, grp, live, e, 0, false);
     MtWin win = {0u, 0u};
     if (live) win = mt_prefetch(p.mt + (size_t)b * MT_STRIDE, e.mt_pos, t);
+    unsigned no_tape[TAPE_DW];   // the closed loop twists its words on demand
     const int in_dim = 4 + NA + N;
 
     for (int s = 0; s < io.T; s++) {
@@ -1539,7 +1614,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io
         for (int i = 0; i < N; i++) act[i] = s_act[el * N + i];
         if (wave_valid)
             step_once<N, 0>(p, T, io, tile, b, lane, (size_t)s * p.B + wave_b0, plan, live, act, win, s + 1 < io.T,
-                            PIPE && s > 0, (size_t)(s - 1) * p.B + wave_b0, PIPE, e);
+                            PIPE && s > 0, (size_t)(s - 1) * p.B + wave_b0, PIPE, e, no_tape, false, false);
     }
     if (PIPE && wave_valid) {  // rows of the last step
         FlushRegs<N> fr;
@@ -1775,23 +1850,10 @@ __device__ __forceinline__ void lane_rebuild(const DevParams &p, int b0, int lan
 // rebuilds the env's hit tape straight into its lane's registers (ballots).  Each env comes round about every 64 steps,
 // having consumed ~400 words: the MT19937 traffic (2.5 KB read + ~1.6 KB written per refresh) is spread under the
 // arithmetic of the whole rollout, and no lane waits for words.
-struct RowRegs {
-    unsigned w[10];   // lane l: words l + 64 i of the row
-};
-
-__device__ __forceinline__ void row_load(const unsigned *m, int lane, RowRegs &r) {
-#pragma unroll
-    for (int i = 0; i < 10; i++) r.w[i] = lane + 64 * i < MT_N ? m[lane + 64 * i] : 0u;
-}
-
 template <int N>
 __device__ __forceinline__ void lane_advance_finish(const DevParams &p, int b0, int lane, int src, const RowRegs &rr,
                                                     unsigned *rowbuf, EnvL<N> &e, unsigned (&tape)[TAPE_DW]) {
-#pragma unroll
-    for (int i = 0; i < 10; i++)
-        if (lane + 64 * i < MT_N) rowbuf[lane + 64 * i] = rr.w[i];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    row_to_lds(rr, rowbuf, lane);
     const int pos = __shfl(e.mt_pos, src);
     const int a = __shfl(e.ahead, src);
     row_twist_ahead(rowbuf, p.mt + (size_t)(b0 + src) * MT_STRIDE, pos, a < 0 ? 0 : a, lane);
@@ -2792,14 +2854,11 @@ int cs_rollout(const cs_config *cfg, void *state_dev, const void *actions_dev, i
             CS_DISPATCH_N(cfg->n_agents, launch_lane<N>(cfg, p, it, lane_smem(cfg), s));
         }
     } else if ((flags & CS_KERNEL_SOLO) || ((flags & CS_KERNEL_DUO) == 0 && !duo_pays(cfg))) {
-        if (T >= 8 && cfg->n_agents <= 4)
-            hipLaunchKernelGGL(k_mt_advance, dim3((unsigned)((p.B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p,
-                               prepass_min_ahead(cfg, T));
+        io.min_ahead = prepass_min_ahead(cfg, T);   // rows are topped up in the kernels' prologue: no pre-pass launch
         CS_DISPATCH_N(cfg->n_agents,
                       hipLaunchKernelGGL(k_rollout<N>, dim3(env_blocks(p)), dim3(BLOCK), 0, (hipStream_t)stream, p, io));
     } else {
-        if (T >= 8) hipLaunchKernelGGL(k_mt_advance, dim3((unsigned)((p.B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p,
-                               prepass_min_ahead(cfg, T));
+        io.min_ahead = prepass_min_ahead(cfg, T);
         CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_rollout_duo<N>, dim3((unsigned)((p.B + 15) / 16)), dim3(DUO_BLOCK),
                                                         0, (hipStream_t)stream, p, io));
     }
