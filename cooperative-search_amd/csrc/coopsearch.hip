@@ -970,22 +970,33 @@ __device__ __forceinline__ EmitPlan<N> make_emit_plan(const DevParams &p, int la
 //   emit_deposit: every live lane writes its pieces of step s into the tile (end of step s);
 //   emit_flush:   all 64 lanes read the tile back and store it (called at the start of step s+1, or right away by
 //                 the single-step kernel).  slot0 = output slot of the wavefront's first env for the deposited step.
-template <int N>
+template <int N, bool SELECT = true>
 __device__ __forceinline__ void emit_deposit(const DevParams &p, WaveTile &tile, int t, int grp, bool live, const Env<N> &e,
                                              int reward, bool term) {
     if (live) {
-        // lane i < N deposits agent i: picked with selects (an indexed read would put the arrays in scratch)
-        double mx = 0.0, my = 0.0, mc = 0.0, ms = 0.0;
+        if (SELECT) {
+            // lane i < N deposits agent i, picked with selects: in the two-role kernel the compiler turns the branchy
+            // form below into an indexed read (agent arrays in scratch), and k_rollout<5> needs 5 VGPRs more with it
+            // (258: one wavefront per SIMD instead of two)
+            double mx = 0.0, my = 0.0, mc = 0.0, ms = 0.0;
 #pragma unroll
-        for (int i = 0; i < N; i++) {
-            mx = t == i ? e.ax[i] : mx;
-            my = t == i ? e.ay[i] : my;
-            mc = t == i ? e.cs[i] : mc;
-            ms = t == i ? e.sn[i] : ms;
+            for (int i = 0; i < N; i++) {
+                mx = t == i ? e.ax[i] : mx;
+                my = t == i ? e.ay[i] : my;
+                mc = t == i ? e.cs[i] : mc;
+                ms = t == i ? e.sn[i] : ms;
+            }
+            if (t < N)
+                *reinterpret_cast<float4 *>(&tile.row[grp][4 * t]) =
+                    make_float4((float)((mx - p.mid) * p.inv_half), (float)((my - p.mid) * p.inv_half), (float)mc, (float)ms);
+        } else {
+#pragma unroll
+            for (int i = 0; i < N; i++)
+                if (t == i)
+                    *reinterpret_cast<float4 *>(&tile.row[grp][4 * i]) =
+                        make_float4((float)((e.ax[i] - p.mid) * p.inv_half), (float)((e.ay[i] - p.mid) * p.inv_half),
+                                    (float)e.cs[i], (float)e.sn[i]);
         }
-        if (t < N)
-            *reinterpret_cast<float4 *>(&tile.row[grp][4 * t]) =
-                make_float4((float)((mx - p.mid) * p.inv_half), (float)((my - p.mid) * p.inv_half), (float)mc, (float)ms);
         if (t < p.n_targets) {
             tile.row[grp][4 * N + 3 * t + 0] = e.ntx;
             tile.row[grp][4 * N + 3 * t + 1] = e.nty;
@@ -1165,6 +1176,8 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(DevParams p, StepIO io) {
     }
     if (!USE_TAPE && live) win = mt_prefetch(p.mt + (size_t)b * MT_STRIDE, e.mt_pos, t);
     for (int s = 0; s < io.T; s++) {
+        // (no in-loop top-up here: it would push this kernel past 256 VGPRs and cost its second wavefront per SIMD; an env
+        // that exhausts its row falls back to twisting on demand until the next launch's prologue)
         int act_next[N];
         const int sn = s + 1 < io.T ? s + 1 : s;
         load_actions<N>(io, (size_t)sn * p.B + (live ? b : 0), act_next);
@@ -1344,6 +1357,9 @@ __global__ __launch_bounds__(DUO_BLOCK) void k_rollout_duo(DevParams p, StepIO i
         bool term = true, mispredicted = false;
         FlushRegs<N> fr;
         DUO_STAMP(8);
+        // a row that is about to run out of twisted words is topped up in place (about once per env and 80 steps)
+        if (__ballot(live && tape_ok && e.ahead < 2 * N * CS_MAX_TARGETS))
+            group_wave_advance<N>(p, wave_b0, nvalid, lane, 2 * N * CS_MAX_TARGETS, rowbufs[pw], e, tape, tape_ok);
         if (PIPE && s > 0 && wave_valid) emit_flush_load<N>(tile, plan, fr);
         if (live) {
             bool done = e.target_find >= p.n_targets || e.time_step >= p.time_limit;
@@ -1385,7 +1401,7 @@ __global__ __launch_bounds__(DUO_BLOCK) void k_rollout_duo(DevParams p, StepIO i
             if (lane == 0) fix[s & 1][pw] = m4;
         }
         if (PIPE && s > 0 && wave_valid) emit_flush_store<N>(p, io, plan, fr, (size_t)(s - 1) * p.B + wave_b0);
-        emit_deposit<N>(p, tile, t, grp, live, e, reward, term);
+        emit_deposit<N, true>(p, tile, t, grp, live, e, reward, term);
         if (!PIPE && wave_valid) {
             emit_flush_load<N>(tile, plan, fr);
             emit_flush_store<N>(p, io, plan, fr, slot0);

@@ -633,3 +633,35 @@ def test_mt_advance_changes_when_not_what():
     r1, r2 = raw_state(e1), raw_state(e2)
     for k in ("tgt", "agent", "hdr", "mt"):
         assert torch.equal(r1[k], r2[k]), k
+
+
+def test_flight_c4_scale_auto_reset_matches_oracle():
+    """BASELINE config 4's variant at B = 1024 (the oracle's flight step costs ~20 us per env and thread): 200 steps with
+    auto-reset through the default episode length, every integer compared every step, the 2504-wide observation
+    (map first) every 25 steps, the full raw state at the end."""
+    B, n, T, m = 1024, 3, 200, 15
+    seeds = np.arange(B, dtype=np.uint32) + 4040
+    args = cs.make_env_args("flight", n_agents=n)
+    args.time_limit = 60   # three full episodes per env: resets (map kept, quirk Q9) inside the horizon
+    env = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, freeze_done=False, auto_reset=True)
+    env.seed(seeds)
+    env.reset(init=True)
+    cfg = orc.make_config(variant="flight", n_agents=n, time_limit=60)
+    rng = np.random.RandomState(44)
+    with orc.hip_equivalent_arithmetic():
+        ob = orc.OracleBatch(cfg, B, seeds)
+        ob.reset(init=True, threads=8)
+        for t in range(T):
+            a = rng.randint(0, 3, size=(B, n)).astype(np.int32)
+            r, term, win = env.step(torch.from_numpy(a))
+            emit = t % 25 == 24 or t == T - 1
+            orr, ot, ow = ob.step(a, auto_reset=True, freeze_done=False, threads=8, emit=emit)
+            np.testing.assert_array_equal(r.cpu().numpy(), orr, err_msg=f"reward step {t}")
+            np.testing.assert_array_equal(term.cpu().numpy().astype(np.uint8), ot)
+            np.testing.assert_array_equal(win.cpu().numpy().astype(np.uint8), ow)
+            if emit:
+                np.testing.assert_allclose(env.get_obs().cpu().numpy(), ob.obs, rtol=0, atol=F32_TOL,
+                                           err_msg=f"obs (map + feats) step {t}")
+                np.testing.assert_allclose(env.get_state().cpu().numpy(), ob.state, rtol=0, atol=F32_TOL)
+        compare_with_oracle(env, ob, B, n, m, "flight B=1024 auto-reset")
+        assert hdr(env)[:, _lib.H_EPISODES].min() >= 3
