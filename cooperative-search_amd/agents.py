@@ -7,6 +7,8 @@ device.  `AgentRNN` has the reference architecture and parameter names (network/
 GRUCell -> fc2), so the reference's `*_rnn_net_params.pkl` state_dicts load unchanged.  Stock torch modules: nothing
 custom is needed on ROCm for a 64-wide GRU.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -127,6 +129,8 @@ class FusedAgents:
             raise ValueError("FusedAgents: rnn_hidden_dim must be 64, obs_shape 4 and 4 + n_actions + n_agents <= 16")
         self._C, self._lib = C, _lib
         self._L = _lib.load()
+        # torch.ops.coopsearch.* (checks in C++, torch's stream) unless an experimental library is selected
+        self._ops = None if os.environ.get("COOPSEARCH_LIB") else _lib.torch_ops()
         self.args, self.batch, self.device = args, int(batch), torch.device(device)
         self.n_agents, self.n_actions, self.cells = args.n_agents, args.n_actions, cells
         self.rows = self.batch * self.n_agents
@@ -167,6 +171,9 @@ class FusedAgents:
             raise self._lib.CoopSearchError(self._L.cs_policy_last_error().decode())
 
     def _conv_features(self, maps, map_stride, n_maps, feat):
+        if self._ops is not None:
+            self._ops.policy_conv_features(*self.conv_w, maps, int(map_stride), int(n_maps), feat)
+            return
         vp = lambda t: self._C.c_void_p(t.data_ptr())
         self._check(self._L.cs_policy_conv_features(*[vp(w) for w in self.conv_w], vp(maps), map_stride, n_maps,
                                                     vp(feat), self._stream()))
@@ -204,6 +211,12 @@ class FusedAgents:
         if self.conv:  # the map of an env's first row stands for all its rows (flight_env.py:223-230)
             self._conv_features(obs, self.n_agents * width, self.batch, self.feat)
         eps, sel = self.selection(epsilon, evaluate)
+        if self._ops is not None:
+            self._ops.policy_forward(self.packed, obs, width, self.cells, last, self.feat if self.conv else None, self.n_agents,
+                                     self.hidden, self.q if want_q else None, out, self.rows, self.n_agents, self.n_actions, eps,
+                                     self.seed, self.calls, self.row0, sel)
+            self.calls += 1
+            return out
         self._check(self._L.cs_policy_forward(vp(self.packed), vp(obs), width, self.cells, vp(last),
                                               vp(self.feat) if self.conv else None, self.n_agents, vp(self.hidden),
                                               vp(self.q) if want_q else None, vp(out), self.rows, self.n_agents,
@@ -221,6 +234,11 @@ class FusedAgents:
         if self.conv:
             feat = torch.empty(self.rows, 16, device=self.device)
             self._conv_features(x, x.stride(0), self.rows, feat)
+        if self._ops is not None:
+            self._ops.policy_forward(self.packed, x, x.stride(0), self.cells, None, feat, 1, self.hidden,
+                                     self.q if want_q else None, self.actions, self.rows, self.n_agents, self.n_actions, 0.0,
+                                     self.seed, self.calls, self.row0, 0)
+            return self.actions
         self._check(self._L.cs_policy_forward(vp(self.packed), vp(x), x.stride(0), self.cells, None,
                                               vp(feat) if self.conv else None, 1, vp(self.hidden),
                                               vp(self.q) if want_q else None, vp(self.actions), self.rows, self.n_agents,

@@ -15,6 +15,7 @@
 #include <torch/types.h>
 
 #include <cstring>
+#include <vector>
 
 #include "coopsearch.h"
 
@@ -171,6 +172,114 @@ void mt_canonical(const Tensor &cfg, Tensor state, Tensor rows_out) {
     ok(cs_mt_canonical(&c, state.data_ptr(), reinterpret_cast<uint32_t *>(rows_out.data_ptr()), stream_of(state)));
 }
 
+// ---- caller-side rows: agent network forward, fused closed loop, episode assembly ------------
+
+void check_f32(const Tensor &t, const char *name, int64_t numel, const Tensor &like) {
+    TORCH_CHECK(t.is_cuda() && t.device() == like.device(), "coopsearch: ", name, " must be on ", like.device());
+    TORCH_CHECK(t.scalar_type() == at::kFloat && t.is_contiguous(), "coopsearch: ", name, " must be contiguous float32");
+    TORCH_CHECK(numel < 0 || t.numel() == numel, "coopsearch: ", name, " must have ", numel, " elements, got ", t.numel());
+}
+
+int64_t policy_packed_floats() { return (int64_t)cs_policy_packed_floats(); }
+
+// Agents.choose_action (agent/agent.py:33-97) for rows = B * n_agents rows in one launch (cs_policy_forward)
+void policy_forward(const Tensor &packed, const Tensor &obs, int64_t obs_stride, int64_t obs_offset,
+                    const c10::optional<Tensor> &last, const c10::optional<Tensor> &feat, int64_t rows_per_feat, Tensor hidden,
+                    c10::optional<Tensor> q, Tensor actions, int64_t rows, int64_t n_agents, int64_t n_actions, double epsilon,
+                    int64_t seed, int64_t step, int64_t row0, int64_t select) {
+    check_f32(packed, "packed", (int64_t)cs_policy_packed_floats(), packed);
+    check_f32(obs, "obs", -1, packed);
+    TORCH_CHECK(rows >= 1 && obs_stride >= 4 && obs_offset >= 0 && obs.numel() >= (rows - 1) * obs_stride + obs_offset + 4,
+                "coopsearch: obs does not hold ", rows, " rows of stride ", obs_stride);
+    check_f32(hidden, "hidden", rows * 64, packed);
+    if (q.has_value() && q->defined()) check_f32(*q, "q", rows * n_actions, packed);
+    if (feat.has_value() && feat->defined()) {
+        TORCH_CHECK(rows_per_feat >= 1, "coopsearch: rows_per_feat must be >= 1");
+        check_f32(*feat, "feat", ((rows + rows_per_feat - 1) / rows_per_feat) * 16, packed);
+    }
+    if (last.has_value() && last->defined()) check_dev(*last, "last", at::kLong, rows, packed);
+    check_dev(actions, "actions", at::kLong, rows, packed);
+    const int rc = cs_policy_forward(packed.data_ptr<float>(), obs.data_ptr<float>(), (int)obs_stride, (int)obs_offset,
+                                     opt_ptr<const int64_t>(last), opt_ptr<const float>(feat), (int)rows_per_feat,
+                                     hidden.data_ptr<float>(), opt_ptr<float>(q), actions.data_ptr<int64_t>(), (int)rows,
+                                     (int)n_agents, (int)n_actions, (float)epsilon, (uint64_t)seed, (uint32_t)step, (uint64_t)row0,
+                                     (int)select, stream_of(packed));
+    TORCH_CHECK(rc == CS_OK, cs_policy_last_error());
+}
+
+// flight: conv front end of the agent network (network/base_net.py:9-18) on n_maps probability maps
+void policy_conv_features(const Tensor &c1w, const Tensor &c1b, const Tensor &c2w, const Tensor &c2b, const Tensor &lw,
+                          const Tensor &lb, const Tensor &maps, int64_t map_stride, int64_t n_maps, Tensor feat) {
+    check_f32(maps, "maps", -1, maps);
+    TORCH_CHECK(n_maps >= 1 && maps.numel() >= (n_maps - 1) * map_stride + 2500, "coopsearch: maps does not hold ", n_maps, " maps");
+    check_f32(c1w, "conv1.weight", 4 * 16, maps);
+    check_f32(c1b, "conv1.bias", 4, maps);
+    check_f32(c2w, "conv2.weight", 4 * 9, maps);
+    check_f32(c2b, "conv2.bias", 1, maps);
+    check_f32(lw, "linear.weight", 16 * 576, maps);
+    check_f32(lb, "linear.bias", 16, maps);
+    check_f32(feat, "feat", n_maps * 16, maps);
+    const int rc = cs_policy_conv_features(c1w.data_ptr<float>(), c1b.data_ptr<float>(), c2w.data_ptr<float>(), c2b.data_ptr<float>(),
+                                           lw.data_ptr<float>(), lb.data_ptr<float>(), maps.data_ptr<float>(), map_stride, (int)n_maps,
+                                           feat.data_ptr<float>(), stream_of(maps));
+    TORCH_CHECK(rc == CS_OK, cs_policy_last_error());
+}
+
+// T x (cs_policy_forward -> cs_step) in one launch (cs_rollout_policy; flight_easy, n_agents <= 5)
+void rollout_policy(const Tensor &cfg, Tensor state, const Tensor &packed, Tensor hidden, const Tensor &last, int64_t T, int64_t flags,
+                    double epsilon, int64_t seed, int64_t step0, int64_t row0, int64_t select, Tensor actions, Tensor reward,
+                    Tensor terminated, Tensor win, c10::optional<Tensor> obs, c10::optional<Tensor> state_out) {
+    const cs_config &c = config_of(cfg);
+    check_state(c, state);
+    const Shapes s = shapes_of(c);
+    TORCH_CHECK(T >= 1, "coopsearch: T must be >= 1");
+    check_f32(packed, "packed", (int64_t)cs_policy_packed_floats(), state);
+    check_f32(hidden, "hidden", s.B * s.n * 64, state);
+    check_dev(last, "last", at::kLong, s.B * s.n, state);
+    check_dev(actions, "actions", at::kLong, T * s.B * s.n, state);
+    check_dev(reward, "reward", at::kFloat, T * s.B, state);
+    check_dev(terminated, "terminated", at::kByte, T * s.B, state);
+    check_dev(win, "win", at::kByte, T * s.B, state);
+    check_outputs(c, state, T, obs, state_out);
+    ok(cs_rollout_policy(&c, state.data_ptr(), packed.data_ptr<float>(), hidden.data_ptr<float>(), last.data_ptr<int64_t>(), (int)T,
+                         (int)flags, (float)epsilon, (uint64_t)seed, (uint32_t)step0, (uint64_t)row0, (int)select,
+                         actions.data_ptr<int64_t>(), reward.data_ptr<float>(), terminated.data_ptr<uint8_t>(),
+                         win.data_ptr<uint8_t>(), opt_ptr<float>(obs), opt_ptr<float>(state_out), stream_of(state)));
+}
+
+// common/rollout.py:66-76,105-132 + replay_buffer.py:41-61: step-major tables -> the 11-key episode batch (cs_store_episodes);
+// `outs` in the order o, u, s, r, o_next, s_next, avail_u, avail_u_next, u_onehot, padded, terminated
+void store_episodes(const Tensor &o_tab, const Tensor &s_tab, const Tensor &u_tab, const Tensor &r_tab, const Tensor &term_tab,
+                    const c10::optional<Tensor> &slots, int64_t n_actions, std::vector<Tensor> outs) {
+    TORCH_CHECK(u_tab.dim() == 3, "coopsearch: u_tab must be [T, B, n]");
+    const int64_t T = u_tab.size(0), B = u_tab.size(1), n = u_tab.size(2);
+    TORCH_CHECK(o_tab.dim() == 4 && s_tab.dim() == 3, "coopsearch: o_tab must be [T+1, B, n, w], s_tab [T+1, B, S]");
+    const int64_t w = o_tab.size(3), S = s_tab.size(2), A = n_actions;
+    check_f32(o_tab, "o_tab", (T + 1) * B * n * w, o_tab);
+    check_f32(s_tab, "s_tab", (T + 1) * B * S, o_tab);
+    check_dev(u_tab, "u_tab", at::kLong, T * B * n, o_tab);
+    check_f32(r_tab, "r_tab", T * B, o_tab);
+    TORCH_CHECK(term_tab.scalar_type() == at::kByte || term_tab.scalar_type() == at::kBool, "coopsearch: term_tab must be uint8 / bool");
+    check_dev(term_tab, "term_tab", term_tab.scalar_type(), T * B, o_tab);
+    if (slots.has_value() && slots->defined()) check_dev(*slots, "slots", at::kLong, B, o_tab);
+    TORCH_CHECK(outs.size() == 11, "coopsearch: store_episodes takes the 11 destination tensors");
+    const int64_t per_slot[11] = {T * n * w, T * n, T * S, T, T * n * w, T * S, T * n * A, T * n * A, T * n * A, T, T};
+    float *ptr[11];
+    for (int k = 0; k < 11; k++) {
+        check_f32(outs[k], "episode destination", -1, o_tab);
+        TORCH_CHECK(outs[k].dim() >= 2 && outs[k].size(1) == T && outs[k].numel() == outs[k].size(0) * per_slot[k] &&
+                        outs[k].size(0) >= ((slots.has_value() && slots->defined()) ? 1 : B),
+                    "coopsearch: episode destination ", k, " must be [slots, T, ...] of the episode shape");
+        ptr[k] = outs[k].data_ptr<float>();
+    }
+    const cs_episode_out eo{ptr[0], ptr[1], ptr[2], ptr[3], ptr[4], ptr[5], ptr[6], ptr[7], ptr[8], ptr[9], ptr[10]};
+    const int rc = cs_store_episodes((int)B, (int)T, (int)n, (int)A, (int)w, (int)S, o_tab.data_ptr<float>(), s_tab.data_ptr<float>(),
+                                     u_tab.data_ptr<int64_t>(), r_tab.data_ptr<float>(),
+                                     reinterpret_cast<const uint8_t *>(term_tab.data_ptr()), opt_ptr<const int64_t>(slots), &eo,
+                                     stream_of(o_tab));
+    TORCH_CHECK(rc == CS_OK, cs_episodes_last_error());
+}
+
 int64_t abi_version() { return cs_abi_version(); }
 
 }  // namespace
@@ -189,4 +298,15 @@ TORCH_LIBRARY(coopsearch, m) {
     m.def("env_metrics(Tensor cfg, Tensor(a!) state, Tensor(b!) out4) -> ()", &env_metrics);
     m.def("mt_advance(Tensor cfg, Tensor(a!) state, int min_ahead) -> ()", &mt_advance);
     m.def("mt_canonical(Tensor cfg, Tensor state, Tensor(a!) rows_out) -> ()", &mt_canonical);
+    m.def("policy_packed_floats() -> int", &policy_packed_floats);
+    m.def("policy_forward(Tensor packed, Tensor obs, int obs_stride, int obs_offset, Tensor? last, Tensor? feat, int rows_per_feat, "
+          "Tensor(a!) hidden, Tensor(b!)? q, Tensor(c!) actions, int rows, int n_agents, int n_actions, float epsilon, int seed, "
+          "int step, int row0, int select) -> ()", &policy_forward);
+    m.def("policy_conv_features(Tensor conv1_w, Tensor conv1_b, Tensor conv2_w, Tensor conv2_b, Tensor lin_w, Tensor lin_b, "
+          "Tensor maps, int map_stride, int n_maps, Tensor(a!) feat) -> ()", &policy_conv_features);
+    m.def("rollout_policy(Tensor cfg, Tensor(a!) state, Tensor packed, Tensor(b!) hidden, Tensor last, int T, int flags, "
+          "float epsilon, int seed, int step0, int row0, int select, Tensor(c!) actions, Tensor(d!) reward, Tensor(e!) terminated, "
+          "Tensor(f!) win, Tensor(g!)? obs, Tensor(h!)? state_out) -> ()", &rollout_policy);
+    m.def("store_episodes(Tensor o_tab, Tensor s_tab, Tensor u_tab, Tensor r_tab, Tensor term_tab, Tensor? slots, int n_actions, "
+          "Tensor(a!)[] outs) -> ()", &store_episodes);
 }

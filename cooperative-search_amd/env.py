@@ -335,11 +335,17 @@ class BatchedFlightEnv:
         has_obs = out.get("obs") is not None and out.get("state") is not None
         flags = (_lib.FREEZE_DONE if self.freeze_done else 0) | (_lib.AUTO_RESET if self.auto_reset else 0)
         sel_eps, sel_flags = agents.selection(epsilon, evaluate)
-        _lib.check(self._L.cs_rollout_policy(
-            self._cfgp, self._blob.data_ptr(), agents.packed.data_ptr(), agents.hidden.data_ptr(),
-            agents.actions.data_ptr(), T, flags, sel_eps, agents.seed, agents.calls, agents.row0, sel_flags,
-            out["actions"].data_ptr(), out["reward"].data_ptr(), out["terminated"].data_ptr(), out["win"].data_ptr(),
-            out["obs"].data_ptr() if has_obs else None, out["state"].data_ptr() if has_obs else None, self._stream()))
+        if self._ops is not None:
+            self._ops.rollout_policy(self._cfg_t, self._blob, agents.packed, agents.hidden, agents.actions, T, flags, sel_eps,
+                                     agents.seed, agents.calls, agents.row0, sel_flags, out["actions"], out["reward"],
+                                     out["terminated"].view(torch.uint8), out["win"].view(torch.uint8),
+                                     out["obs"] if has_obs else None, out["state"] if has_obs else None)
+        else:
+            _lib.check(self._L.cs_rollout_policy(
+                self._cfgp, self._blob.data_ptr(), agents.packed.data_ptr(), agents.hidden.data_ptr(),
+                agents.actions.data_ptr(), T, flags, sel_eps, agents.seed, agents.calls, agents.row0, sel_flags,
+                out["actions"].data_ptr(), out["reward"].data_ptr(), out["terminated"].data_ptr(), out["win"].data_ptr(),
+                out["obs"].data_ptr() if has_obs else None, out["state"].data_ptr() if has_obs else None, self._stream()))
         agents.calls += T
         agents.actions.copy_(out["actions"][-1])
         if update_views:

@@ -164,7 +164,8 @@ def test_torch_op_library_builds_loads_and_registers_every_op():
     entry points work without a GPU."""
     ops = _lib.torch_ops()
     for name in ("abi_version", "state_bytes", "env_init", "env_seed", "env_reset", "env_step", "env_rollout", "env_emit",
-                 "env_metrics", "mt_advance", "mt_canonical"):
+                 "env_metrics", "mt_advance", "mt_canonical", "policy_packed_floats", "policy_forward", "policy_conv_features",
+                 "rollout_policy", "store_episodes"):
         assert hasattr(ops, name), name
     assert int(ops.abi_version()) == _lib.ABI_VERSION
     import torch

@@ -93,3 +93,45 @@ def test_torch_ops_reject_bad_tensors():
     with pytest.raises(RuntimeError, match="n_agents"):
         ops.state_bytes(bad)
     assert int(ops.abi_version()) == _lib.ABI_VERSION
+
+
+def test_caller_side_ops_agree_with_ctypes_and_check_their_tensors(monkeypatch):
+    """policy_forward / rollout_policy / store_episodes through torch.ops.coopsearch against the ctypes route."""
+    from cooperative_search_amd.agents import FusedAgents
+    from cooperative_search_amd import collector
+    n, B, T = 3, 128, 30
+    args = cs.make_env_args("flight_easy", n_agents=n)
+    env_t = cs.BatchedFlightEnv(args, batch=B, freeze_done=True)
+    cs.apply_env_info(args, env_t)
+    torch.manual_seed(2)
+    ag_t = FusedAgents(args, B, seed=9)
+    assert ag_t._ops is not None
+    out_t = env_t.rollout_policy(ag_t, T, epsilon=0.2, evaluate=False)
+    ep_t = collector.assemble_episodes(torch.cat([out_t["obs"][:1] * 0, out_t["obs"]]), torch.cat([out_t["state"][:1] * 0, out_t["state"]]),
+                                       out_t["actions"], out_t["reward"], out_t["terminated"], 3)
+    # the same through ctypes
+    monkeypatch.setenv("COOPSEARCH_LIB", _lib.library_path())
+    env_c = cs.BatchedFlightEnv(args, batch=B, freeze_done=True)
+    ag_c = FusedAgents(args, B, net=ag_t.net, seed=9)
+    assert env_c._ops is None and ag_c._ops is None
+    out_c = env_c.rollout_policy(ag_c, T, epsilon=0.2, evaluate=False)
+    ep_c = collector.assemble_episodes(torch.cat([out_c["obs"][:1] * 0, out_c["obs"]]), torch.cat([out_c["state"][:1] * 0, out_c["state"]]),
+                                       out_c["actions"], out_c["reward"], out_c["terminated"], 3)
+    monkeypatch.delenv("COOPSEARCH_LIB")
+    for k in ("actions", "reward", "terminated", "obs", "state"):
+        assert torch.equal(out_t[k], out_c[k]), k
+    for k in ep_t:
+        assert torch.equal(ep_t[k], ep_c[k]), k
+    a_t = ag_t.choose_action(env_t.get_obs(), epsilon=0.1, want_q=True).clone()
+    a_c = ag_c.choose_action(env_c.get_obs(), epsilon=0.1, want_q=True).clone()
+    assert torch.equal(a_t, a_c) and torch.equal(ag_t.q, ag_c.q) and torch.equal(ag_t.hidden, ag_c.hidden)
+    ops = _lib.torch_ops()
+    with pytest.raises(RuntimeError, match="hidden"):
+        ops.policy_forward(ag_t.packed, env_t.get_obs(), 4, 0, ag_t.actions, None, n, ag_t.hidden[:-1].contiguous(), None, ag_t.actions,
+                           B * n, n, 3, 0.0, 0, 0, 0, 0)
+    with pytest.raises(RuntimeError, match="actions"):
+        ops.policy_forward(ag_t.packed, env_t.get_obs(), 4, 0, ag_t.actions, None, n, ag_t.hidden, None, ag_t.actions.int(),
+                           B * n, n, 3, 0.0, 0, 0, 0, 0)
+    with pytest.raises(RuntimeError, match="11 destination"):
+        ops.store_episodes(out_t["obs"], out_t["state"], out_t["actions"][:-1].contiguous(), out_t["reward"][:-1].contiguous(),
+                           out_t["terminated"][:-1].contiguous().view(torch.uint8), None, 3, [])
