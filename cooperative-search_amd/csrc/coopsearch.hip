@@ -1671,6 +1671,9 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io
 // Results are bit-identical to the group kernels (same per-env arithmetic, same MT19937 word order);
 // tests/test_gpu_parity.py runs both.
 // =========================================================================================================
+#ifndef CS_LANE_REFRESH_MAX_N
+#define CS_LANE_REFRESH_MAX_N 4   /* measured: 4 agents 29.9 -> 37.6 % at B = 262144; 5 agents spill with it (+10 % at 65536, -4 % at 262144) */
+#endif
 constexpr int LANE_REFILL = 192;   // words twisted per refill (<= 227: independent of each other)
 constexpr int LANE_REFILL_MAX = 192;
 #ifndef CS_LANE_CHUNK
@@ -1927,7 +1930,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO i
     const int t16 = lane & (G - 1), gshift = lane & ~(G - 1), grp = lane >> 4;
     const unsigned tmask = p.n_targets >= 16 ? 0xffffu : ((1u << p.n_targets) - 1u);
     constexpr int LOW = 2 * N * CS_MAX_TARGETS;   // words one step can consume: every lane enters a step with that many twisted
-    constexpr bool REFRESH = N <= 3;              // in-loop refresh (above); larger teams rely on cs_rollout's pre-pass
+    constexpr bool REFRESH = N <= CS_LANE_REFRESH_MAX_N;   // in-loop refresh (above); larger teams rely on cs_rollout's pre-pass
     unsigned *rowbuf = reinterpret_cast<unsigned *>(tiles + (size_t)(BLOCK / 64) * 64 * W) + wave * MT_N;
     RowRegs rr;
     int cand = -1;                                // env (lane) whose row is in flight in `rr`
@@ -2858,10 +2861,10 @@ int cs_rollout(const cs_config *cfg, void *state_dev, const void *actions_dev, i
         const size_t n = (size_t)cfg->n_agents, W = 4 * n + 3 * (size_t)cfg->n_targets, B = (size_t)p.B;
         const size_t act_w = n * ((flags & CS_ACTIONS_I64) ? 8 : 4);
         // (teams of up to 3 refresh their rows inside the kernel, one env per wavefront and step: one launch, no pre-pass)
-        const int chunk = cfg->n_agents <= 3 ? T : LANE_CHUNK;
+        const int chunk = cfg->n_agents <= CS_LANE_REFRESH_MAX_N ? T : LANE_CHUNK;
         for (int t0 = 0; t0 < T; t0 += chunk) {
             const int tc = T - t0 < chunk ? T - t0 : chunk;
-            if (tc >= 8 && cfg->n_agents > 3)
+            if (tc >= 8 && cfg->n_agents > CS_LANE_REFRESH_MAX_N)
                 hipLaunchKernelGGL(k_mt_advance, dim3((unsigned)((p.B + 3) / 4)), dim3(256), 0, s, p, prepass_min_ahead(cfg, tc));
             StepIO it{(const char *)actions_dev + (size_t)t0 * B * act_w, reward_dev + (size_t)t0 * B,
                       terminated_dev + (size_t)t0 * B, win_dev + (size_t)t0 * B,
