@@ -793,13 +793,13 @@ __device__ __forceinline__ void env_reset(const DevParams &p, const double *T, i
         // polar method: attempts (x1, x2) are drawn until 0 < r2 < 1; the pair's SECOND value f*x2 is returned
         // first, f*x1 is cached for the next call -- so the j-th accepted attempt serves the j-th 'f' target.
         double jx = 0.0, jy = 0.0;
-#pragma unroll
-        for (int j = 0; j < CS_MAX_TARGETS; j++) {  // per-lane pick from the kernel-argument tables (selects, no scratch)
-            mx = j == t ? p.tx0[j] : mx;
-            my = j == t ? p.ty0[j] : my;
-            jx = j == t ? p.jx2[j] : jx;
-            jy = j == t ? p.jy2[j] : jy;
-        }
+        // this lane's entries of the kernel-argument tables, read where they are (the kernarg segment, indexed by lane):
+        // as 64 selects the tables sat in SGPRs across the rollout loops and spilled in every kernel that can reset
+        // (k_rollout<5>: 1244 -> 441 v_readlane / v_writelane, 253 -> 250 VGPRs)
+        mx = p.tx0[t];
+        my = p.ty0[t];
+        jx = p.jx2[t];
+        jy = p.jy2[t];
         const unsigned fmask = ~p.deter_mask & tmask;        // jittered targets
         const int need_total = __popc(fmask);
         const bool mine = (fmask >> t) & 1u;
