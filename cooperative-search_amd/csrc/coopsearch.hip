@@ -1672,7 +1672,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io
 // tests/test_gpu_parity.py runs both.
 // =========================================================================================================
 #ifndef CS_LANE_REFRESH_MAX_N
-#define CS_LANE_REFRESH_MAX_N 4   /* measured: 4 agents 29.9 -> 37.6 % at B = 262144; 5 agents spill with it (+10 % at 65536, -4 % at 262144) */
+#define CS_LANE_REFRESH_MAX_N 5   /* measured at B = 262144: 4 agents 29.9 -> 34-38 %, 5 agents 23.5 -> 28 % */
 #endif
 constexpr int LANE_REFILL = 192;   // words twisted per refill (<= 227: independent of each other)
 constexpr int LANE_REFILL_MAX = 192;
