@@ -1339,6 +1339,14 @@ __global__ __launch_bounds__(DUO_BLOCK) void k_rollout_duo(DevParams p, StepIO i
     }
 
     // ---------------------------------------------------------------------------------------------- D: detection
+    // D is the longer half of the pair and the YOUNGER wavefront of its SIMD (K waves are dispatched first): at equal
+    // priority the issue arbiter serves the older wave first and D gets the leftover slots (timeline: its detection +
+    // emission take 1.8x what they take alone).  Raised priority gives the slots to the longer half (measured, B = 4096:
+    // prio 0 / 1 / 2 / 3 -> 1.73 / 1.80 / 1.75 / 1.78e9 env-steps/s; at 2 K becomes the slower half: produce 2600 -> 3300).
+#ifndef CS_DUO_D_PRIO
+#define CS_DUO_D_PRIO 1
+#endif
+    __builtin_amdgcn_s_setprio(CS_DUO_D_PRIO);
     const bool wave_valid = nvalid > 0;
     const EmitPlan<N> plan = make_emit_plan<N>(p, lane, wave_valid ? nvalid : 1);
     constexpr bool PIPE = N <= 4;

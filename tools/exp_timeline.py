@@ -5,7 +5,7 @@ import numpy as np, torch
 import cooperative_search_amd as cs
 n, B, T = int(os.environ.get("N", 3)), int(os.environ.get("B", 4096)), 64
 args = cs.make_env_args("flight_easy", n_agents=n); args.time_limit = 10**9
-env = cs.BatchedFlightEnv(args, batch=B, freeze_done=False, auto_reset=True, kernel="group")
+env = cs.BatchedFlightEnv(args, batch=B, freeze_done=False, auto_reset=True, kernel="solo")
 acts = torch.randint(0, 3, (T, B, n), dtype=torch.int32, device="cuda")
 out = env.rollout(acts); out = env.rollout(acts, out=out, update_views=False)
 torch.cuda.synchronize()
