@@ -1346,7 +1346,8 @@ __global__ __launch_bounds__(DUO_BLOCK) void k_rollout_duo(DevParams p, StepIO i
 #ifndef CS_DUO_D_PRIO
 #define CS_DUO_D_PRIO 1
 #endif
-    __builtin_amdgcn_s_setprio(CS_DUO_D_PRIO);
+    if (N <= 3) __builtin_amdgcn_s_setprio(CS_DUO_D_PRIO);   // larger teams: K (n agents' kinematics) is the longer half
+
     const bool wave_valid = nvalid > 0;
     const EmitPlan<N> plan = make_emit_plan<N>(p, lane, wave_valid ? nvalid : 1);
     constexpr bool PIPE = N <= 4;
