@@ -15,8 +15,9 @@ Workloads (BASELINE.json configs):
     c5                            flight_easy, 5 agents, 15 targets, 8192 envs per GPU (65536 over 8 GPUs)
 Modes:
     step     one cs_step launch per step (the closed-loop path a policy drives), replayed from a hipGraph
-    rollout  cs_rollout: up to 100 steps per launch with the env resident in registers (open-loop action table;
-             flight_easy only) -- default for flight_easy
+    rollout  cs_rollout over an open-loop action table, 100 steps per call (default).  flight_easy: up to 100 steps per
+             launch with the env resident in registers; flight: one launch per step in which the map sweep of step t and
+             the kinematics / detection of step t + 1 run side by side (k_flight_pipe)
 
 Timing protocol (one clock): after W warm-up steps, the K-step region -- bracketed by a barrier and
 torch.cuda.synchronize() on both sides -- is repeated until it has accumulated >= MIN_GPU_S of GPU time (at least
@@ -138,8 +139,8 @@ def largest_divisor_leq(k, cap):
 def kernel_label(env_name, n, B, mode, kernel):
     """The kernel cs_step / cs_rollout dispatches to (csrc/coopsearch.hip: use_lane_kernel, duo_pays)."""
     lane = env_name == "flight_easy" and (kernel == "lane" or (kernel == "auto" and B >= 32768))
-    if env_name == "flight":
-        return f"k_step<{n},1> + k_map<{n}>"
+    if env_name == "flight":   # rollout call: step t + 1 rides inside the map sweep of step t, one launch per step
+        return f"k_flight_pipe<{n}>" if mode == "rollout" else f"k_step<{n},1> + k_map<{n}>"
     if lane:
         return f"k_rollout_lane<{n}>"
     if mode == "step":
@@ -335,7 +336,7 @@ def run_workload(cs, dev, comm, env_name, n, B, mode, K, W, kernel, rank=0, no_g
     ev, wall = timed_region(region, dev, comm, min_gpu_s)
     t_ev = comm.max(statistics.median(ev))
     t_wall = comm.max(statistics.median(wall))
-    steps_per_launch = S if mode == "rollout" else 1
+    steps_per_launch = S if mode == "rollout" and env_name != "flight" else 1   # flight: one launch per step either way
     alg = algorithmic_bytes_per_env_step(env_name, n, m, mode)
     label = kernel_label(env_name, n, B, mode, kernel)
     achieved = alg * B * K / t_ev / 1e9
@@ -481,9 +482,7 @@ def main():
     if a.batch:
         wl["batch"] = a.batch
     env_name, n, B, m = wl["env"], wl["n_agents"], wl["batch"], 15
-    mode = a.mode or ("rollout" if env_name == "flight_easy" else "step")
-    if env_name == "flight" and mode == "rollout":
-        raise SystemExit("rollout mode is flight_easy only")
+    mode = a.mode or "rollout"
     K, W = a.steps, a.warmup
 
     res, env = run_workload(cs, dev, comm, env_name, n, B, mode, K, W, a.kernel, rank=rank, no_graph=a.no_graph,
@@ -533,7 +532,10 @@ def main():
                                  "flight_easy", 3, 4096, "step", 2000, 200, "auto"),
                 side_measurement(cs, dev, comm, "c3 flight_easy 5a15t B=16384", "flight_easy", 5, 16384, "rollout",
                                  1000, 100, "auto"),
-                side_measurement(cs, dev, comm, "c4 flight 3a15t B=8192", "flight", 3, 8192, "step", 400, 100, "auto"),
+                side_measurement(cs, dev, comm, "c4 flight 3a15t B=8192 (cs_rollout: sweep of step t beside step t + 1)",
+                                 "flight", 3, 8192, "rollout", 400, 100, "auto"),
+                side_measurement(cs, dev, comm, "c4 flight 3a15t B=8192, cs_step per step (hipGraph): k_step then k_map",
+                                 "flight", 3, 8192, "step", 400, 100, "auto"),
                 side_measurement(cs, dev, comm, "flight_easy 3a15t B=262144 (lane-per-env kernel: the HBM-regime kernel)",
                                  "flight_easy", 3, 262144, "rollout", 200, 100, "lane"),
                 side_measurement(cs, dev, comm, "flight_easy 3a15t B=1048576 (lane-per-env kernel; batch sweep asymptote)",

@@ -4,7 +4,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 2   # CS_ABI_VERSION of include/coopsearch.h; bumped whenever an export or a struct changes
+ABI_VERSION = 3   # CS_ABI_VERSION of include/coopsearch.h; bumped whenever an export or a struct changes
 MT_STRIDE = 672    # CS_MT_STRIDE
 MAX_AGENTS = 8
 MAX_TARGETS = 16
@@ -35,7 +35,8 @@ class CsConfig(C.Structure):
 
 class CsLayout(C.Structure):
     _fields_ = [("total_bytes", C.c_size_t), ("tgt_off", C.c_size_t), ("agent_off", C.c_size_t),
-                ("hdr_off", C.c_size_t), ("mt_off", C.c_size_t), ("ahead_off", C.c_size_t), ("tape_off", C.c_size_t), ("prob_off", C.c_size_t)]
+                ("hdr_off", C.c_size_t), ("mt_off", C.c_size_t), ("ahead_off", C.c_size_t), ("tape_off", C.c_size_t), ("prob_off", C.c_size_t),
+                ("job_off", C.c_size_t)]
 
 
 class CsEpisodeOut(C.Structure):

@@ -57,6 +57,7 @@ struct DevParams {
     int *ahead;      // [B] words at the cursor that are already twisted
     unsigned *tape;  // [B][16] hit bits of the twisted words (lane kernel), see k_mt_advance
     float *prob;     // [B][cells]
+    char *job;       // [2][B] MapJob records (flight): what k_map needs of the step that ran before it
     float thr32, eps32;  // lane kernel's fp32 pre-filter of the sensor test, in normalised coordinates
 };
 
@@ -375,6 +376,40 @@ __device__ __forceinline__ void env_store(const DevParams &p, int b, int t, cons
         double2 *t2 = reinterpret_cast<double2 *>(p.tgt + (size_t)b * G * 2);
         t2[t] = make_double2(e.tx, e.ty);
     }
+}
+
+// flight: everything the map sweep needs of the step (or reset) that ran before it, as a record of its own, so that a
+// sweep for step t can run beside the kinematics / detection of step t + 1 (which overwrite hdr / agent / tgt).  Two
+// records per env, selected by the launch's parity.
+struct MapJob {
+    int flags;                  // FLAG_DIRTY / FLAG_RESET_PASS of this step
+    unsigned newly, newly_reset;
+    int pad;
+    int cell[CS_MAX_TARGETS];   // flat map cell of every target (int() truncation, clamped: flight_env.py:279), -1 = none
+    double axy[CS_MAX_AGENTS][2];
+    char fill[CS_JOB_BYTES - 16 - 4 * CS_MAX_TARGETS - 16 * CS_MAX_AGENTS];
+};
+static_assert(sizeof(MapJob) == CS_JOB_BYTES, "MapJob layout");
+
+__device__ __forceinline__ MapJob *job_ptr(const DevParams &p, int parity, int b) {
+    return reinterpret_cast<MapJob *>(p.job) + (size_t)parity * p.B + b;
+}
+
+template <int N>
+__device__ __forceinline__ void job_store(const DevParams &p, int parity, int b, int t, const Env<N> &e) {
+    MapJob *j = job_ptr(p, parity, b);
+    if (t == 0) *reinterpret_cast<int4 *>(j) = make_int4(e.flags & (FLAG_DIRTY | FLAG_RESET_PASS), (int)e.newly, (int)e.newly_reset, 0);
+    int cell = -1;
+    if (t < p.n_targets) {
+        int ix = (int)e.tx, iy = (int)e.ty;  // int(): truncation toward zero, flight_env.py:279
+        ix = ix < p.map_size - 1 ? ix : p.map_size - 1;
+        iy = iy < p.map_size - 1 ? iy : p.map_size - 1;
+        cell = (ix >= 0 && iy >= 0) ? ix * p.map_size + iy : -1;
+    }
+    j->cell[t] = cell;
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        if (t == i) *reinterpret_cast<double2 *>(j->axy[i]) = make_double2(e.ax[i], e.ay[i]);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -920,6 +955,7 @@ struct StepIO {
     int flags, T;
     int env0, env_n;      // lane kernel: this launch covers envs [env0, env0 + env_n)
     int min_ahead;        // 16-lane rollout kernels: rows with fewer twisted words than this are topped up in the prologue
+    int job_parity;       // flight: which of the env's two MapJob records this step writes
 };
 
 // int32 actions, or the low dword of little-endian int64 actions (values 0..2): one branch-free strided read
@@ -1112,11 +1148,10 @@ __device__ __forceinline__ void step_once(const DevParams &p, const double *T, c
     CS_STAMP(5);
 }
 
+// One launch's share of a single step: workgroup `blk` of BLOCK threads = 16 envs.
 template <int N, int VARIANT>
-__global__ __launch_bounds__(BLOCK) void k_step(DevParams p, StepIO io) {
-    __shared__ double T[TRIG_ROWS * TRIG_COLS];
-    __shared__ WaveTile tiles[BLOCK / 64];
-    const int gid = blockIdx.x * BLOCK + threadIdx.x;
+__device__ __forceinline__ void step_block(const DevParams &p, const StepIO &io, double *T, WaveTile *tiles, int blk) {
+    const int gid = blk * BLOCK + threadIdx.x;
     const int b = gid / G, t = gid % G;
     const int lane = threadIdx.x & 63;
     const bool live = b < p.B;
@@ -1128,7 +1163,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(DevParams p, StepIO io) {
         load_actions<N>(io, (size_t)b, act);
     }
     load_trig_to_lds(T);
-    const int wave_b0 = (blockIdx.x * BLOCK + (threadIdx.x & ~63)) / G;
+    const int wave_b0 = (blk * BLOCK + (threadIdx.x & ~63)) / G;
     if (wave_b0 >= p.B) return;
     const int nvalid = p.B - wave_b0 < 4 ? p.B - wave_b0 : 4;
     MtWin win = {0u, 0u};
@@ -1137,7 +1172,17 @@ __global__ __launch_bounds__(BLOCK) void k_step(DevParams p, StepIO io) {
     unsigned no_tape[TAPE_DW];   // single steps twist their words on demand
     step_once<N, VARIANT>(p, T, io, tiles[threadIdx.x >> 6], b, lane, (size_t)wave_b0, plan, live, act, win, false, false, 0, false, e,
                           no_tape, false, false);
-    if (live) env_store<N>(p, b, t, e, false);
+    if (live) {
+        env_store<N>(p, b, t, e, false);
+        if (VARIANT == 1) job_store<N>(p, io.job_parity, b, t, e);
+    }
+}
+
+template <int N, int VARIANT>
+__global__ __launch_bounds__(BLOCK) void k_step(DevParams p, StepIO io) {
+    __shared__ double T[TRIG_ROWS * TRIG_COLS];
+    __shared__ WaveTile tiles[BLOCK / 64];
+    step_block<N, VARIANT>(p, io, T, tiles, blockIdx.x);
 }
 
 // T steps per launch, env resident in registers between steps (flight_easy).  The next step's actions and MT
@@ -2271,6 +2316,7 @@ __global__ __launch_bounds__(BLOCK) void k_reset(DevParams p, const uint8_t *mas
             env_store<N>(p, b, t, e, false);
         }
     }
+    if (p.variant == 1) job_store<N>(p, 0, b, t, e);   // the sweep that follows a reset reads record 0
     const size_t obs_w = (size_t)N * (p.variant == 1 ? p.cells + 4 : 4);
     const size_t st_w = (size_t)(4 * N + 3 * p.n_targets);
     emit<N>(p, t, e, obs ? obs + (size_t)b * obs_w : nullptr, state ? state + (size_t)b * st_w : nullptr);
@@ -2372,23 +2418,30 @@ __device__ __forceinline__ void build_rowbits(const DevParams &p, const double (
 #ifndef CS_MAP_NT
 #define CS_MAP_NT 1
 #endif
+#ifndef CS_MAP_ILP
+#define CS_MAP_ILP 1
+#endif
 constexpr int MAP_BLOCK = CS_MAP_BLOCK;
+constexpr int MAP_ILP = CS_MAP_ILP;   // float4 chunks per thread, all loaded before the first is processed
 
-template <int N>
-__global__ __launch_bounds__(MAP_BLOCK) void k_map(DevParams p, float *obs, int apply) {
-    __shared__ MapPassLds s_pass[2];  // [0] reset-time pass at the start positions, [1] the step's pass
-    const int b = blockIdx.x;
-    const int *hdr = p.hdr + (size_t)b * CS_H_WORDS;
-    const int flags = apply ? hdr[CS_H_FLAGS] : 0;
+template <int N, int ILP>
+__device__ __forceinline__ void map_sweep(const DevParams &p, MapPassLds *s_pass, float *obs, int apply, int parity, int b,
+                                          int yblk) {
+    const MapJob *job = job_ptr(p, parity, b);
+    const int flags = apply ? job->flags : 0;
     const bool dirty = flags & FLAG_DIRTY;
     const bool reset_pass = flags & FLAG_RESET_PASS;
     if (!dirty && !reset_pass && !obs) return;
     float4 *m4 = reinterpret_cast<float4 *>(p.prob + (size_t)b * p.cells);
     const int nchunks = p.cells / 4;
-    // the map load does not depend on anything below: issue it first
-    const int c_first = blockIdx.y * MAP_BLOCK + threadIdx.x;
-    float4 v_first = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c_first < nchunks) v_first = m4[c_first];
+    // the map loads do not depend on anything below: issue them first
+    const int c_first = yblk * ILP * MAP_BLOCK + threadIdx.x;
+    float4 v_in[ILP];
+#pragma unroll
+    for (int k = 0; k < ILP; k++) {
+        v_in[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c_first + k * MAP_BLOCK < nchunks) v_in[k] = m4[c_first + k * MAP_BLOCK];
+    }
 
     if (dirty || reset_pass) {
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -2399,7 +2452,7 @@ __global__ __launch_bounds__(MAP_BLOCK) void k_map(DevParams p, float *obs, int 
 #pragma unroll
             for (int i = 0; i < N; i++) {
                 if (k == 1) {
-                    const double4 a = reinterpret_cast<const double4 *>(p.agent + (size_t)b * CS_MAX_AGENTS * 4)[i];
+                    const double2 a = *reinterpret_cast<const double2 *>(job->axy[i]);
                     ax[i] = a.x;
                     ay[i] = a.y;
                 } else {
@@ -2415,16 +2468,8 @@ __global__ __launch_bounds__(MAP_BLOCK) void k_map(DevParams p, float *obs, int 
             build_rowbits<N>(p, ax, ay, lane, s_pass[k].rowbits);
             if (lane == 63) s_pass[k].rowbits[CS_MAX_MAP + 1] = 0;  // row map_size + 1 is read by wrapping chunks
             if (lane < CS_MAX_TARGETS) {  // cells of the newly found targets
-                const unsigned newly = (unsigned)hdr[k == 0 ? CS_H_NEWLY_RESET : CS_H_NEWLY];
-                int cell = -1;
-                if ((newly >> lane) & 1u) {
-                    const double *tg = p.tgt + ((size_t)b * G + lane) * 2;
-                    int ix = (int)tg[0], iy = (int)tg[1];  // int(): truncation toward zero, flight_env.py:279
-                    ix = ix < p.map_size - 1 ? ix : p.map_size - 1;
-                    iy = iy < p.map_size - 1 ? iy : p.map_size - 1;
-                    cell = (ix >= 0 && iy >= 0) ? ix * p.map_size + iy : -1;
-                }
-                s_pass[k].cells[lane] = cell;
+                const unsigned newly = k == 0 ? job->newly_reset : job->newly;
+                s_pass[k].cells[lane] = ((newly >> lane) & 1u) ? job->cell[lane] : -1;
                 if (lane == 0) s_pass[k].any_found = newly != 0;
             }
         }
@@ -2433,8 +2478,11 @@ __global__ __launch_bounds__(MAP_BLOCK) void k_map(DevParams p, float *obs, int 
     const size_t row_w = (size_t)p.cells + 4;
     const float qf = (float)p.q;
     const float inv_map = 1.0f / (float)p.map_size;
-    for (int c = c_first; c < nchunks; c += gridDim.y * MAP_BLOCK) {
-        float4 v = c == c_first ? v_first : m4[c];
+#pragma unroll
+    for (int kc = 0; kc < ILP; kc++) {
+        const int c = c_first + kc * MAP_BLOCK;
+        if (c >= nchunks) break;
+        float4 v = v_in[kc];
         if (dirty || reset_pass) {
             float pv[4] = {v.x, v.y, v.z, v.w};
             const int cell0 = 4 * c;
@@ -2484,6 +2532,45 @@ __global__ __launch_bounds__(MAP_BLOCK) void k_map(DevParams p, float *obs, int 
 #endif
             }
         }
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(MAP_BLOCK) void k_map(DevParams p, float *obs, int apply, int parity) {
+    __shared__ MapPassLds s_pass[2];  // [0] reset-time pass at the start positions, [1] the step's pass
+    map_sweep<N, MAP_ILP>(p, s_pass, obs, apply, parity, blockIdx.x, blockIdx.y);
+}
+
+// flight rollouts: the map sweep of step t and the kinematics / detection of step t + 1 in ONE launch.  The two do not
+// depend on each other (the sweep reads step t's MapJob record, the step writes the other one), the sweep is bandwidth
+// bound and the step latency bound, so the step's workgroups (lowest indices: dispatched first) ride inside the sweep's
+// shadow instead of costing a serial ~10 us of their own.  The step's registers cap the occupancy at four workgroups
+// per CU (at the price of a 12-byte spill in the step role), so each sweep thread keeps PIPE_ILP float4 loads in flight
+// (measured: the sweep alone loses nothing at that occupancy, profiles/r02_flight_pipe.md).
+#ifndef CS_PIPE_ILP
+#define CS_PIPE_ILP 3
+#endif
+#ifndef CS_PIPE_WAVES
+#define CS_PIPE_WAVES 4   // wavefronts per SIMD the register budget must allow (<= 128 VGPRs): four workgroups per CU
+#endif
+constexpr int PIPE_ILP = CS_PIPE_ILP;
+template <int N>
+__global__ __launch_bounds__(BLOCK, CS_PIPE_WAVES) void k_flight_pipe(DevParams p, StepIO io, float *map_obs, int map_parity,
+                                                                      int nstep, int stride, int ysplit) {
+    static_assert(BLOCK == MAP_BLOCK, "one workgroup shape for both roles");
+    __shared__ double T[TRIG_ROWS * TRIG_COLS];
+    __shared__ WaveTile tiles[BLOCK / 64];
+    __shared__ MapPassLds s_pass[2];
+    // every stride-th workgroup steps 16 envs, the others sweep: spread out, the (long-lived) step workgroups never hold
+    // more than a small share of a CU's slots
+    const int blk = blockIdx.x;
+    const int q = blk / stride, r = blk - q * stride;
+    if (r == 0 && q < nstep) {
+        step_block<N, 1>(p, io, T, tiles, q);
+    } else {
+        const int before = q + 1 < nstep ? q + 1 : nstep;   // step workgroups with a lower index
+        const int m = blk - before;
+        map_sweep<N, PIPE_ILP>(p, s_pass, map_obs, 1, map_parity, m / ysplit, m % ysplit);
     }
 }
 
@@ -2673,6 +2760,7 @@ int make_params(const cs_config *c, void *state, DevParams *p) {
         p->eps32 = (float)(1e-6 + 4e-6 * thr);
     }
     p->prob = (float *)(base + lay.prob_off);
+    p->job = base + lay.job_off;
     return CS_OK;
 }
 
@@ -2685,7 +2773,9 @@ int launched(const char *what) {
     return CS_OK;
 }
 
-inline dim3 map_grid(const DevParams &p) { return dim3((unsigned)p.B, (unsigned)((p.cells / 4 + MAP_BLOCK - 1) / MAP_BLOCK)); }
+inline dim3 map_grid(const DevParams &p) {
+    return dim3((unsigned)p.B, (unsigned)((p.cells / 4 + MAP_ILP * MAP_BLOCK - 1) / (MAP_ILP * MAP_BLOCK)));
+}
 
 // Lane-per-env launch(es) of one chunk: a VEC launch over the full wavefronts when every step's block of get_state
 // rows is 16-byte aligned, a plain launch for the remaining < 64 envs (or for everything otherwise).
@@ -2776,6 +2866,8 @@ int cs_state_layout(const cs_config *cfg, cs_layout *out) {
     off = align_up(off + B * TAPE_STRIDE * sizeof(uint32_t), 256);
     out->prob_off = off;
     if (cfg->variant == 1) off = align_up(off + B * (size_t)cfg->map_size * cfg->map_size * sizeof(float), 256);
+    out->job_off = off;
+    if (cfg->variant == 1) off += 2 * B * CS_JOB_BYTES;
     out->total_bytes = off;
     return CS_OK;
 }
@@ -2815,7 +2907,7 @@ int cs_reset(const cs_config *cfg, void *state_dev, const uint8_t *mask_dev, int
                   hipLaunchKernelGGL(k_reset<N>, dim3(env_blocks(p)), dim3(BLOCK), 0, s, p, mask_dev, init, obs_dev,
                                      state_out_dev));
     if (cfg->variant == 1) {
-        CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_map<N>, map_grid(p), dim3(MAP_BLOCK), 0, s, p, obs_dev, 1));
+        CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_map<N>, map_grid(p), dim3(MAP_BLOCK), 0, s, p, obs_dev, 1, 0));
     }
     return launched("cs_reset");
 }
@@ -2834,7 +2926,7 @@ int cs_step(const cs_config *cfg, void *state_dev, const void *actions_dev, int 
         CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL((k_step<N, 0>), dim3(env_blocks(p)), dim3(BLOCK), 0, s, p, io));
     } else {
         CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL((k_step<N, 1>), dim3(env_blocks(p)), dim3(BLOCK), 0, s, p, io));
-        CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_map<N>, map_grid(p), dim3(MAP_BLOCK), 0, s, p, obs_dev, 1));
+        CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_map<N>, map_grid(p), dim3(MAP_BLOCK), 0, s, p, obs_dev, 1, 0));
     }
     return launched("cs_step");
 }
@@ -2852,14 +2944,29 @@ int cs_rollout(const cs_config *cfg, void *state_dev, const void *actions_dev, i
         hipStream_t s = (hipStream_t)stream;
         const size_t n = (size_t)cfg->n_agents, W = 4 * n + 3 * (size_t)cfg->n_targets, B = (size_t)p.B;
         const size_t obs_w = n * ((size_t)p.cells + 4), act_w = n * ((flags & CS_ACTIONS_I64) ? 8 : 4);
-        for (int t = 0; t < T; t++) {
+        auto step_io = [&](int t) {
             StepIO it{(const char *)actions_dev + (size_t)t * B * act_w, reward_dev + (size_t)t * B,
                       terminated_dev + (size_t)t * B, win_dev + (size_t)t * B,
                       obs_dev ? obs_dev + (size_t)t * B * obs_w : nullptr,
                       state_out_dev ? state_out_dev + (size_t)t * B * W : nullptr, flags, 1};
-            CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL((k_step<N, 1>), dim3(env_blocks(p)), dim3(BLOCK), 0, s, p, it));
-            CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_map<N>, map_grid(p), dim3(MAP_BLOCK), 0, s, p, it.obs, 1));
+            it.job_parity = t & 1;
+            return it;
+        };
+        // step 0, then T - 1 launches that sweep step t's map beside step t + 1, then the last sweep
+        const int nstep = (int)env_blocks(p);
+        const int ysplit = (p.cells / 4 + PIPE_ILP * MAP_BLOCK - 1) / (PIPE_ILP * MAP_BLOCK);
+        // step workgroups spread over the first quarter of the grid
+        const int total = nstep + p.B * ysplit;
+        const int stride = total / 4 / nstep > 1 ? total / 4 / nstep : 1;
+        CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL((k_step<N, 1>), dim3(nstep), dim3(BLOCK), 0, s, p, step_io(0)));
+        for (int t = 0; t + 1 < T; t++) {
+            const StepIO nx = step_io(t + 1);
+            float *map_obs = obs_dev ? obs_dev + (size_t)t * B * obs_w : nullptr;
+            CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_flight_pipe<N>, dim3((unsigned)total), dim3(BLOCK), 0, s, p, nx,
+                                                            map_obs, t & 1, nstep, stride, ysplit));
         }
+        CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_map<N>, map_grid(p), dim3(MAP_BLOCK), 0, s, p,
+                                                        obs_dev ? obs_dev + (size_t)(T - 1) * B * obs_w : nullptr, 1, (T - 1) & 1));
         return launched("cs_rollout");
     }
     StepIO io{actions_dev, reward_dev, terminated_dev, win_dev, obs_dev, state_out_dev, flags, T};
@@ -2948,7 +3055,7 @@ int cs_emit(const cs_config *cfg, void *state_dev, float *obs_dev, float *state_
     CS_DISPATCH_N(cfg->n_agents,
                   hipLaunchKernelGGL(k_emit<N>, dim3(env_blocks(p)), dim3(BLOCK), 0, s, p, obs_dev, state_out_dev));
     if (cfg->variant == 1 && obs_dev) {
-        CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_map<N>, map_grid(p), dim3(MAP_BLOCK), 0, s, p, obs_dev, 0));
+        CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_map<N>, map_grid(p), dim3(MAP_BLOCK), 0, s, p, obs_dev, 0, 0));
     }
     return launched("cs_emit");
 }

@@ -31,13 +31,14 @@
 extern "C" {
 #endif
 
-#define CS_ABI_VERSION 2   /* 2: cs_layout.ahead_off (pre-twisted MT words), cs_mt_canonical */
+#define CS_ABI_VERSION 3   /* 2: cs_layout.ahead_off (pre-twisted MT words), cs_mt_canonical; 3: cs_layout.job_off */
 #define CS_MAX_AGENTS 8
 #define CS_MAX_TARGETS 16
 #define CS_MAX_MAP 64
 #define CS_MT_PAD 32      /* words 0..31 of an env's MT19937 row are mirrored behind word 623 */
 #define CS_MT_STRIDE 672  /* uint32 words per env row: 624 state + 32 mirror + 16 unused (21 x 128 bytes) */
 #define CS_TAPE_STRIDE 16 /* uint32 words per env of the lane kernel's hit tape (cs_layout.tape_off) */
+#define CS_JOB_BYTES 256  /* bytes per env and record of the flight map-update job records (cs_layout.job_off) */
 
 enum { CS_OK = 0, CS_E_CONFIG = -1, CS_E_ARG = -2, CS_E_LAUNCH = -3 };
 
@@ -103,6 +104,10 @@ typedef struct cs_layout {
                           it was built for.  Derived data: written by cs_mt_advance / the lane kernel, ignored (and
                           rebuilt) whenever it does not match the cursor                                        */
     size_t prob_off;   /* float  [B][map*map] probability map, first index = x cell (flight only)        */
+    size_t job_off;    /* uint8  [2][B][CS_JOB_BYTES] flight only: what the map sweep needs of the step that ran before
+                          it (pending-pass flags, newly found masks, target cells, agent positions), double buffered so
+                          that cs_rollout can sweep step t's map while step t + 1 runs.  Derived data: rewritten by
+                          every cs_reset / cs_step / cs_rollout before it is read                              */
 } cs_layout;
 
 /* words of the per-env header */

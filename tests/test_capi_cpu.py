@@ -33,7 +33,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert set(syms) == set(_lib.EXPORTS), (syms, _lib.EXPORTS)
     for s in syms:
         assert hasattr(L, s), s
-    assert L.cs_abi_version() == _lib.ABI_VERSION == 2
+    assert L.cs_abi_version() == _lib.ABI_VERSION == 3
 
 
 def _cfg(**kw):
@@ -51,11 +51,11 @@ def test_state_layout_host_only():
     assert lay.tgt_off == 0 and lay.agent_off == B * 256 and lay.hdr_off == lay.agent_off + B * 256
     assert lay.mt_off == lay.hdr_off + B * 64 and lay.ahead_off == lay.mt_off + B * _lib.MT_STRIDE * 4
     assert lay.tape_off == lay.ahead_off + B * 4 and lay.prob_off == lay.tape_off + B * 64
-    assert lay.total_bytes == lay.prob_off   # flight_easy: no map
+    assert lay.total_bytes == lay.prob_off == lay.job_off   # flight_easy: no map, no map-update job records
     cfg = _cfg(env="flight", n_agents=3, batch=8192)
     assert L.cs_state_layout(C.byref(cfg), C.byref(lay)) == 0
-    assert lay.total_bytes == lay.prob_off + 8192 * 2500 * 4
-    for off in (lay.tgt_off, lay.agent_off, lay.hdr_off, lay.mt_off, lay.ahead_off, lay.tape_off, lay.prob_off):
+    assert lay.job_off == lay.prob_off + 8192 * 2500 * 4 and lay.total_bytes == lay.job_off + 2 * 8192 * 256
+    for off in (lay.tgt_off, lay.agent_off, lay.hdr_off, lay.mt_off, lay.ahead_off, lay.tape_off, lay.prob_off, lay.job_off):
         assert off % 256 == 0
 
 

@@ -535,20 +535,37 @@ def test_c_example_runs_and_reproduces_the_random_policy_statistics(tmp_path):
     assert abs(float(m.group(4)) / 15 * 100 - 84.87) < 3.0     # shipped random-policy figure for 3a15t AM0
 
 
-def test_flight_rollout_call_equals_stepwise():
-    B, n, T = 96, 3, 40
+@pytest.mark.parametrize("B,n,T", [(96, 3, 40), (37, 3, 1), (37, 5, 7), (300, 3, 2), (1, 3, 5), (530, 4, 33)])
+def test_flight_rollout_call_equals_stepwise(B, n, T):
+    """cs_rollout(flight) sweeps step t's map in the same launch that runs step t + 1 (k_flight_pipe, double-buffered
+    map-update records): it must leave exactly what T cs_step calls leave, for odd and even T, ragged batches, resets
+    inside the horizon, and whatever call (step / rollout / reset) comes next."""
     args = cs.make_env_args("flight", n_agents=n)
     args.time_limit = 17
     seeds = np.arange(B, dtype=np.uint32) + 321
-    acts = torch.randint(0, 3, (T, B, n), dtype=torch.int64, device="cuda", generator=torch.Generator("cuda").manual_seed(2))
+    acts = torch.randint(0, 3, (2 * T + 1, B, n), dtype=torch.int64, device="cuda", generator=torch.Generator("cuda").manual_seed(2))
     e1 = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, freeze_done=False, auto_reset=True)
     e2 = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, freeze_done=False, auto_reset=True)
-    out = e2.rollout(acts)
+    out = e2.rollout(acts[:T])
     assert out["obs"].shape == (T, B, n, 2504)
     for t in range(T):
         r, term, win = e1.step(acts[t])
         assert torch.equal(r, out["reward"][t]) and torch.equal(term, out["terminated"][t]) and torch.equal(win, out["win"][t])
         assert torch.equal(e1.get_obs(), out["obs"][t]) and torch.equal(e1.get_state(), out["state"][t])
+    r1, r2 = raw_state(e1), raw_state(e2)
+    for k in ("tgt", "agent", "hdr", "mt", "prob"):
+        assert torch.equal(r1[k], r2[k]), k
+    # a single step after the rollout (the step's record parity differs from the rollout's last one when T is even) ...
+    ra, rb = e1.step(acts[T]), e2.step(acts[T])
+    assert all(torch.equal(x, y) for x, y in zip(ra, rb)) and torch.equal(e1.get_obs(), e2.get_obs())
+    # ... then a rollout without observation buffers (the sweeps still have to update the map), then a masked reset
+    e2.rollout(acts[T + 1:], emit=False)
+    for t in range(T + 1, 2 * T + 1):
+        e1.step(acts[t])
+    mask = torch.arange(B, device="cuda") % 3 == 0
+    e1.reset(mask=mask)
+    e2.reset(mask=mask)
+    assert torch.equal(e1.get_obs(), e2.get_obs()) and torch.equal(e1.get_state(), e2.get_state())
     r1, r2 = raw_state(e1), raw_state(e2)
     for k in ("tgt", "agent", "hdr", "mt", "prob"):
         assert torch.equal(r1[k], r2[k]), k
