@@ -23,6 +23,7 @@ run c5_rollout flight_easy 5 group 8192 rollout 4 100
 run c5s_rollout flight_easy 5 lane 65536 rollout 3 100
 run lane3_rollout flight_easy 3 lane 262144 rollout 3 100
 run c4_step flight 3 group 8192 step 1 100
+run c4_rollout flight 3 group 8192 rollout 1 100
 python3 - "$OUT" <<'PY'
 import csv, glob, json, os, re, sys, collections
 out = sys.argv[1]
