@@ -374,17 +374,15 @@ def closed_loop_measurement(cs, dev, n, B, K, W, env_name="flight_easy"):
     cs.apply_env_info(args, env)
     torch.manual_seed(0)
     agents = cs.FusedAgents(args, B, device=dev)
-    one_launch = env_name == "flight_easy"   # k_rollout_policy: 100 closed-loop steps per launch
+    # one call per 100 closed-loop steps: k_rollout_policy (flight_easy: one launch) / cs_rollout_policy_flight (flight:
+    # conv on the map in place + network + step + map update per step, no observation copies of the map)
     chunk = 100
-    out = env.rollout_policy(agents, chunk) if one_launch else None
+    emit = env_name == "flight_easy"
+    out = env.rollout_policy(agents, chunk, emit=emit)
 
     def advance(steps):
-        if one_launch:
-            for _ in range(steps // chunk):
-                env.rollout_policy(agents, chunk, out=out, update_views=False)
-        else:
-            for _ in range(steps):
-                env.step(agents.choose_action(env.get_obs()))
+        for _ in range(steps // chunk):
+            env.rollout_policy(agents, chunk, emit=emit, out=out, update_views=False)
 
     K, W = (K // chunk) * chunk, max(chunk, (W // chunk) * chunk)
     advance(W)
@@ -405,8 +403,9 @@ def closed_loop_measurement(cs, dev, n, B, K, W, env_name="flight_easy"):
     del env, agents
     torch.cuda.empty_cache()
     out = {"workload": f"closed loop: {env_name} {n}a15t B={B}, recurrent policy picks every action"
-                       + (" (k_rollout_policy: network + env step fused, 100 steps per launch)" if one_launch
-                          else " (conv features, policy, env step kernels per step)"),
+                       + (" (k_rollout_policy: network + env step fused, 100 steps per launch)" if env_name == "flight_easy"
+                          else " (cs_rollout_policy_flight: conv on the map in place, network, step, map update per step; "
+                               "the n observation copies of the map are not written)"),
            "mode": "closed-loop", "value": B * K / dt, "unit": "env-steps/s", "ms_per_step": dt * 1e3 / K,
            "policy_kernels_us": pol_us}
     if env_name == "flight_easy":   # one kernel, GEMM-shaped: price it against the fp32 matrix peak

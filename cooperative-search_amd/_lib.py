@@ -16,7 +16,7 @@ SELECT_SOFTMAX, SELECT_SAMPLE = 1, 2
 FREEZE_DONE, AUTO_RESET, ACTIONS_I64, KERNEL_GROUP, KERNEL_LANE, KERNEL_SOLO, KERNEL_DUO = 1, 2, 4, 8, 16, 32, 64
 
 EXPORTS = ["cs_abi_version", "cs_last_error", "cs_state_layout", "cs_init", "cs_seed", "cs_reset", "cs_step",
-           "cs_rollout", "cs_rollout_policy", "cs_emit", "cs_metrics", "cs_mt_canonical", "cs_mt_advance", "cs_policy_packed_floats", "cs_policy_pack", "cs_policy_forward",
+           "cs_rollout", "cs_rollout_policy", "cs_rollout_policy_flight", "cs_emit", "cs_metrics", "cs_mt_canonical", "cs_mt_advance", "cs_policy_packed_floats", "cs_policy_pack", "cs_policy_forward",
            "cs_policy_conv_features", "cs_policy_last_error", "cs_store_episodes", "cs_episodes_last_error"]
 
 
@@ -82,6 +82,8 @@ def load():
     L.cs_rollout.argtypes = [C.POINTER(CsConfig), vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
     L.cs_rollout_policy.argtypes = [C.POINTER(CsConfig), vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32,
                                     C.c_uint64, C.c_int, vp, vp, vp, vp, vp, vp, vp]
+    L.cs_rollout_policy_flight.argtypes = [C.POINTER(CsConfig)] + [vp] * 11 + [C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32,
+                                           C.c_uint64, C.c_int, vp, vp, vp, vp, vp, vp, vp]
     L.cs_emit.argtypes = [C.POINTER(CsConfig), vp, vp, vp, vp]
     L.cs_metrics.argtypes = [C.POINTER(CsConfig), vp, vp, vp]
     L.cs_mt_canonical.argtypes = [C.POINTER(CsConfig), vp, vp, vp]

@@ -58,6 +58,8 @@ struct DevParams {
     unsigned *tape;  // [B][16] hit bits of the twisted words (lane kernel), see k_mt_advance
     float *prob;     // [B][cells]
     char *job;       // [2][B] MapJob records (flight): what k_map needs of the step that ran before it
+    int obs_row_w;   // floats per (env, agent) row of the obs output: 4, flight: cells + 4 (map first, flight_env.py:223-230)
+    int obs_feat_off;  // where the agent's own 4 floats sit in its row: 0, flight: cells
     float thr32, eps32;  // lane kernel's fp32 pre-filter of the sensor test, in normalised coordinates
 };
 
@@ -910,8 +912,7 @@ __device__ __forceinline__ void env_reset(const DevParams &p, const double *T, i
 // ---------------------------------------------------------------------------------------------------------
 template <int N>
 __device__ __forceinline__ void emit(const DevParams &p, int t, const Env<N> &e, float *obs_row, float *state_row) {
-    const int obs_w = p.variant == 1 ? p.cells + 4 : 4;
-    const int feat_off = p.variant == 1 ? p.cells : 0;
+    const int obs_w = p.obs_row_w, feat_off = p.obs_feat_off;
 #pragma unroll
     for (int i = 0; i < N; i++) {
         if (t == i) {
@@ -994,9 +995,8 @@ __device__ __forceinline__ EmitPlan<N> make_emit_plan(const DevParams &p, int la
     }
     const int l = lane < nvalid * N ? lane : nvalid * N - 1;
     const int r = l / N, i = l - r * N;
-    const int obs_w = p.variant == 1 ? p.cells + 4 : 4;
     pl.obs_lds = r * TILE_W + 4 * i;
-    pl.obs_out = (r * N + i) * obs_w + (p.variant == 1 ? p.cells : 0);
+    pl.obs_out = (r * N + i) * p.obs_row_w + p.obs_feat_off;
     pl.rtw = (lane & 3) < nvalid ? (lane & 3) : nvalid - 1;
     return pl;
 }
@@ -1075,8 +1075,7 @@ __device__ __forceinline__ void emit_flush_store(const DevParams &p, const StepI
     io.terminated[slot0 + pl.rtw] = (uint8_t)f.term;
     io.win[slot0 + pl.rtw] = (uint8_t)f.win;
     if (io.obs) {  // one float4 per (env, agent)
-        const size_t obs_w = p.variant == 1 ? (size_t)p.cells + 4 : 4;
-        *reinterpret_cast<float4 *>(io.obs + slot0 * N * obs_w + pl.obs_out) = f.obs;
+        *reinterpret_cast<float4 *>(io.obs + slot0 * N * (size_t)p.obs_row_w + pl.obs_out) = f.obs;
     }
     if (io.state) {  // the wavefront's rows are contiguous in get_state's [B][W] layout
         float *dst = io.state + slot0 * (size_t)(4 * N + 3 * p.n_targets);
@@ -1267,23 +1266,30 @@ struct KinSlot {   // agents of one env after a step: K -> D
     int pad;
 };
 
-constexpr int DUO_BLOCK = 512;   // 4 K wavefronts + 4 D wavefronts, 16 envs
+// Pairs per workgroup share the per-step barrier, so a pair waits for the slowest of its neighbours every step.  Measured
+// (flight_easy 3a15t, B = 4096): 4 / 2 / 1 pairs -> 1.78 / 1.77 / 2.02e9 env-steps/s; 5 agents: 1.17 -> 1.32e9.
+#ifndef CS_DUO_PAIRS
+#define CS_DUO_PAIRS 1
+#endif
+constexpr int DUO_PAIRS = CS_DUO_PAIRS;        // wavefront pairs per workgroup
+constexpr int DUO_ENVS = 4 * DUO_PAIRS;        // envs per workgroup
+constexpr int DUO_BLOCK = 128 * DUO_PAIRS;     // DUO_PAIRS K wavefronts, then DUO_PAIRS D wavefronts
 
 template <int N>
-__global__ __launch_bounds__(DUO_BLOCK) void k_rollout_duo(DevParams p, StepIO io) {
+__global__ __launch_bounds__(DUO_BLOCK, 2) void k_rollout_duo(DevParams p, StepIO io) {
     __shared__ double T[TRIG_ROWS * TRIG_COLS];
     __shared__ WaveTile tiles[DUO_BLOCK / 64];   // K waves use .trig, D waves the emission rows
-    __shared__ KinSlot<N> slots[2][16];
-    __shared__ unsigned fix[2][4];               // [step parity][pair]: groups whose termination K mispredicted
-    __shared__ unsigned rowbufs[4][MT_N];        // one MT19937 row per D wavefront (prologue top-up)
+    __shared__ KinSlot<N> slots[2][DUO_ENVS];
+    __shared__ unsigned fix[2][DUO_PAIRS];               // [step parity][pair]: groups whose termination K mispredicted
+    __shared__ unsigned rowbufs[DUO_PAIRS][MT_N];        // one MT19937 row per D wavefront (prologue top-up)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool is_k = wave < 4;
-    const int pw = wave & 3;                     // wave pair = 4 envs
+    const bool is_k = wave < DUO_PAIRS;
+    const int pw = wave % DUO_PAIRS;             // wave pair = 4 envs
     const int t = lane & (G - 1), grp = lane >> 4, gshift = lane & ~(G - 1);
     const int el = 4 * pw + grp;                 // env within the block
-    const int b = blockIdx.x * 16 + el;
+    const int b = blockIdx.x * DUO_ENVS + el;
     const bool live = b < p.B;
-    const int wave_b0 = blockIdx.x * 16 + 4 * pw;
+    const int wave_b0 = blockIdx.x * DUO_ENVS + 4 * pw;
     const int nvalid = p.B - wave_b0 < 4 ? p.B - wave_b0 : 4;   // <= 0: a pair without envs (it still meets the barriers)
     const bool auto_reset = io.flags & CS_AUTO_RESET, freeze = io.flags & CS_FREEZE_DONE;
     Env<N> e;
@@ -1352,9 +1358,14 @@ __global__ __launch_bounds__(DUO_BLOCK) void k_rollout_duo(DevParams p, StepIO i
             DUO_STAMP(1);
             __syncthreads();
             DUO_STAMP(2);
-            const unsigned f0 = fix[s & 1][0], f1 = fix[s & 1][1], f2 = fix[s & 1][2], f3 = fix[s & 1][3];
-            if (f0 | f1 | f2 | f3) {   // block-uniform, rare: an env of the block terminated by finding its last target
-                const unsigned mine = pw == 0 ? f0 : (pw == 1 ? f1 : (pw == 2 ? f2 : f3));
+            unsigned any_fix = 0, mine = 0;
+#pragma unroll
+            for (int q = 0; q < DUO_PAIRS; q++) {
+                const unsigned f = fix[s & 1][q];
+                any_fix |= f;
+                mine = pw == q ? f : mine;
+            }
+            if (any_fix) {   // block-uniform, rare: an env of the block terminated by finding its last target
                 if (more && live && ((mine >> grp) & 1u)) {
                     const KinSlot<N> &sl = slots[s & 1][el];   // the env as it was after step s
 #pragma unroll
@@ -1400,9 +1411,9 @@ __global__ __launch_bounds__(DUO_BLOCK) void k_rollout_duo(DevParams p, StepIO i
     bool tape_ok = false;
     if (live) tape_ok = tape_load(p, b, e, tape);
     group_wave_advance<N>(p, wave_b0, nvalid, lane, io.min_ahead, rowbufs[pw], e, tape, tape_ok);   // while K produces step 0
-    if (threadIdx.x == 4 * 64) {
+    if (threadIdx.x == DUO_PAIRS * 64) {
 #pragma unroll
-        for (int q = 0; q < 8; q++) (&fix[0][0])[q] = 0u;
+        for (int q = 0; q < 2 * DUO_PAIRS; q++) (&fix[0][0])[q] = 0u;
     }
     __syncthreads();   // the ring holds step 0
     for (int s = 0; s < io.T; s++) {
@@ -1463,8 +1474,10 @@ __global__ __launch_bounds__(DUO_BLOCK) void k_rollout_duo(DevParams p, StepIO i
         DUO_STAMP(11);
         __syncthreads();
         DUO_STAMP(12);
-        const unsigned f0 = fix[s & 1][0], f1 = fix[s & 1][1], f2 = fix[s & 1][2], f3 = fix[s & 1][3];
-        if (f0 | f1 | f2 | f3) __syncthreads();   // K redoes step s + 1 of the flagged envs
+        unsigned any_fix = 0;
+#pragma unroll
+        for (int q = 0; q < DUO_PAIRS; q++) any_fix |= fix[s & 1][q];
+        if (any_fix) __syncthreads();   // K redoes step s + 1 of the flagged envs
     }
     if (PIPE && wave_valid) {
         FlushRegs<N> fr;
@@ -2317,7 +2330,7 @@ __global__ __launch_bounds__(BLOCK) void k_reset(DevParams p, const uint8_t *mas
         }
     }
     if (p.variant == 1) job_store<N>(p, 0, b, t, e);   // the sweep that follows a reset reads record 0
-    const size_t obs_w = (size_t)N * (p.variant == 1 ? p.cells + 4 : 4);
+    const size_t obs_w = (size_t)N * p.obs_row_w;
     const size_t st_w = (size_t)(4 * N + 3 * p.n_targets);
     emit<N>(p, t, e, obs ? obs + (size_t)b * obs_w : nullptr, state ? state + (size_t)b * st_w : nullptr);
 }
@@ -2332,7 +2345,7 @@ __global__ __launch_bounds__(BLOCK) void k_emit(DevParams p, float *obs, float *
     Env<N> e;
     env_load<N>(p, b, t, e);
     env_trig<N>(T, e);
-    const size_t obs_w = (size_t)N * (p.variant == 1 ? p.cells + 4 : 4);
+    const size_t obs_w = (size_t)N * p.obs_row_w;
     const size_t st_w = (size_t)(4 * N + 3 * p.n_targets);
     emit<N>(p, t, e, obs ? obs + (size_t)b * obs_w : nullptr, state ? state + (size_t)b * st_w : nullptr);
 }
@@ -2761,6 +2774,8 @@ int make_params(const cs_config *c, void *state, DevParams *p) {
     }
     p->prob = (float *)(base + lay.prob_off);
     p->job = base + lay.job_off;
+    p->obs_row_w = c->variant == 1 ? p->cells + 4 : 4;
+    p->obs_feat_off = c->variant == 1 ? p->cells : 0;
     return CS_OK;
 }
 
@@ -2994,7 +3009,7 @@ int cs_rollout(const cs_config *cfg, void *state_dev, const void *actions_dev, i
                       hipLaunchKernelGGL(k_rollout<N>, dim3(env_blocks(p)), dim3(BLOCK), 0, (hipStream_t)stream, p, io));
     } else {
         io.min_ahead = prepass_min_ahead(cfg, T);
-        CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_rollout_duo<N>, dim3((unsigned)((p.B + 15) / 16)), dim3(DUO_BLOCK),
+        CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_rollout_duo<N>, dim3((unsigned)((p.B + DUO_ENVS - 1) / DUO_ENVS)), dim3(DUO_BLOCK),
                                                         0, (hipStream_t)stream, p, io));
     }
     return launched("cs_rollout");
@@ -3028,6 +3043,55 @@ int cs_rollout_policy(const cs_config *cfg, void *state_dev, const float *packed
     }
 #undef CS_LAUNCH_RP
     return launched("cs_rollout_policy");
+}
+
+int cs_rollout_policy_flight(const cs_config *cfg, void *state_dev, const float *packed_dev, const float *conv1_w_dev,
+                             const float *conv1_b_dev, const float *conv2_w_dev, const float *conv2_b_dev,
+                             const float *lin_w_dev, const float *lin_b_dev, float *hidden_dev, const int64_t *last_dev,
+                             float *scratch_dev, int T, int flags, float epsilon, uint64_t seed, uint32_t step0, uint64_t row0,
+                             int select, int64_t *actions_dev, float *reward_dev, uint8_t *terminated_dev, uint8_t *win_dev,
+                             float *obs_dev, float *state_out_dev, void *stream) {
+    DevParams p;
+    int rc = make_params(cfg, state_dev, &p);
+    if (rc) return rc;
+    if (cfg->variant != 1) return fail(CS_E_CONFIG, "cs_rollout_policy_flight: flight only");
+    if (cfg->map_size != 50) return fail(CS_E_CONFIG, "cs_rollout_policy_flight: the conv front end is built for map_size 50");
+    if (T < 1) return fail(CS_E_ARG, "T must be >= 1");
+    if (!packed_dev || !conv1_w_dev || !conv1_b_dev || !conv2_w_dev || !conv2_b_dev || !lin_w_dev || !lin_b_dev ||
+        !hidden_dev || !last_dev || !scratch_dev || !actions_dev || !reward_dev || !terminated_dev || !win_dev)
+        return fail(CS_E_ARG, "null rollout buffer");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)cfg->n_agents, B = (size_t)p.B, W = 4 * n + 3 * (size_t)cfg->n_targets;
+    const size_t obs_w = n * ((size_t)p.cells + 4);
+    constexpr int NA = 3;   // the env has three actions (flight_env.py:32)
+    float *feat = scratch_dev, *tails = scratch_dev + B * 16;
+    // the agents' own 4 floats, compact ([B][n][4]): what the first network call reads and, when no observation rows
+    // are wanted, where every step leaves them
+    DevParams pc = p;
+    pc.obs_row_w = 4;
+    pc.obs_feat_off = 0;
+    CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_emit<N>, dim3(env_blocks(p)), dim3(BLOCK), 0, s, pc, tails, nullptr));
+    for (int t = 0; t < T; t++) {
+        // the conv front end reads each env's map where it lives: one read per env, no observation copy needed
+        if (cs_policy_conv_features(conv1_w_dev, conv1_b_dev, conv2_w_dev, conv2_b_dev, lin_w_dev, lin_b_dev, p.prob,
+                                    (int64_t)p.cells, p.B, feat, stream) != CS_OK)
+            return fail(CS_E_LAUNCH, cs_policy_last_error());
+        const bool prev_rows = obs_dev && t > 0;   // own floats of step t - 1: in its observation rows, or compact
+        const float *own = prev_rows ? obs_dev + (size_t)(t - 1) * B * obs_w : tails;
+        int64_t *act = actions_dev + (size_t)t * B * n;
+        if (cs_policy_forward(packed_dev, own, prev_rows ? p.cells + 4 : 4, prev_rows ? p.cells : 0,
+                              t == 0 ? last_dev : act - B * n, feat, cfg->n_agents, hidden_dev, nullptr, act, (int)(B * n),
+                              cfg->n_agents, NA, epsilon, seed, step0 + (uint32_t)t, row0, select, stream) != CS_OK)
+            return fail(CS_E_LAUNCH, cs_policy_last_error());
+        StepIO it{act, reward_dev + (size_t)t * B, terminated_dev + (size_t)t * B, win_dev + (size_t)t * B,
+                  obs_dev ? obs_dev + (size_t)t * B * obs_w : tails,
+                  state_out_dev ? state_out_dev + (size_t)t * B * W : nullptr, (flags & ~CS_ACTIONS_I64) | CS_ACTIONS_I64, 1};
+        CS_DISPATCH_N(cfg->n_agents,
+                      hipLaunchKernelGGL((k_step<N, 1>), dim3(env_blocks(p)), dim3(BLOCK), 0, s, obs_dev ? p : pc, it));
+        CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_map<N>, map_grid(p), dim3(MAP_BLOCK), 0, s, p,
+                                                        obs_dev ? obs_dev + (size_t)t * B * obs_w : nullptr, 1, 0));
+    }
+    return launched("cs_rollout_policy_flight");
 }
 
 int cs_mt_advance(const cs_config *cfg, void *state_dev, int min_ahead, void *stream) {

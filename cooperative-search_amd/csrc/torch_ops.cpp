@@ -247,6 +247,39 @@ void rollout_policy(const Tensor &cfg, Tensor state, const Tensor &packed, Tenso
                          win.data_ptr<uint8_t>(), opt_ptr<float>(obs), opt_ptr<float>(state_out), stream_of(state)));
 }
 
+// flight: T x (conv features of the env's map -> policy forward -> env step) enqueued by one call (cs_rollout_policy_flight)
+void rollout_policy_flight(const Tensor &cfg, Tensor state, const Tensor &packed, const Tensor &c1w, const Tensor &c1b,
+                           const Tensor &c2w, const Tensor &c2b, const Tensor &lw, const Tensor &lb, Tensor hidden, const Tensor &last,
+                           Tensor scratch, int64_t T, int64_t flags, double epsilon, int64_t seed, int64_t step0, int64_t row0,
+                           int64_t select, Tensor actions, Tensor reward, Tensor terminated, Tensor win, c10::optional<Tensor> obs,
+                           c10::optional<Tensor> state_out) {
+    const cs_config &c = config_of(cfg);
+    check_state(c, state);
+    const Shapes s = shapes_of(c);
+    TORCH_CHECK(T >= 1, "coopsearch: T must be >= 1");
+    check_f32(packed, "packed", (int64_t)cs_policy_packed_floats(), state);
+    check_f32(c1w, "conv1.weight", 4 * 16, state);
+    check_f32(c1b, "conv1.bias", 4, state);
+    check_f32(c2w, "conv2.weight", 4 * 9, state);
+    check_f32(c2b, "conv2.bias", 1, state);
+    check_f32(lw, "linear.weight", 16 * 576, state);
+    check_f32(lb, "linear.bias", 16, state);
+    check_f32(hidden, "hidden", s.B * s.n * 64, state);
+    check_dev(last, "last", at::kLong, s.B * s.n, state);
+    check_f32(scratch, "scratch", s.B * (16 + 4 * s.n), state);
+    check_dev(actions, "actions", at::kLong, T * s.B * s.n, state);
+    check_dev(reward, "reward", at::kFloat, T * s.B, state);
+    check_dev(terminated, "terminated", at::kByte, T * s.B, state);
+    check_dev(win, "win", at::kByte, T * s.B, state);
+    check_outputs(c, state, T, obs, state_out);
+    ok(cs_rollout_policy_flight(&c, state.data_ptr(), packed.data_ptr<float>(), c1w.data_ptr<float>(), c1b.data_ptr<float>(),
+                                c2w.data_ptr<float>(), c2b.data_ptr<float>(), lw.data_ptr<float>(), lb.data_ptr<float>(),
+                                hidden.data_ptr<float>(), last.data_ptr<int64_t>(), scratch.data_ptr<float>(), (int)T, (int)flags,
+                                (float)epsilon, (uint64_t)seed, (uint32_t)step0, (uint64_t)row0, (int)select,
+                                actions.data_ptr<int64_t>(), reward.data_ptr<float>(), terminated.data_ptr<uint8_t>(),
+                                win.data_ptr<uint8_t>(), opt_ptr<float>(obs), opt_ptr<float>(state_out), stream_of(state)));
+}
+
 // common/rollout.py:66-76,105-132 + replay_buffer.py:41-61: step-major tables -> the 11-key episode batch (cs_store_episodes);
 // `outs` in the order o, u, s, r, o_next, s_next, avail_u, avail_u_next, u_onehot, padded, terminated
 void store_episodes(const Tensor &o_tab, const Tensor &s_tab, const Tensor &u_tab, const Tensor &r_tab, const Tensor &term_tab,
@@ -307,6 +340,10 @@ TORCH_LIBRARY(coopsearch, m) {
     m.def("rollout_policy(Tensor cfg, Tensor(a!) state, Tensor packed, Tensor(b!) hidden, Tensor last, int T, int flags, "
           "float epsilon, int seed, int step0, int row0, int select, Tensor(c!) actions, Tensor(d!) reward, Tensor(e!) terminated, "
           "Tensor(f!) win, Tensor(g!)? obs, Tensor(h!)? state_out) -> ()", &rollout_policy);
+    m.def("rollout_policy_flight(Tensor cfg, Tensor(a!) state, Tensor packed, Tensor c1w, Tensor c1b, Tensor c2w, Tensor c2b, "
+          "Tensor lw, Tensor lb, Tensor(b!) hidden, Tensor last, Tensor(i!) scratch, int T, int flags, float epsilon, int seed, "
+          "int step0, int row0, int select, Tensor(c!) actions, Tensor(d!) reward, Tensor(e!) terminated, Tensor(f!) win, "
+          "Tensor(g!)? obs, Tensor(h!)? state_out) -> ()", &rollout_policy_flight);
     m.def("store_episodes(Tensor o_tab, Tensor s_tab, Tensor u_tab, Tensor r_tab, Tensor term_tab, Tensor? slots, int n_actions, "
           "Tensor(a!)[] outs) -> ()", &store_episodes);
 }

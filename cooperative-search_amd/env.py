@@ -310,17 +310,18 @@ class BatchedFlightEnv:
         return out
 
     def rollout_policy(self, agents, T, epsilon=0.0, evaluate=True, emit=True, out=None, update_views=True):
-        """T closed-loop steps in ONE launch (flight_easy, n <= 5): each step runs `agents`' network (a `FusedAgents`) on
-        the current observation, picks the actions and steps the envs -- exactly what T x
-        `env.step(agents.choose_action(env.get_obs(), epsilon, evaluate))` computes, with the hidden state, the actions
-        and the envs resident on chip in between.  Returns the `rollout` dict plus `actions` (int64 [T, B, n]);
-        `agents.hidden` / `agents.actions` / `agents.calls` advance as if the T calls had been made."""
-        if self.flight:
-            raise _lib.CoopSearchError("rollout_policy: flight_easy only")
+        """T closed-loop steps in ONE call: each step runs `agents`' network (a `FusedAgents`) on the current observation,
+        picks the actions and steps the envs -- exactly what T x
+        `env.step(agents.choose_action(env.get_obs(), epsilon, evaluate))` computes.  flight_easy (n <= 5): one launch,
+        with the hidden state, the actions and the envs resident on chip in between.  flight: three kernels per step
+        enqueued by one call (cs_rollout_policy_flight): the conv front end reads every env's map where it lives, and
+        with emit=False the n observation copies of the map are never written.  Returns the `rollout` dict plus `actions`
+        (int64 [T, B, n]); `agents.hidden` / `agents.actions` / `agents.calls` advance as if the T calls had been made."""
         T = int(T)
         B, n = self.batch, self.n_agents
-        if agents.rows != B * n or getattr(agents, "conv", False):
-            raise ValueError("rollout_policy: `agents` must be a non-conv FusedAgents for this env's batch")
+        if agents.rows != B * n or bool(getattr(agents, "conv", False)) != self.flight:
+            raise ValueError("rollout_policy: `agents` must be a FusedAgents for this env's batch "
+                             "(with the conv front end for flight, without it for flight_easy)")
         out = dict(out) if out else {}
         dev = self.device
         spec = dict(reward=((T, B), torch.float32), terminated=((T, B), torch.uint8), win=((T, B), torch.uint8),
@@ -335,7 +336,24 @@ class BatchedFlightEnv:
         has_obs = out.get("obs") is not None and out.get("state") is not None
         flags = (_lib.FREEZE_DONE if self.freeze_done else 0) | (_lib.AUTO_RESET if self.auto_reset else 0)
         sel_eps, sel_flags = agents.selection(epsilon, evaluate)
-        if self._ops is not None:
+        if self.flight:
+            scratch = getattr(agents, "_flight_scratch", None)
+            if scratch is None or scratch.numel() != B * (16 + 4 * n):
+                scratch = agents._flight_scratch = torch.empty(B, 16 + 4 * n, dtype=torch.float32, device=dev)
+            if self._ops is not None:
+                self._ops.rollout_policy_flight(self._cfg_t, self._blob, agents.packed, *agents.conv_w, agents.hidden,
+                                                agents.actions, scratch, T, flags, sel_eps, agents.seed, agents.calls,
+                                                agents.row0, sel_flags, out["actions"], out["reward"],
+                                                out["terminated"].view(torch.uint8), out["win"].view(torch.uint8),
+                                                out["obs"] if has_obs else None, out["state"] if has_obs else None)
+            else:
+                _lib.check(self._L.cs_rollout_policy_flight(
+                    self._cfgp, self._blob.data_ptr(), agents.packed.data_ptr(), *[w.data_ptr() for w in agents.conv_w],
+                    agents.hidden.data_ptr(), agents.actions.data_ptr(), scratch.data_ptr(), T, flags, sel_eps, agents.seed,
+                    agents.calls, agents.row0, sel_flags, out["actions"].data_ptr(), out["reward"].data_ptr(),
+                    out["terminated"].data_ptr(), out["win"].data_ptr(), out["obs"].data_ptr() if has_obs else None,
+                    out["state"].data_ptr() if has_obs else None, self._stream()))
+        elif self._ops is not None:
             self._ops.rollout_policy(self._cfg_t, self._blob, agents.packed, agents.hidden, agents.actions, T, flags, sel_eps,
                                      agents.seed, agents.calls, agents.row0, sel_flags, out["actions"], out["reward"],
                                      out["terminated"].view(torch.uint8), out["win"].view(torch.uint8),

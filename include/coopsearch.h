@@ -239,6 +239,23 @@ int cs_rollout_policy(const cs_config *cfg, void *state_dev, const float *packed
                       uint64_t row0, int select, int64_t *actions_dev, float *reward_dev, uint8_t *terminated_dev,
                       uint8_t *win_dev, float *obs_dev, float *state_out_dev, void *stream);
 
+/* Closed loop for flight (the loop body of common/rollout.py:43-76 with the conv network of network/base_net.py:9-36):
+ * T x (cs_policy_conv_features -> cs_policy_forward -> cs_step) enqueued by ONE call.  Bit for bit the results of the T
+ * triples of calls; what changes is the data movement: the conv front end reads every env's probability map where it
+ * lives in the state blob (one 10 KB read per env instead of a pass over the n observation copies), and with
+ * obs_dev == NULL the n copies of the map that get_obs emits (flight_env.py:223-230) are never written -- the network
+ * is their only consumer inside the loop.  The map update still runs every step.
+ *   conv1_w_dev .. lin_b_dev   the six tensors of cs_policy_conv_features
+ *   scratch_dev                float [B][16 + 4 n_agents] (conv features; the agents' own 4 observation floats)
+ *   last_dev                   int64 [B][n] action before the first step (< 0 = none)
+ *   actions_dev                int64 [T][B][n] chosen actions (out); obs_dev / state_out_dev NULL or as in cs_rollout */
+int cs_rollout_policy_flight(const cs_config *cfg, void *state_dev, const float *packed_dev, const float *conv1_w_dev,
+                             const float *conv1_b_dev, const float *conv2_w_dev, const float *conv2_b_dev,
+                             const float *lin_w_dev, const float *lin_b_dev, float *hidden_dev, const int64_t *last_dev,
+                             float *scratch_dev, int T, int flags, float epsilon, uint64_t seed, uint32_t step0, uint64_t row0,
+                             int select, int64_t *actions_dev, float *reward_dev, uint8_t *terminated_dev, uint8_t *win_dev,
+                             float *obs_dev, float *state_out_dev, void *stream);
+
 /* ---- caller-side rows f1 / f2: episode batch assembly ------------------------------------------------------------
  * common/rollout.py:66-76,105-132 (the eleven per-episode arrays and their padding: steps after termination are zero
  * rows with padded = 1, terminated = 1) and common/replay_buffer.py:41-61 (store_episode) in one pass over the

@@ -165,7 +165,7 @@ def test_torch_op_library_builds_loads_and_registers_every_op():
     ops = _lib.torch_ops()
     for name in ("abi_version", "state_bytes", "env_init", "env_seed", "env_reset", "env_step", "env_rollout", "env_emit",
                  "env_metrics", "mt_advance", "mt_canonical", "policy_packed_floats", "policy_forward", "policy_conv_features",
-                 "rollout_policy", "store_episodes"):
+                 "rollout_policy", "rollout_policy_flight", "store_episodes"):
         assert hasattr(ops, name), name
     assert int(ops.abi_version()) == _lib.ABI_VERSION
     import torch

@@ -257,6 +257,52 @@ def test_fused_closed_loop_rollout_equals_stepwise(n, B, T, eps, auto_reset):
         assert (oa["actions"] != oa["actions"][0:1]).any()
 
 
+@pytest.mark.parametrize("n,B,T,eps,auto_reset,emit", [(3, 64, 30, 0.0, False, True), (3, 37, 25, 0.25, True, False),
+                                                       (5, 50, 12, 0.1, True, True), (2, 300, 21, 0.3, True, False)])
+def test_flight_closed_loop_call_equals_stepwise(n, B, T, eps, auto_reset, emit):
+    """cs_rollout_policy_flight (conv on the map where it lives, no observation copies when emit=False) against T x
+    (choose_action(get_obs) -> step): same actions, rewards, hidden state, env state and probability maps."""
+    a = cs.make_env_args("flight", n_agents=n)
+    a.time_limit = 9
+    torch.manual_seed(7 * n + B)
+    outs = []
+    net = None
+    for fused_loop in (False, True):
+        env = cs.BatchedFlightEnv(a, batch=B, freeze_done=not auto_reset, auto_reset=auto_reset)
+        cs.apply_env_info(a, env)
+        if net is None:
+            net = AgentRNN(rnn_input_shape(a), a).cuda()
+            for p in net.parameters():
+                p.data.mul_(2.0)
+        env.seed(np.arange(B) + 5)
+        env.reset(init=True)
+        ag = FusedAgents(a, B, net=net, seed=99)
+        if fused_loop:
+            o = env.rollout_policy(ag, T, epsilon=eps, evaluate=False, emit=emit)
+            o = {k: v for k, v in o.items() if v is not None}
+        else:
+            o = dict(actions=[], reward=[], terminated=[], win=[], obs=[], state=[])
+            for t in range(T):
+                act = ag.choose_action(env.get_obs(), epsilon=eps)
+                r, term, win = env.step(act)
+                for k, v in (("actions", act), ("reward", r), ("terminated", term), ("win", win), ("obs", env.get_obs()),
+                             ("state", env.get_state())):
+                    o[k].append(v.clone())
+            o = {k: torch.stack(v) for k, v in o.items()}
+        raw = env.raw()
+        outs.append((o, ag.hidden.clone(), ag.actions.clone(), ag.calls, raw["hdr"].clone(), raw["agent"].clone(),
+                     raw["prob"].clone(), env.get_obs().clone(), env.get_state().clone()))
+    (oa, ha, la, ca, hdra, aga, pa, obsa, sta), (ob, hb, lb, cb, hdrb, agb, pb, obsb, stb) = outs
+    assert ("obs" in ob) == emit
+    for k in ob:
+        assert torch.equal(oa[k], ob[k]), k
+    assert torch.equal(ha, hb) and torch.equal(la, lb) and ca == cb
+    assert torch.equal(hdra, hdrb) and torch.equal(aga, agb) and torch.equal(pa, pb)
+    assert torch.equal(obsa, obsb) and torch.equal(sta, stb)
+    if eps > 0:
+        assert (oa["actions"] != oa["actions"][0:1]).any()
+
+
 def test_closed_loop_c_example_runs(tmp_path):
     """examples/closed_loop_demo.cpp: cs_policy_pack -> cs_rollout_policy -> cs_store_episodes from plain C++/HIP."""
     import re, subprocess

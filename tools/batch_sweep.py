@@ -4,9 +4,10 @@ import json, subprocess, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rows = []
 for n in (3, 5):
-    for logb in range(10, 21, 2):
-        B = 1 << logb
+    for B in (1024, 2048, 4096, 8192, 16384, 65536, 262144, 1048576):
         for kernel in ("solo", "duo", "lane"):
+            if kernel == "lane" and B in (2048, 8192):
+                continue
             if kernel != "lane" and B > (1 << 18):
                 continue
             if kernel == "duo" and B > (1 << 14):
