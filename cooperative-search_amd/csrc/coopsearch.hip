@@ -941,7 +941,7 @@ __device__ unsigned long long g_stamps[64][16];
 #define CS_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && g_tl_step >= 0 && g_tl_step < 64) g_stamps[g_tl_step][k] = __builtin_readcyclecounter(); } while (0)
 __device__ int g_tl_step_dummy;
 #define LANE_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && s < 64) g_stamps[s][k] = __builtin_readcyclecounter(); } while (0)
-#define DUO_STAMP(k) do { if (blockIdx.x == 0 && (threadIdx.x & 255) == 0 && s < 64) g_stamps[s][k] = __builtin_readcyclecounter(); } while (0)
+#define DUO_STAMP(k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && s < 64) g_stamps[s][k] = __builtin_readcyclecounter(); } while (0)
 #else
 #define DUO_STAMP(k) do {} while (0)
 #define CS_STAMP(k) do {} while (0)
@@ -2437,6 +2437,75 @@ __device__ __forceinline__ void build_rowbits(const DevParams &p, const double (
 constexpr int MAP_BLOCK = CS_MAP_BLOCK;
 constexpr int MAP_ILP = CS_MAP_ILP;   // float4 chunks per thread, all loaded before the first is processed
 
+// The pending pass(es) applied to float4 chunk c of an env's map: true if a cell changed (flight_env.py:275-303).
+__device__ __forceinline__ bool map_update_chunk(const DevParams &p, const MapPassLds *s_pass, bool dirty, bool reset_pass, int c,
+                                                 float4 &v) {
+    const float qf = (float)p.q;
+    const float inv_map = 1.0f / (float)p.map_size;
+    float pv[4] = {v.x, v.y, v.z, v.w};
+    const int cell0 = 4 * c;
+    const int ci = (int)(((float)cell0 + 0.5f) * inv_map);  // exact for cell0 < 4096
+    const int cj0 = cell0 - ci * p.map_size;
+    unsigned any = 0;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        if (k == 0 ? !reset_pass : !dirty) continue;
+        const MapPassLds &m = s_pass[k];
+        const unsigned long long r0 = m.rowbits[ci], r1 = m.rowbits[ci + 1];
+        const unsigned long long r2 = m.rowbits[ci + 2 <= CS_MAX_MAP + 1 ? ci + 2 : CS_MAX_MAP + 1];
+        unsigned cnts = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const bool wrap = cj0 + q >= p.map_size;  // chunk straddles two rows when map_size % 4 != 0
+            const int yi = wrap ? cj0 + q - p.map_size : cj0 + q;
+            const unsigned long long ra = wrap ? r1 : r0, rb = wrap ? r2 : r1;
+            const int cnt = __popc((unsigned)((ra >> yi) & 3ull)) + __popc((unsigned)((rb >> yi) & 3ull));
+            // percent*(1-detect_prob)*p / ((1-detect_prob)*p + (1-p)), flight_env.py:292
+            const float upd = ((float)cnt * 0.25f) * qf * pv[q] / (qf * pv[q] + (1.0f - pv[q]));
+            pv[q] = cnt ? upd : pv[q];
+            cnts |= (unsigned)cnt << (4 * q);
+        }
+        if (m.any_found && cnts) {  // a newly found target's cell, if in view, is set to 1 (:288-289)
+            for (int j = 0; j < p.n_targets; j++) {
+                const int d = m.cells[j] - cell0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) pv[q] = (d == q && ((cnts >> (4 * q)) & 0xfu)) ? 1.0f : pv[q];
+            }
+        }
+        any |= cnts;
+    }
+    if (any) v = make_float4(pv[0], pv[1], pv[2], pv[3]);
+    return any != 0;
+}
+
+// One wavefront's share of a pass: lattice bitmap + cells of the newly found targets (lane < 16) into `pass`.
+template <int N>
+__device__ __forceinline__ void map_build_pass(const DevParams &p, int k, const double (&jx)[N], const double (&jy)[N],
+                                               unsigned newly, int cell, int lane, MapPassLds &pass) {
+    double ax[N], ay[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        if (k == 1) {
+            ax[i] = jx[i];
+            ay[i] = jy[i];
+        } else {
+            const double s = N != 1 ? (double)(i * p.map_size) / (double)(N - 1) : p.L / 2.0;  // flight_env.py:148-187
+            switch (p.agent_mode) {
+            case 0: ax[i] = s; ay[i] = 0.0; break;
+            case 1: ax[i] = s; ay[i] = p.L / 2.0; break;
+            case 2: ax[i] = 0.0; ay[i] = s; break;
+            default: ax[i] = p.L; ay[i] = s; break;
+            }
+        }
+    }
+    build_rowbits<N>(p, ax, ay, lane, pass.rowbits);
+    if (lane == 63) pass.rowbits[CS_MAX_MAP + 1] = 0;  // row map_size + 1 is read by wrapping chunks
+    if (lane < CS_MAX_TARGETS) {  // cells of the newly found targets
+        pass.cells[lane] = ((newly >> lane) & 1u) ? cell : -1;
+        if (lane == 0) pass.any_found = newly != 0;
+    }
+}
+
 template <int N, int ILP>
 __device__ __forceinline__ void map_sweep(const DevParams &p, MapPassLds *s_pass, float *obs, int apply, int parity, int b,
                                           int yblk) {
@@ -2461,79 +2530,25 @@ __device__ __forceinline__ void map_sweep(const DevParams &p, MapPassLds *s_pass
         // wave 0 builds the step's pass and wave 1 the reset-time pass (a one-wave workgroup builds both in turn)
         for (int k = 1; k >= 0; k--) {
             if (wave != (MAP_BLOCK >= 128 ? 1 - k : 0) || !(k == 1 ? dirty : reset_pass)) continue;
-            double ax[N], ay[N];
+            double jx[N], jy[N];
 #pragma unroll
             for (int i = 0; i < N; i++) {
-                if (k == 1) {
-                    const double2 a = *reinterpret_cast<const double2 *>(job->axy[i]);
-                    ax[i] = a.x;
-                    ay[i] = a.y;
-                } else {
-                    const double s = N != 1 ? (double)(i * p.map_size) / (double)(N - 1) : p.L / 2.0;  // flight_env.py:148-187
-                    switch (p.agent_mode) {
-                    case 0: ax[i] = s; ay[i] = 0.0; break;
-                    case 1: ax[i] = s; ay[i] = p.L / 2.0; break;
-                    case 2: ax[i] = 0.0; ay[i] = s; break;
-                    default: ax[i] = p.L; ay[i] = s; break;
-                    }
-                }
+                const double2 a = *reinterpret_cast<const double2 *>(job->axy[i]);
+                jx[i] = a.x;
+                jy[i] = a.y;
             }
-            build_rowbits<N>(p, ax, ay, lane, s_pass[k].rowbits);
-            if (lane == 63) s_pass[k].rowbits[CS_MAX_MAP + 1] = 0;  // row map_size + 1 is read by wrapping chunks
-            if (lane < CS_MAX_TARGETS) {  // cells of the newly found targets
-                const unsigned newly = k == 0 ? job->newly_reset : job->newly;
-                s_pass[k].cells[lane] = ((newly >> lane) & 1u) ? job->cell[lane] : -1;
-                if (lane == 0) s_pass[k].any_found = newly != 0;
-            }
+            map_build_pass<N>(p, k, jx, jy, k == 0 ? job->newly_reset : job->newly, job->cell[lane & (CS_MAX_TARGETS - 1)], lane,
+                              s_pass[k]);
         }
     }
     __syncthreads();  // uniform: dirty / reset_pass are per-workgroup values
     const size_t row_w = (size_t)p.cells + 4;
-    const float qf = (float)p.q;
-    const float inv_map = 1.0f / (float)p.map_size;
 #pragma unroll
     for (int kc = 0; kc < ILP; kc++) {
         const int c = c_first + kc * MAP_BLOCK;
         if (c >= nchunks) break;
         float4 v = v_in[kc];
-        if (dirty || reset_pass) {
-            float pv[4] = {v.x, v.y, v.z, v.w};
-            const int cell0 = 4 * c;
-            const int ci = (int)(((float)cell0 + 0.5f) * inv_map);  // exact for cell0 < 4096
-            const int cj0 = cell0 - ci * p.map_size;
-            unsigned any = 0;
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                if (k == 0 ? !reset_pass : !dirty) continue;
-                const MapPassLds &m = s_pass[k];
-                const unsigned long long r0 = m.rowbits[ci], r1 = m.rowbits[ci + 1];
-                const unsigned long long r2 = m.rowbits[ci + 2 <= CS_MAX_MAP + 1 ? ci + 2 : CS_MAX_MAP + 1];
-                unsigned cnts = 0;
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const bool wrap = cj0 + q >= p.map_size;  // chunk straddles two rows when map_size % 4 != 0
-                    const int yi = wrap ? cj0 + q - p.map_size : cj0 + q;
-                    const unsigned long long ra = wrap ? r1 : r0, rb = wrap ? r2 : r1;
-                    const int cnt = __popc((unsigned)((ra >> yi) & 3ull)) + __popc((unsigned)((rb >> yi) & 3ull));
-                    // percent*(1-detect_prob)*p / ((1-detect_prob)*p + (1-p)), flight_env.py:292
-                    const float upd = ((float)cnt * 0.25f) * qf * pv[q] / (qf * pv[q] + (1.0f - pv[q]));
-                    pv[q] = cnt ? upd : pv[q];
-                    cnts |= (unsigned)cnt << (4 * q);
-                }
-                if (m.any_found && cnts) {  // a newly found target's cell, if in view, is set to 1 (:288-289)
-                    for (int j = 0; j < p.n_targets; j++) {
-                        const int d = m.cells[j] - cell0;
-#pragma unroll
-                        for (int q = 0; q < 4; q++) pv[q] = (d == q && ((cnts >> (4 * q)) & 0xfu)) ? 1.0f : pv[q];
-                    }
-                }
-                any |= cnts;
-            }
-            if (any) {
-                v = make_float4(pv[0], pv[1], pv[2], pv[3]);
-                m4[c] = v;
-            }
-        }
+        if ((dirty || reset_pass) && map_update_chunk(p, s_pass, dirty, reset_pass, c, v)) m4[c] = v;
         if (obs) {
             const v4f nv = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -2552,6 +2567,15 @@ template <int N>
 __global__ __launch_bounds__(MAP_BLOCK) void k_map(DevParams p, float *obs, int apply, int parity) {
     __shared__ MapPassLds s_pass[2];  // [0] reset-time pass at the start positions, [1] the step's pass
     map_sweep<N, MAP_ILP>(p, s_pass, obs, apply, parity, blockIdx.x, blockIdx.y);
+}
+
+// The update alone (no observation rows wanted): without the n output copies to hide it, the sweep is bound by the
+// per-workgroup prologue (job record -> lattice bitmap -> barrier), so one workgroup per env does the whole map.
+constexpr int MAP_UPD_ILP = (CS_MAX_MAP * CS_MAX_MAP / 4 + MAP_BLOCK - 1) / MAP_BLOCK;
+template <int N>
+__global__ __launch_bounds__(MAP_BLOCK) void k_map_update(DevParams p, int parity) {
+    __shared__ MapPassLds s_pass[2];
+    map_sweep<N, MAP_UPD_ILP>(p, s_pass, nullptr, 1, parity, blockIdx.x, 0);
 }
 
 // flight rollouts: the map sweep of step t and the kinematics / detection of step t + 1 in ONE launch.  The two do not
@@ -2941,7 +2965,11 @@ int cs_step(const cs_config *cfg, void *state_dev, const void *actions_dev, int 
         CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL((k_step<N, 0>), dim3(env_blocks(p)), dim3(BLOCK), 0, s, p, io));
     } else {
         CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL((k_step<N, 1>), dim3(env_blocks(p)), dim3(BLOCK), 0, s, p, io));
-        CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_map<N>, map_grid(p), dim3(MAP_BLOCK), 0, s, p, obs_dev, 1, 0));
+        if (obs_dev) {
+            CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_map<N>, map_grid(p), dim3(MAP_BLOCK), 0, s, p, obs_dev, 1, 0));
+        } else {
+            CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_map_update<N>, dim3((unsigned)p.B), dim3(MAP_BLOCK), 0, s, p, 0));
+        }
     }
     return launched("cs_step");
 }
@@ -3085,11 +3113,15 @@ int cs_rollout_policy_flight(const cs_config *cfg, void *state_dev, const float 
             return fail(CS_E_LAUNCH, cs_policy_last_error());
         StepIO it{act, reward_dev + (size_t)t * B, terminated_dev + (size_t)t * B, win_dev + (size_t)t * B,
                   obs_dev ? obs_dev + (size_t)t * B * obs_w : tails,
-                  state_out_dev ? state_out_dev + (size_t)t * B * W : nullptr, (flags & ~CS_ACTIONS_I64) | CS_ACTIONS_I64, 1};
+                  state_out_dev ? state_out_dev + (size_t)t * B * W : nullptr, flags | CS_ACTIONS_I64, 1};
         CS_DISPATCH_N(cfg->n_agents,
                       hipLaunchKernelGGL((k_step<N, 1>), dim3(env_blocks(p)), dim3(BLOCK), 0, s, obs_dev ? p : pc, it));
-        CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_map<N>, map_grid(p), dim3(MAP_BLOCK), 0, s, p,
-                                                        obs_dev ? obs_dev + (size_t)t * B * obs_w : nullptr, 1, 0));
+        if (obs_dev) {
+            CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_map<N>, map_grid(p), dim3(MAP_BLOCK), 0, s, p,
+                                                            obs_dev + (size_t)t * B * obs_w, 1, 0));
+        } else {   // the update alone: fusing it into the conv kernel was measured slower
+            CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_map_update<N>, dim3((unsigned)p.B), dim3(MAP_BLOCK), 0, s, p, 0));
+        }
     }
     return launched("cs_rollout_policy_flight");
 }
