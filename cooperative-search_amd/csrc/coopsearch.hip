@@ -283,7 +283,20 @@ __device__ __forceinline__ void trig_heading(const double *T, double yaw, double
 }
 
 __device__ __forceinline__ void load_trig_to_lds(double *T) {
-    for (int i = threadIdx.x; i < TRIG_ROWS * TRIG_COLS; i += blockDim.x) T[i] = (&g_trig[0][0])[i];
+    // every launch starts with this round trip: all of a thread's loads in flight together (workgroups of >= 128 threads)
+    constexpr int NT = TRIG_ROWS * TRIG_COLS, PER = (NT + 127) / 128;
+    const double *src = &g_trig[0][0];
+    double v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int i = threadIdx.x + k * blockDim.x;
+        v[k] = src[i < NT ? i : NT - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int i = threadIdx.x + k * blockDim.x;
+        if (i < NT) T[i] = v[k];
+    }
     __syncthreads();
 }
 
@@ -942,8 +955,10 @@ __device__ unsigned long long g_stamps[64][16];
 __device__ int g_tl_step_dummy;
 #define LANE_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && s < 64) g_stamps[s][k] = __builtin_readcyclecounter(); } while (0)
 #define DUO_STAMP(k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && s < 64) g_stamps[s][k] = __builtin_readcyclecounter(); } while (0)
+#define DUO_MARK(row, k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_stamps[row][k] = __builtin_readcyclecounter(); } while (0)
 #else
 #define DUO_STAMP(k) do {} while (0)
+#define DUO_MARK(row, k) do {} while (0)
 #define CS_STAMP(k) do {} while (0)
 #define LANE_STAMP(k) do {} while (0)
 #endif
@@ -1284,6 +1299,7 @@ __global__ __launch_bounds__(DUO_BLOCK, 2) void k_rollout_duo(DevParams p, StepI
     __shared__ unsigned rowbufs[DUO_PAIRS][MT_N];        // one MT19937 row per D wavefront (prologue top-up)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool is_k = wave < DUO_PAIRS;
+    DUO_MARK(63, is_k ? 3 : 13);   // entry
     const int pw = wave % DUO_PAIRS;             // wave pair = 4 envs
     const int t = lane & (G - 1), grp = lane >> 4, gshift = lane & ~(G - 1);
     const int el = 4 * pw + grp;                 // env within the block
@@ -1295,6 +1311,7 @@ __global__ __launch_bounds__(DUO_BLOCK, 2) void k_rollout_duo(DevParams p, StepI
     Env<N> e;
     if (live) env_load<N>(p, b, t, e);
     load_trig_to_lds(T);
+    DUO_MARK(63, is_k ? 4 : 14);   // state requested, trig table in LDS
     WaveTile &tile = tiles[wave];
     const size_t arow = live ? (size_t)b : 0;
 
@@ -1391,6 +1408,7 @@ __global__ __launch_bounds__(DUO_BLOCK, 2) void k_rollout_duo(DevParams p, StepI
             for (int i = 0; i < N; i++)
                 if (t == i) a4[i] = make_double4(e.ax[i], e.ay[i], e.yaw[i], 0.0);
         }
+        DUO_MARK(63, 5);
         return;
     }
 
@@ -1493,6 +1511,7 @@ __global__ __launch_bounds__(DUO_BLOCK, 2) void k_rollout_duo(DevParams p, StepI
         p.ahead[b] = e.ahead;
     }
     if (live && tape_ok) group_tape_store<N>(p, b, t, e, tape);
+    DUO_MARK(63, 15);
 }
 
 // =========================================================================================================
@@ -3036,7 +3055,8 @@ int cs_rollout(const cs_config *cfg, void *state_dev, const void *actions_dev, i
         CS_DISPATCH_N(cfg->n_agents,
                       hipLaunchKernelGGL(k_rollout<N>, dim3(env_blocks(p)), dim3(BLOCK), 0, (hipStream_t)stream, p, io));
     } else {
-        io.min_ahead = prepass_min_ahead(cfg, T);
+        // the pair tops rows up in place whenever one runs low (D's loop), so the prologue only has to cover one step
+        io.min_ahead = 2 * cfg->n_agents * CS_MAX_TARGETS;
         CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_rollout_duo<N>, dim3((unsigned)((p.B + DUO_ENVS - 1) / DUO_ENVS)), dim3(DUO_BLOCK),
                                                         0, (hipStream_t)stream, p, io));
     }
