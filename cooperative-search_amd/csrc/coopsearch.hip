@@ -1321,7 +1321,7 @@ __global__ __launch_bounds__(DUO_BLOCK, 2) void k_rollout_duo(DevParams p, StepI
         load_actions<N>(io, arow, act);
         bool k_done = live && (e.target_find >= p.n_targets || e.time_step >= p.time_limit);   // exact at launch
         int k_time = e.time_step;
-        if (live) env_trig<N>(T, e);   // what a frozen env keeps emitting
+        if (live && freeze) env_trig<N>(T, e);   // what a frozen env keeps emitting (every other path recomputes cs / sn)
         // produces the state after step `sp` from the state after step sp - 1 and writes it to the ring
         auto produce = [&](int sp, const int (&a)[N]) __attribute__((always_inline)) {
             if (live) {
