@@ -1089,13 +1089,28 @@ __device__ __forceinline__ void emit_flush_store(const DevParams &p, const StepI
     io.reward[slot0 + pl.rtw] = f.reward;  // duplicates write the same value
     io.terminated[slot0 + pl.rtw] = (uint8_t)f.term;
     io.win[slot0 + pl.rtw] = (uint8_t)f.win;
+#ifndef CS_EMIT_NT
+#define CS_EMIT_NT 1
+#endif
     if (io.obs) {  // one float4 per (env, agent)
-        *reinterpret_cast<float4 *>(io.obs + slot0 * N * (size_t)p.obs_row_w + pl.obs_out) = f.obs;
+        float4 *dst = reinterpret_cast<float4 *>(io.obs + slot0 * N * (size_t)p.obs_row_w + pl.obs_out);
+#if CS_EMIT_NT
+        const v4f nv = {f.obs.x, f.obs.y, f.obs.z, f.obs.w};
+        __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(dst));
+#else
+        *dst = f.obs;
+#endif
     }
     if (io.state) {  // the wavefront's rows are contiguous in get_state's [B][W] layout
         float *dst = io.state + slot0 * (size_t)(4 * N + 3 * p.n_targets);
 #pragma unroll
-        for (int k = 0; k < EmitPlan<N>::K; k++) dst[pl.st_out[k]] = f.st[k];
+        for (int k = 0; k < EmitPlan<N>::K; k++) {
+#if CS_EMIT_NT
+            __builtin_nontemporal_store(f.st[k], dst + pl.st_out[k]);
+#else
+            dst[pl.st_out[k]] = f.st[k];
+#endif
+        }
     }
 }
 
