@@ -242,19 +242,29 @@ __device__ __forceinline__ void tape_shift(unsigned (&t)[TAPE_DW], int n) {
 
 // An env's hit tape from the state blob, shifted to the env's cursor; returns false when the stored tape does not
 // describe the words twisted ahead of this cursor (never built, other detect_prob, ...): the caller rebuilds it.
-template <class EnvT>
-__device__ __forceinline__ bool tape_load(const DevParams &p, int b, const EnvT &e, unsigned (&tape)[TAPE_DW]) {
+// the env's stored tape record: requested early (with the rest of the state), interpreted once it is needed
+struct TapeRaw {
+    U4 t0, t1, t2, t3;
+};
+__device__ __forceinline__ TapeRaw tape_fetch(const DevParams &p, int b) {
     const U4 *tp = reinterpret_cast<const U4 *>(p.tape + (size_t)b * TAPE_STRIDE);
-    const U4 t0 = tp[0], t1 = tp[1], t2 = tp[2], t3 = tp[3];
-    tape[0] = t0.x; tape[1] = t0.y; tape[2] = t0.z; tape[3] = t0.w;
-    tape[4] = t1.x; tape[5] = t1.y; tape[6] = t1.z; tape[7] = t1.w;
-    tape[8] = t2.x; tape[9] = t2.y;
-    const unsigned long long base = (unsigned long long)t2.z | ((unsigned long long)t2.w << 32);
-    const unsigned long long K = (unsigned long long)t3.x | ((unsigned long long)t3.y << 32);
+    return TapeRaw{tp[0], tp[1], tp[2], tp[3]};
+}
+template <class EnvT>
+__device__ __forceinline__ bool tape_finish(const DevParams &p, const TapeRaw &r, const EnvT &e, unsigned (&tape)[TAPE_DW]) {
+    tape[0] = r.t0.x; tape[1] = r.t0.y; tape[2] = r.t0.z; tape[3] = r.t0.w;
+    tape[4] = r.t1.x; tape[5] = r.t1.y; tape[6] = r.t1.z; tape[7] = r.t1.w;
+    tape[8] = r.t2.x; tape[9] = r.t2.y;
+    const unsigned long long base = (unsigned long long)r.t2.z | ((unsigned long long)r.t2.w << 32);
+    const unsigned long long K = (unsigned long long)r.t3.x | ((unsigned long long)r.t3.y << 32);
     const unsigned long long used = e.words - base;   // words consumed since the tape was written
     const bool ok = K == p.detect_K && e.words >= base && used + (unsigned long long)e.ahead <= (unsigned long long)MT_N;
     tape_shift<8>(tape, ok ? (int)(used >> 1) : 0);
     return ok;
+}
+template <class EnvT>
+__device__ __forceinline__ bool tape_load(const DevParams &p, int b, const EnvT &e, unsigned (&tape)[TAPE_DW]) {
+    return tape_finish(p, tape_fetch(p, b), e, tape);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1225,11 +1235,16 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(DevParams p, StepIO io) {
     const int b = gid / G, t = gid % G;
     const int lane = threadIdx.x & 63;
     const bool live = b < p.B;
+    // the env's hit tape (cs_mt_advance), replicated in the group's lanes; teams of 5 and more keep the on-demand
+    // window instead: the ten tape registers would cost them their second wavefront per SIMD
+    constexpr bool USE_TAPE = N <= 4;
     Env<N> e;
     int act[N];
-    if (live) {
+    TapeRaw traw = {};
+    if (live) {   // everything the first step waits for is requested before the barrier that publishes the trig table
         env_load<N>(p, b, t, e);
         load_actions<N>(io, (size_t)b, act);
+        if (USE_TAPE) traw = tape_fetch(p, b);
     }
     load_trig_to_lds(T);
     const int wave_b0 = (blockIdx.x * BLOCK + (threadIdx.x & ~63)) / G;
@@ -1239,13 +1254,10 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(DevParams p, StepIO io) {
     const EmitPlan<N> plan = make_emit_plan<N>(p, lane, nvalid);
     constexpr bool PIPE = N <= 4;
     MtWin win = {0u, 0u};
-    // the env's hit tape (cs_mt_advance), replicated in the group's lanes; teams of 5 and more keep the on-demand
-    // window instead: the ten tape registers would cost them their second wavefront per SIMD
-    constexpr bool USE_TAPE = N <= 4;
     unsigned tape[TAPE_DW];
     bool tape_ok = false;
     if (USE_TAPE) {
-        if (live) tape_ok = tape_load(p, b, e, tape);
+        if (live) tape_ok = tape_finish(p, traw, e, tape);
         group_wave_advance<N>(p, wave_b0, nvalid, lane, io.min_ahead, rowbufs[N <= 4 ? threadIdx.x >> 6 : 0], e, tape, tape_ok);
     }
     if (!USE_TAPE && live) win = mt_prefetch(p.mt + (size_t)b * MT_STRIDE, e.mt_pos, t);
@@ -1325,15 +1337,22 @@ __global__ __launch_bounds__(DUO_BLOCK, 2) void k_rollout_duo(DevParams p, StepI
     const bool auto_reset = io.flags & CS_AUTO_RESET, freeze = io.flags & CS_FREEZE_DONE;
     Env<N> e;
     if (live) env_load<N>(p, b, t, e);
+    // everything either role will wait for first is requested before the barrier that publishes the trig table
+    const size_t arow = live ? (size_t)b : 0;
+    int act[N], act_next[N];
+    TapeRaw traw = {};
+    if (is_k) {
+        load_actions<N>(io, arow, act);
+        load_actions<N>(io, (size_t)(1 < io.T ? 1 : 0) * p.B + arow, act_next);   // one step ahead of its use
+    } else if (live) {
+        traw = tape_fetch(p, b);
+    }
     load_trig_to_lds(T);
     DUO_MARK(63, is_k ? 4 : 14);   // state requested, trig table in LDS
     WaveTile &tile = tiles[wave];
-    const size_t arow = live ? (size_t)b : 0;
 
     if (is_k) {
         // ------------------------------------------------------------------------------------------ K: kinematics
-        int act[N], act_next[N];
-        load_actions<N>(io, arow, act);
         bool k_done = live && (e.target_find >= p.n_targets || e.time_step >= p.time_limit);   // exact at launch
         int k_time = e.time_step;
         if (live && freeze) env_trig<N>(T, e);   // what a frozen env keeps emitting (every other path recomputes cs / sn)
@@ -1378,7 +1397,6 @@ __global__ __launch_bounds__(DUO_BLOCK, 2) void k_rollout_duo(DevParams p, StepI
                 if (t == 0) sl.out = ((unsigned)e.flags >> 8) & 0xffu;
             }
         };
-        load_actions<N>(io, (size_t)(1 < io.T ? 1 : 0) * p.B + arow, act_next);   // one step ahead of its use
         produce(0, act);
         __syncthreads();
         for (int s = 0; s < io.T; s++) {
@@ -1442,7 +1460,7 @@ __global__ __launch_bounds__(DUO_BLOCK, 2) void k_rollout_duo(DevParams p, StepI
     constexpr bool PIPE = N <= 4;
     unsigned tape[TAPE_DW];   // the env's hit tape, replicated in the group's lanes
     bool tape_ok = false;
-    if (live) tape_ok = tape_load(p, b, e, tape);
+    if (live) tape_ok = tape_finish(p, traw, e, tape);
     group_wave_advance<N>(p, wave_b0, nvalid, lane, io.min_ahead, rowbufs[pw], e, tape, tape_ok);   // while K produces step 0
     if (threadIdx.x == DUO_PAIRS * 64) {
 #pragma unroll
