@@ -531,10 +531,10 @@ def main():
                                  "flight_easy", 3, 4096, "step", 2000, 200, "auto"),
                 side_measurement(cs, dev, comm, "c3 flight_easy 5a15t B=16384", "flight_easy", 5, 16384, "rollout",
                                  1000, 100, "auto"),
-                side_measurement(cs, dev, comm, "c4 flight 3a15t B=8192 (cs_rollout: sweep of step t beside step t + 1)",
-                                 "flight", 3, 8192, "rollout", 400, 100, "auto"),
                 side_measurement(cs, dev, comm, "c4 flight 3a15t B=8192, cs_step per step (hipGraph): k_step then k_map",
                                  "flight", 3, 8192, "step", 400, 100, "auto"),
+                side_measurement(cs, dev, comm, "c4 flight 3a15t B=8192 (cs_rollout: sweep of step t beside step t + 1)",
+                                 "flight", 3, 8192, "rollout", 400, 100, "auto"),
                 side_measurement(cs, dev, comm, "flight_easy 3a15t B=262144 (lane-per-env kernel: the HBM-regime kernel)",
                                  "flight_easy", 3, 262144, "rollout", 200, 100, "lane"),
                 side_measurement(cs, dev, comm, "flight_easy 3a15t B=1048576 (lane-per-env kernel; batch sweep asymptote)",

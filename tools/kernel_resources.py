@@ -9,7 +9,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
-so = os.path.join(ROOT, "cooperative-search_amd", "csrc", "libcoopsearch_hip.so")
+so = os.environ.get("SO") or os.path.join(ROOT, "cooperative-search_amd", "csrc", "libcoopsearch_hip.so")
 pat = sys.argv[1] if len(sys.argv) > 1 else ""
 with tempfile.TemporaryDirectory() as d:
     fat = os.path.join(d, "fat.bin")
