@@ -535,7 +535,7 @@ def test_c_example_runs_and_reproduces_the_random_policy_statistics(tmp_path):
     assert abs(float(m.group(4)) / 15 * 100 - 84.87) < 3.0     # shipped random-policy figure for 3a15t AM0
 
 
-@pytest.mark.parametrize("B,n,T", [(96, 3, 40), (37, 3, 1), (37, 5, 7), (300, 3, 2), (1, 3, 5), (530, 4, 33)])
+@pytest.mark.parametrize("B,n,T", [(96, 3, 40), (37, 3, 1), (37, 5, 7), (300, 3, 2), (1, 3, 5), (530, 4, 33), (8192, 3, 6)])
 def test_flight_rollout_call_equals_stepwise(B, n, T):
     """cs_rollout(flight) sweeps step t's map in the same launch that runs step t + 1 (k_flight_pipe, double-buffered
     map-update records): it must leave exactly what T cs_step calls leave, for odd and even T, ragged batches, resets
