@@ -135,3 +135,39 @@ def test_caller_side_ops_agree_with_ctypes_and_check_their_tensors(monkeypatch):
     with pytest.raises(RuntimeError, match="11 destination"):
         ops.store_episodes(out_t["obs"], out_t["state"], out_t["actions"][:-1].contiguous(), out_t["reward"][:-1].contiguous(),
                            out_t["terminated"][:-1].contiguous().view(torch.uint8), None, 3, [])
+
+
+@pytest.mark.parametrize("emit", [True, False])
+def test_flight_closed_loop_call_agrees_between_bindings(monkeypatch, emit):
+    """cs_rollout_policy_flight through torch.ops.coopsearch.rollout_policy_flight and through ctypes; the op layer
+    refuses a scratch tensor of the wrong size."""
+    from cooperative_search_amd.agents import FusedAgents
+    n, B, T = 3, 48, 12
+    args = cs.make_env_args("flight", n_agents=n)
+    args.time_limit = 7
+    env_t = cs.BatchedFlightEnv(args, batch=B, freeze_done=False, auto_reset=True)
+    cs.apply_env_info(args, env_t)
+    torch.manual_seed(4)
+    ag_t = FusedAgents(args, B, seed=3)
+    assert ag_t._ops is not None
+    out_t = env_t.rollout_policy(ag_t, T, epsilon=0.2, evaluate=False, emit=emit)
+    monkeypatch.setenv("COOPSEARCH_LIB", _lib.library_path())
+    env_c = cs.BatchedFlightEnv(args, batch=B, freeze_done=False, auto_reset=True)
+    ag_c = FusedAgents(args, B, net=ag_t.net, seed=3)
+    assert env_c._ops is None and ag_c._ops is None
+    out_c = env_c.rollout_policy(ag_c, T, epsilon=0.2, evaluate=False, emit=emit)
+    monkeypatch.delenv("COOPSEARCH_LIB")
+    for k in ("actions", "reward", "terminated", "win") + (("obs", "state") if emit else ()):
+        assert torch.equal(out_t[k], out_c[k]), k
+    assert torch.equal(ag_t.hidden, ag_c.hidden) and torch.equal(env_t.raw()["prob"], env_c.raw()["prob"])
+    assert torch.equal(env_t.get_obs(), env_c.get_obs())
+    ops = _lib.torch_ops()
+    with pytest.raises(RuntimeError, match="scratch"):
+        ops.rollout_policy_flight(env_t._cfg_t, env_t._blob, ag_t.packed, *ag_t.conv_w, ag_t.hidden, ag_t.actions,
+                                  torch.empty(B, 16, device="cuda"), T, 0, 0.0, 0, 0, 0, 0, out_t["actions"], out_t["reward"],
+                                  out_t["terminated"].view(torch.uint8), out_t["win"].view(torch.uint8), None, None)
+    easy = cs.BatchedFlightEnv(cs.make_env_args("flight_easy", n_agents=n), batch=B)
+    with pytest.raises(RuntimeError, match="flight only"):
+        ops.rollout_policy_flight(easy._cfg_t, easy._blob, ag_t.packed, *ag_t.conv_w, ag_t.hidden, ag_t.actions,
+                                  torch.empty(B, 16 + 4 * n, device="cuda"), T, 0, 0.0, 0, 0, 0, 0, out_t["actions"], out_t["reward"],
+                                  out_t["terminated"].view(torch.uint8), out_t["win"].view(torch.uint8), None, None)
