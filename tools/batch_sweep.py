@@ -4,7 +4,7 @@ import json, subprocess, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rows = []
 for n in (3, 5):
-    for B in (1024, 2048, 4096, 8192, 16384, 65536, 262144, 1048576):
+    for B in (1024, 2048, 4096, 8192, 16384, 65536, 262144, 1048576, 4194304):
         for kernel in ("solo", "duo", "lane"):
             if kernel == "lane" and B in (2048, 8192):
                 continue
@@ -12,10 +12,10 @@ for n in (3, 5):
                 continue
             if kernel == "duo" and B > (1 << 14):
                 continue
-            steps = 400 if B >= (1 << 18) else 1000
+            steps = 40 if B >= (1 << 22) else (400 if B >= (1 << 18) else 1000)   # 2^22: the output tables of 100 steps would not fit
             out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-also",
                                   "--workload", "c2" if n == 3 else "c3", "--mode", "rollout", "--kernel", kernel,
-                                  "--batch", str(B), "--steps", str(steps), "--warmup", "100"],
+                                  "--batch", str(B), "--steps", str(steps), "--warmup", str(min(100, steps))],
                                  capture_output=True, text=True).stdout.strip().splitlines()[-1]
             d = json.loads(out)
             rows.append((n, B, kernel, d["value"], d["ms_per_step"] * 1e3, d["roofline"]["frac"]))
