@@ -271,7 +271,8 @@ class BatchedFlightEnv:
         return dst["reward"], dst["terminated"].view(torch.bool), dst["win"].view(torch.bool)
 
     def rollout(self, actions, emit=True, out=None, update_views=True):
-        """T steps from one call (flight_easy: ONE launch; flight: T step+map launch pairs): actions [T, B, n] -> dict of
+        """T steps from one call (flight_easy: ONE launch; flight: one launch per step, in which the map sweep of step t runs
+        beside the kinematics / detection of step t + 1): actions [T, B, n] -> dict of
         [T, B, ...] tensors.
         `out` reuses caller buffers (keys reward/terminated/win/obs/state); update_views=False skips refreshing
         the live get_obs()/get_state() buffers afterwards (they then lag until the next step/refresh)."""

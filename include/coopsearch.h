@@ -161,15 +161,17 @@ int cs_step(const cs_config *cfg, void *state_dev, const void *actions_dev, int 
 
 /* T consecutive env.step calls from ONE call: actions [T][B][n]; reward [T][B]; terminated/win [T][B];
  * obs [T][B][n][obs width]; state_out [T][B][4n+3m] (obs/state_out may be NULL).  Same results as T cs_step calls
- * with the same flags.  flight_easy: one launch with the env resident in registers; flight: T (step, map) launch
- * pairs enqueued back to back. */
+ * with the same flags.  flight_easy: one launch with the env resident in registers; flight: one launch per step in
+ * which the map sweep of step t (update + the map part of get_obs) runs beside the kinematics / detection of step
+ * t + 1 -- the two are independent once the sweep reads the step's job record (cs_layout.job_off). */
 int cs_rollout(const cs_config *cfg, void *state_dev, const void *actions_dev, int T, int flags,
                float *reward_dev, uint8_t *terminated_dev, uint8_t *win_dev,
                float *obs_dev, float *state_out_dev, void *stream);
 
 /* MT19937 pre-pass: for every env with fewer than `min_ahead` twisted words ahead of its cursor, twist the whole row
  * ahead (ahead -> 624) in one coalesced sweep.  Does not change any stream: only WHEN its words are regenerated.
- * cs_rollout's lane-per-env path runs it before every 64-step chunk; exported for callers that drive cs_step. */
+ * cs_rollout's lane-per-env path runs it before every 64-step chunk for teams of 6 and more (smaller teams refresh
+ * their rows inside the kernels); exported for callers that drive cs_step. */
 int cs_mt_advance(const cs_config *cfg, void *state_dev, int min_ahead, void *stream);
 
 /* Writes every env's MT19937 row in CANONICAL form -- all 624 words twisted ahead of the cursor -- to
