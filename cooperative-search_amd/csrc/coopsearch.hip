@@ -924,9 +924,11 @@ __device__ __forceinline__ void env_reset(const DevParams &p, const double *T, i
     }
     // the reset-time pass (quirk Q3) draws nothing unless a target is within view of a start position (never for
     // agent_mode 0 with the shipped target file): request the MT window only then
-    MtWin win = {0u, 0u};
-    if ((__ballot(any_in_range) >> gshift) & 0xffffull) win = mt_prefetch(mt, e.mt_pos, t);
-    detect_pass<N>(p, b, t, gshift, e, win);
+    if ((__ballot(any_in_range) >> gshift) & 0xffffull) {
+        detect_pass<N>(p, b, t, gshift, e, mt_prefetch(mt, e.mt_pos, t));
+    } else {
+        detect_finish<N>(p, t, gshift, e, false);   // what the pass does when no pair is in range: no draw, reward -1
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
