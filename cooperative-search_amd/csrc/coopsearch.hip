@@ -104,26 +104,35 @@ struct AttemptBatch {
     // `ahead` = words at `pos` that are already twisted (their stored value IS the new word)
     __device__ __forceinline__ void generate(const unsigned *mt, int pos, int l, int ahead) {
         const int i0 = wrap624(pos + 4 * l);
-        unsigned cur[5], far[4];
-#pragma unroll
-        for (int q = 0; q < 5; q++) cur[q] = mt[wrap624(i0 + q)];
-#pragma unroll
-        for (int q = 0; q < 4; q++) far[q] = mt[wrap624(wrap624(i0 + MT_M) + q)];
         unsigned tw[4];
+        if (ahead >= 4 * G) {   // group-uniform, the usual case: the whole batch was twisted ahead of time
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            nw[q] = 4 * l + q < ahead ? cur[q] : mt_mix(cur[q], cur[q + 1], far[q]);
-            tw[q] = mt_temper(nw[q]);
+            for (int q = 0; q < 4; q++) {
+                nw[q] = mt[wrap624(i0 + q)];
+                tw[q] = mt_temper(nw[q]);
+            }
+        } else {
+            unsigned cur[5], far[4];
+#pragma unroll
+            for (int q = 0; q < 5; q++) cur[q] = mt[wrap624(i0 + q)];
+#pragma unroll
+            for (int q = 0; q < 4; q++) far[q] = mt[wrap624(wrap624(i0 + MT_M) + q)];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                nw[q] = 4 * l + q < ahead ? cur[q] : mt_mix(cur[q], cur[q + 1], far[q]);
+                tw[q] = mt_temper(nw[q]);
+            }
         }
         // numpy random_sample: 53-bit double from two words
         u1 = ((double)(tw[0] >> 5) * 67108864.0 + (double)(tw[1] >> 6)) / 9007199254740992.0;
         u2 = ((double)(tw[2] >> 5) * 67108864.0 + (double)(tw[3] >> 6)) / 9007199254740992.0;
     }
-    // write back the first `words` words of the batch
-    __device__ __forceinline__ void commit(unsigned *mt, int pos, int l, int words) const {
+    // write back the first `words` words of the batch (those that were twisted here: the first `ahead` are in place)
+    __device__ __forceinline__ void commit(unsigned *mt, int pos, int l, int words, int ahead) const {
+        if (ahead >= words) return;   // group-uniform
 #pragma unroll
         for (int q = 0; q < 4; q++)
-            if (4 * l + q < words) mt_store(mt, wrap624(wrap624(pos + 4 * l) + q), nw[q]);
+            if (4 * l + q < words && 4 * l + q >= ahead) mt_store(mt, wrap624(wrap624(pos + 4 * l) + q), nw[q]);
     }
 };
 
@@ -886,7 +895,7 @@ __device__ __forceinline__ void env_reset(const DevParams &p, const double *T, i
             // words consumed: up to and including the attempt that supplied the last needed pair, else the batch
             const int last = have >= want ? kth_set_bit16(amask, want - 1) : 15;
             const int words = 4 * (last + 1);
-            ab.commit(mt, e.mt_pos, t, words);
+            ab.commit(mt, e.mt_pos, t, words, e.ahead);
             e.mt_pos = wrap624(e.mt_pos + words);
             e.words += (unsigned long long)words;
             e.ahead = e.ahead > words ? e.ahead - words : 0;
@@ -899,7 +908,7 @@ __device__ __forceinline__ void env_reset(const DevParams &p, const double *T, i
         mx = p.L * ab.u1;
         my = p.L * ab.u2;
         const int words = 4 * p.n_targets;
-        ab.commit(mt, e.mt_pos, t, words);
+        ab.commit(mt, e.mt_pos, t, words, e.ahead);
         e.mt_pos = wrap624(e.mt_pos + words);
         e.words += (unsigned long long)words;
         e.ahead = e.ahead > words ? e.ahead - words : 0;
