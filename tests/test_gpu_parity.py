@@ -325,6 +325,33 @@ def test_group_and_lane_kernels_can_be_interleaved(n):
     assert hdr(ref)[:, _lib.H_EPISODES].min() >= 5
 
 
+@pytest.mark.parametrize("n,B,T", [(3, 4096, 260), (5, 16384, 230)])
+def test_full_size_rollout_matches_oracle(n, B, T):
+    """BASELINE configs 2 / 3 at full size through the kernels the bench runs (c2: the wavefront-pair kernel, c3: the
+    one-wavefront kernel), auto-reset through at least one episode boundary per env: every reward, terminated and win
+    flag of every step, the emitted observation / state of the last step, and the full raw state against the oracle."""
+    m = 15
+    seeds = np.arange(B, dtype=np.uint32) + 20240000          # SURVEY 8(d): env seeds base 20240000
+    env = cs.BatchedFlightEnv(cs.make_env_args("flight_easy", n_agents=n), batch=B, seeds=seeds, freeze_done=False,
+                              auto_reset=True)
+    env.seed(seeds)
+    env.reset(init=True)
+    a = np.random.RandomState(1).randint(0, 3, size=(T, B, n)).astype(np.int32)
+    out = env.rollout(torch.from_numpy(a))
+    with orc.hip_equivalent_arithmetic():
+        ob = orc.OracleBatch(orc.make_config(n_agents=n), B, seeds)
+        ob.reset(init=True, threads=8)
+        want = ob.rollout(a, auto_reset=True, freeze_done=False, threads=8)
+        np.testing.assert_array_equal(out["reward"].cpu().numpy(), want["reward"])
+        np.testing.assert_array_equal(out["terminated"].cpu().numpy().astype(np.uint8), want["terminated"])
+        np.testing.assert_array_equal(out["win"].cpu().numpy().astype(np.uint8), want["win"])
+        for t in (0, T // 2, T - 1):
+            np.testing.assert_allclose(out["obs"][t].cpu().numpy(), want["obs"][t], rtol=0, atol=F32_TOL)
+            np.testing.assert_allclose(out["state"][t].cpu().numpy(), want["state"][t], rtol=0, atol=F32_TOL)
+        compare_with_oracle(env, ob, B, n, m, f"c{2 if n == 3 else 3} full size")
+    assert hdr(env)[:, _lib.H_EPISODES].min() >= 2     # the constructor's reset + at least one auto-reset
+
+
 @pytest.mark.parametrize("n,B", [(3, 4096), (5, 16384)])
 def test_full_size_properties_and_shard_invariance(n, B):
     """BASELINE configs 2/3 at full size: domain invariants + bit-exact shard invariance (rank-local halves with
@@ -625,6 +652,36 @@ def test_flight_long_horizon_matches_oracle():
                                            err_msg=f"obs (map + feats) step {t}")
         compare_with_oracle(env, ob, B, n, m, "flight long horizon")
         assert hdr(env)[:, _lib.H_EPISODES].min() >= 5
+
+
+def test_flight_full_size_pipelined_rollout_matches_oracle():
+    """BASELINE config 4 at full size (8192 envs) through cs_rollout's pipelined launches (k_flight_pipe: the map sweep
+    of step t beside step t + 1), 48 steps with a time limit of 20 so that every env resets twice inside the call:
+    rewards and flags of every step, the 2504-wide observation (map first) at three steps, the raw state at the end."""
+    B, n, m, T = 8192, 3, 15, 48
+    seeds = np.arange(B, dtype=np.uint32) + 20240000
+    args = cs.make_env_args("flight", n_agents=n)
+    args.time_limit = 20
+    env = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, freeze_done=False, auto_reset=True)
+    env.seed(seeds)
+    env.reset(init=True)
+    a = np.random.RandomState(5).randint(0, 3, size=(T, B, n)).astype(np.int32)
+    out = env.rollout(torch.from_numpy(a))
+    with orc.hip_equivalent_arithmetic():
+        ob = orc.OracleBatch(orc.make_config(variant="flight", n_agents=n, time_limit=20), B, seeds)
+        ob.reset(init=True, threads=8)
+        for t in range(T):
+            emit = t in (0, 21, T - 1)
+            orr, ot, ow = ob.step(a[t], auto_reset=True, freeze_done=False, threads=8, emit=emit)
+            np.testing.assert_array_equal(out["reward"][t].cpu().numpy(), orr, err_msg=f"reward step {t}")
+            np.testing.assert_array_equal(out["terminated"][t].cpu().numpy().astype(np.uint8), ot)
+            np.testing.assert_array_equal(out["win"][t].cpu().numpy().astype(np.uint8), ow)
+            if emit:
+                np.testing.assert_allclose(out["obs"][t].cpu().numpy(), ob.obs, rtol=0, atol=F32_TOL,
+                                           err_msg=f"obs (map + feats) step {t}")
+                np.testing.assert_allclose(out["state"][t].cpu().numpy(), ob.state, rtol=0, atol=F32_TOL)
+        compare_with_oracle(env, ob, B, n, m, "c4 full size, pipelined")
+    assert hdr(env)[:, _lib.H_EPISODES].min() >= 3
 
 
 def test_mt_advance_changes_when_not_what():
