@@ -1206,22 +1206,36 @@ __device__ __forceinline__ void step_block(const DevParams &p, const StepIO &io,
     const int lane = threadIdx.x & 63;
     const bool live = b < p.B;
     // issue every independent global load before the barrier that publishes the trig table
+#ifndef CS_STEP_TAPE
+#define CS_STEP_TAPE 1
+#endif
+    // The draws of a single step come from the env's hit tape while it is valid (left by a rollout call or cs_mt_advance;
+    // it is never written here: tape_finish rebases it by the words consumed since), which takes the MT19937 window --
+    // a load that depends on the header's cursor -- off the launch's critical path; otherwise words are twisted on demand.
+    constexpr bool STEP_TAPE = CS_STEP_TAPE && N <= 5;
     Env<N> e;
     int act[N];
+    TapeRaw traw = {};
     if (live) {
         env_load<N>(p, b, t, e);
         load_actions<N>(io, (size_t)b, act);
+        if (STEP_TAPE) traw = tape_fetch(p, b);
     }
     load_trig_to_lds(T);
     const int wave_b0 = (blk * BLOCK + (threadIdx.x & ~63)) / G;
     if (wave_b0 >= p.B) return;
     const int nvalid = p.B - wave_b0 < 4 ? p.B - wave_b0 : 4;
     MtWin win = {0u, 0u};
-    if (live) win = mt_prefetch(p.mt + (size_t)b * MT_STRIDE, e.mt_pos, t);
+    unsigned tape[TAPE_DW];
+    bool tape_ok = false;
+    if (STEP_TAPE) {
+        if (live) tape_ok = tape_finish(p, traw, e, tape);
+    } else if (live) {
+        win = mt_prefetch(p.mt + (size_t)b * MT_STRIDE, e.mt_pos, t);
+    }
     const EmitPlan<N> plan = make_emit_plan<N>(p, lane, nvalid);
-    unsigned no_tape[TAPE_DW];   // single steps twist their words on demand
     step_once<N, VARIANT>(p, T, io, tiles[threadIdx.x >> 6], b, lane, (size_t)wave_b0, plan, live, act, win, false, false, 0, false, e,
-                          no_tape, false, false);
+                          tape, STEP_TAPE, tape_ok);
     if (live) {
         env_store<N>(p, b, t, e, false);
         if (VARIANT == 1) job_store<N>(p, io.job_parity, b, t, e);

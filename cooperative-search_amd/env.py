@@ -21,6 +21,8 @@ from . import _lib
 from .targets import default_circle_dict
 
 DEFAULT_BASE_SEED = 20240000  # env b of the global batch is seeded base + b
+STEP_ADVANCE_EVERY = 32        # step(): hit tapes are refreshed every this many single steps ...
+STEP_ADVANCE_MIN_AHEAD = 400   # ... for the rows with fewer twisted MT19937 words left than this (of 624)
 
 
 def _cfg_from_args(args, circle_dict, batch, variant):
@@ -69,10 +71,13 @@ class BatchedFlightEnv:
                 kinematics wavefront and a detection wavefront per four envs, for batches that leave a wave slot per
                 SIMD empty), "lane" (one env per lane: no replicated arithmetic, for large batches) or "auto" (lane
                 from B >= 32768).  All produce bit-identical results.
+    step_advance  step(): refresh the hit tapes every STEP_ADVANCE_EVERY single steps (default).  False leaves every
+                MT19937 word to be twisted on demand by the step kernel itself -- same results, one more dependent load per
+                launch.
     """
 
     def __init__(self, args, circle_dict=None, batch=1, device="cuda", seeds=None, env_offset=0, freeze_done=True,
-                 auto_reset=False, variant=None, kernel="auto", binding=None):
+                 auto_reset=False, variant=None, kernel="auto", binding=None, step_advance=True):
         if not torch.cuda.is_available():
             raise RuntimeError("BatchedFlightEnv needs a GPU: the HIP path has no CPU fallback")
         self._L = _lib.load()
@@ -125,6 +130,8 @@ class BatchedFlightEnv:
             self._reward = torch.zeros(B, dtype=torch.float32, device=self.device)
             self._terminated = torch.zeros(B, dtype=torch.uint8, device=self.device)
             self._win = torch.zeros(B, dtype=torch.uint8, device=self.device)
+            self.step_advance = bool(step_advance)
+            self._steps_since_advance = STEP_ADVANCE_EVERY   # the first step() refreshes the tapes
             self._obs = torch.zeros(B, n, self.obs_width, dtype=torch.float32, device=self.device)
             self._state = torch.zeros(B, self.state_shape, dtype=torch.float32, device=self.device)
             self._avail = torch.ones(B, self.n_actions, dtype=torch.float32, device=self.device)
@@ -168,6 +175,15 @@ class BatchedFlightEnv:
         if self.flight:
             d["prob"] = self._view(lay.prob_off, B * self.cells, torch.float32, (B, self.map_size, self.map_size))
         return d
+
+    def mt_advance(self, min_ahead=400):
+        """cs_mt_advance: rows with fewer than `min_ahead` twisted words ahead of their cursor are twisted fully ahead and
+        their hit tapes rebuilt (when, never what: the streams are untouched)."""
+        if self._ops is not None:
+            self._ops.mt_advance(self._cfg_t, self._blob, int(min_ahead))
+        else:
+            _lib.check(self._L.cs_mt_advance(self._cfgp, self._blob.data_ptr(), int(min_ahead), self._stream()))
+        self._steps_since_advance = 0
 
     def mt_canonical(self):
         """int32 [B, MT_STRIDE]: every env's MT19937 row in a form that depends only on the stream position (the kernels may
@@ -261,6 +277,13 @@ class BatchedFlightEnv:
                         or not v.is_contiguous() or v.device != dst[k].device:
                     raise ValueError(f"step(out=): bad destination for {k!r}")
                 dst[k] = v
+        # single steps read their draws from the env's hit tape while it is valid; every STEP_ADVANCE_EVERY steps the rows
+        # that are running low are twisted ahead again (cs_mt_advance: a coalesced pass that skips the others), which keeps
+        # the MT19937 window load off the critical path of every cs_step launch.  Never changes a stream, only when its
+        # words are regenerated.
+        if self.step_advance and self._steps_since_advance >= STEP_ADVANCE_EVERY and self.n_agents <= 5:
+            self.mt_advance(STEP_ADVANCE_MIN_AHEAD)
+        self._steps_since_advance += 1
         if self._ops is not None:
             self._ops.env_step(self._cfg_t, self._blob, a, self._flags(a), dst["reward"], dst["terminated"].view(torch.uint8),
                                dst["win"].view(torch.uint8), dst["obs"], dst["state"])

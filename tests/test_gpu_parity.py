@@ -142,7 +142,7 @@ def compare_with_oracle(env, ob, B, n, m, tag, check_pos=True):
             np.testing.assert_allclose(tg[b], tp, rtol=0, atol=1e-12, err_msg=f"{tag} env {b} targets")
 
 
-@pytest.mark.parametrize("kernel", ["group", "solo", "duo", "lane"])
+@pytest.mark.parametrize("kernel", ["group", "group-ondemand", "solo", "duo", "lane"])
 @pytest.mark.parametrize("variant,n,agent_mode,target_mode,B,T", [
     ("flight_easy", 3, 0, 0, 512, 200),
     ("flight_easy", 5, 0, 0, 256, 200),
@@ -153,11 +153,13 @@ def compare_with_oracle(env, ob, B, n, m, tag, check_pos=True):
     ("flight_easy", 2, 1, 0, 100, 100),
 ])
 def test_batched_step_matches_oracle_bit_exact(variant, n, agent_mode, target_mode, B, T, kernel):
-    """Frozen-when-done batch against B oracle envs, every step: outputs exact, raw state bit-identical."""
+    """Frozen-when-done batch against B oracle envs, every step: outputs exact, raw state bit-identical.
+    "group-ondemand": no periodic tape refresh, the step kernel twists every word it draws itself."""
     m = 15
     seeds = (777 + 13 * np.arange(B)).astype(np.uint32)
     args = cs.make_env_args(variant, n_agents=n, agent_mode=agent_mode, target_mode=target_mode)
-    env = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, freeze_done=True, kernel=kernel)
+    env = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, freeze_done=True, kernel=kernel.split("-")[0],
+                              step_advance=not kernel.endswith("ondemand"))
     env.seed(seeds)
     env.reset(init=True)
     cfg = orc.make_config(variant=variant, n_agents=n, agent_mode=agent_mode, target_mode=target_mode)
@@ -179,7 +181,7 @@ def test_batched_step_matches_oracle_bit_exact(variant, n, agent_mode, target_mo
                 compare_with_oracle(env, ob, B, n, m, f"step {t}")
 
 
-@pytest.mark.parametrize("kernel", ["group", "solo", "duo", "lane"])
+@pytest.mark.parametrize("kernel", ["group", "group-ondemand", "solo", "duo", "lane"])
 def test_auto_reset_and_unfrozen_modes_match_oracle(kernel):
     B, n, m, T = 128, 5, 15, 420   # > 2 episodes per env
     seeds = np.arange(B, dtype=np.uint32) + 5
@@ -187,7 +189,7 @@ def test_auto_reset_and_unfrozen_modes_match_oracle(kernel):
     cfg = orc.make_config(n_agents=n)
     for mode in ("auto_reset", "unfrozen"):
         env = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, freeze_done=False, auto_reset=(mode == "auto_reset"),
-                                  kernel=kernel)
+                                  kernel=kernel.split("-")[0], step_advance=not kernel.endswith("ondemand"))
         env.seed(seeds)
         env.reset(init=True)
         rng = np.random.RandomState(9)
@@ -690,8 +692,8 @@ def test_mt_advance_changes_when_not_what():
     B, n = 300, 3
     args = cs.make_env_args("flight_easy", n_agents=n)
     seeds = np.arange(B, dtype=np.uint32) + 4242
-    e1 = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, freeze_done=False, auto_reset=True, kernel="group")
-    e2 = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, freeze_done=False, auto_reset=True, kernel="group")
+    e1 = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, freeze_done=False, auto_reset=True, kernel="group", step_advance=False)
+    e2 = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, freeze_done=False, auto_reset=True, kernel="group", step_advance=False)
     g = torch.Generator("cuda").manual_seed(3)
     for t in range(260):
         a = torch.randint(0, 3, (B, n), dtype=torch.int32, device="cuda", generator=g)
@@ -703,7 +705,7 @@ def test_mt_advance_changes_when_not_what():
         r1, t1, w1 = e1.step(a)
         r2, t2, w2 = e2.step(a)
         assert torch.equal(r1, r2) and torch.equal(t1, t2) and torch.equal(w1, w2), f"step {t}"
-    assert int(e1.raw()["ahead"].max().item()) == 0     # the group kernels never twist ahead themselves
+    assert int(e1.raw()["ahead"].max().item()) == 0     # without the periodic refresh the step kernel never twists ahead
     r1, r2 = raw_state(e1), raw_state(e2)
     for k in ("tgt", "agent", "hdr", "mt"):
         assert torch.equal(r1[k], r2[k]), k
