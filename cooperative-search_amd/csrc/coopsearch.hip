@@ -1199,7 +1199,7 @@ __device__ __forceinline__ void step_once(const DevParams &p, const double *T, c
 }
 
 // One launch's share of a single step: workgroup `blk` of BLOCK threads = 16 envs.
-template <int N, int VARIANT>
+template <int N, int VARIANT, bool TAPE = true>
 __device__ __forceinline__ void step_block(const DevParams &p, const StepIO &io, double *T, WaveTile *tiles, int blk) {
     const int gid = blk * BLOCK + threadIdx.x;
     const int b = gid / G, t = gid % G;
@@ -1212,7 +1212,9 @@ __device__ __forceinline__ void step_block(const DevParams &p, const StepIO &io,
     // The draws of a single step come from the env's hit tape while it is valid (left by a rollout call or cs_mt_advance;
     // it is never written here: tape_finish rebases it by the words consumed since), which takes the MT19937 window --
     // a load that depends on the header's cursor -- off the launch's critical path; otherwise words are twisted on demand.
-    constexpr bool STEP_TAPE = CS_STEP_TAPE && N <= 5;
+    // (the rollout call of flight passes TAPE = false: nothing refreshes the tapes between its launches, and the step
+    // role there is hidden behind the map sweep either way)
+    constexpr bool STEP_TAPE = CS_STEP_TAPE && TAPE && N <= 5;
     Env<N> e;
     int act[N];
     TapeRaw traw = {};
@@ -2680,7 +2682,7 @@ __global__ __launch_bounds__(BLOCK, CS_PIPE_WAVES) void k_flight_pipe(DevParams 
     const int blk = blockIdx.x;
     const int q = blk / stride, r = blk - q * stride;
     if (r == 0 && q < nstep) {
-        step_block<N, 1>(p, io, T, tiles, q);
+        step_block<N, 1, false>(p, io, T, tiles, q);
     } else {
         const int before = q + 1 < nstep ? q + 1 : nstep;   // step workgroups with a lower index
         const int m = blk - before;
