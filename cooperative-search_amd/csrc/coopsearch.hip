@@ -1380,6 +1380,12 @@ __global__ __launch_bounds__(DUO_BLOCK, 2) void k_rollout_duo(DevParams p, StepI
 
     if (is_k) {
         // ------------------------------------------------------------------------------------------ K: kinematics
+        // the longer half of the pair gets the issue priority: K from four agents up (5 agents, B = 4096: 1.35 -> 1.43e9
+        // env-steps/s; raising D instead: 1.36e9), D for smaller teams (below)
+#ifndef CS_DUO_K_PRIO_FROM
+#define CS_DUO_K_PRIO_FROM 4
+#endif
+        if (N >= CS_DUO_K_PRIO_FROM) __builtin_amdgcn_s_setprio(1);
         bool k_done = live && (e.target_find >= p.n_targets || e.time_step >= p.time_limit);   // exact at launch
         int k_time = e.time_step;
         if (live && freeze) env_trig<N>(T, e);   // what a frozen env keeps emitting (every other path recomputes cs / sn)
