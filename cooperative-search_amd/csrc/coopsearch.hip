@@ -2545,10 +2545,15 @@ __device__ __forceinline__ bool map_update_chunk(const DevParams &p, const MapPa
             const int yi = wrap ? cj0 + q - p.map_size : cj0 + q;
             const unsigned long long ra = wrap ? r1 : r0, rb = wrap ? r2 : r1;
             const int cnt = __popc((unsigned)((ra >> yi) & 3ull)) + __popc((unsigned)((rb >> yi) & 3ull));
+            cnts |= (unsigned)cnt << (4 * q);
+        }
+        if (cnts == 0) continue;   // no corner of these four cells in view (4 of 5 chunks): nothing to update
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int cnt = (int)((cnts >> (4 * q)) & 0xfu);
             // percent*(1-detect_prob)*p / ((1-detect_prob)*p + (1-p)), flight_env.py:292
             const float upd = ((float)cnt * 0.25f) * qf * pv[q] / (qf * pv[q] + (1.0f - pv[q]));
             pv[q] = cnt ? upd : pv[q];
-            cnts |= (unsigned)cnt << (4 * q);
         }
         if (m.any_found && cnts) {  // a newly found target's cell, if in view, is set to 1 (:288-289)
             for (int j = 0; j < p.n_targets; j++) {
