@@ -495,6 +495,31 @@ def test_flight_unusual_configurations_match_oracle(kw):
         compare_with_oracle(env, ob, B, n, m, "flight final")
 
 
+@pytest.mark.parametrize("kw", [
+    dict(n_agents=3, map_size=20, view_range=4, agent_mode=1),
+    dict(n_agents=4, map_size=62, view_range=9, agent_mode=3),      # 961 chunks: two sweep workgroups per env in k_flight_pipe
+    dict(n_agents=8, map_size=30, view_range=5, target_num=16, target_mode=1),
+])
+def test_flight_unusual_configurations_pipelined_rollout_equals_stepwise(kw):
+    """The pipelined cs_rollout (k_flight_pipe) on map sizes / team sizes other than the shipped one, against cs_step."""
+    B, T, kw = 21, 13, dict(kw)
+    args = _custom_args("flight", **kw)
+    args.time_limit = 6
+    n = args.n_agents
+    seeds = np.arange(B, dtype=np.uint32) + 77
+    acts = torch.randint(0, 3, (T, B, n), dtype=torch.int32, device="cuda", generator=torch.Generator("cuda").manual_seed(8))
+    e1 = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, freeze_done=False, auto_reset=True)
+    e2 = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, freeze_done=False, auto_reset=True)
+    out = e2.rollout(acts)
+    for t in range(T):
+        r, term, win = e1.step(acts[t])
+        assert torch.equal(r, out["reward"][t]) and torch.equal(term, out["terminated"][t]) and torch.equal(win, out["win"][t])
+        assert torch.equal(e1.get_obs(), out["obs"][t]) and torch.equal(e1.get_state(), out["state"][t])
+    r1, r2 = raw_state(e1), raw_state(e2)
+    for k in ("tgt", "agent", "hdr", "mt", "prob"):
+        assert torch.equal(r1[k], r2[k]), k
+
+
 def test_b1_adapter_runs_a_rollout_shaped_loop():
     """BASELINE config 1: the reference-typed B = 1 adapter driven like common/rollout.py:43-76."""
     meta, z = load_trace("easy_n3_am0_s0_a1")
