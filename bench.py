@@ -145,7 +145,7 @@ def kernel_label(env_name, n, B, mode, kernel):
         return f"k_rollout_lane<{n}>"
     if mode == "step":
         return f"k_step<{n},0>"
-    duo = kernel == "duo" or (kernel in ("auto", "group") and n <= 6 and B <= 6144)
+    duo = kernel == "duo" or (kernel in ("auto", "group") and n <= 6 and B <= 4096)
     return f"k_rollout_duo<{n}>" if duo else f"k_rollout<{n}>"
 
 

@@ -2940,7 +2940,9 @@ inline bool use_lane_kernel(const cs_config *c, int flags) {
 // 16-lanes-per-env rollout: the kinematics / detection wavefront pair wins while the batch leaves a wave slot per SIMD
 // empty (profiles/r02_batch_sweep.md: 3 agents, B = 4096: 1.59e9 vs 1.49e9 env-steps/s, B = 16384: 1.69e9 vs 2.43e9;
 // 5 agents, B = 4096: 1.07e9 vs 0.89e9, B = 16384: 1.14e9 vs 1.43e9; teams of 7 and 8 spill in the pair)
-inline bool duo_pays(const cs_config *c) { return c->n_agents <= 6 && c->batch <= 6144; }
+// the pair kernel pays while its two wavefronts per four envs still find a SIMD each (1024 SIMDs x 2 wave slots at these
+// register counts): measured crossover at 4096 envs -- 4608: pair 3.40 us per step, one-wavefront kernel 3.18 (3 agents)
+inline bool duo_pays(const cs_config *c) { return c->n_agents <= 6 && c->batch <= 4096; }
 
 // Rows with at least this many twisted words ahead are left alone by the pre-pass of a T-step rollout: enough for the
 // typical draw rate (two words per draw, a few draws per step) with a step's worst case in reserve.  Short rollouts

@@ -61,7 +61,7 @@ enum {
     CS_KERNEL_GROUP = 8, /* flight_easy: force the 16-lanes-per-env kernels (default for batch < 32768) */
     CS_KERNEL_LANE = 16, /* flight_easy: force the lane-per-env kernel   (default for batch >= 32768); same results */
     CS_KERNEL_SOLO = 32, /* cs_rollout, 16-lanes-per-env path: one wavefront per four envs does the whole step */
-    CS_KERNEL_DUO = 64   /* ... a kinematics wavefront and a detection wavefront per four envs (default up to 6144 envs
+    CS_KERNEL_DUO = 64   /* ... a kinematics wavefront and a detection wavefront per four envs (default up to 4096 envs
                             of at most 6 agents, where the batch leaves a wave slot per SIMD empty); same results */
 };
 
