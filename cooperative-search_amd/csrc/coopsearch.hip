@@ -847,7 +847,9 @@ __device__ __forceinline__ void start_pose(const DevParams &p, int i, double &x,
 // reset: flight_env_easy.py:79-182 / flight_env.py:83-191.  Group-cooperative; ends with the reset-time
 // detection pass (quirk Q3) whose reward is discarded.
 // ---------------------------------------------------------------------------------------------------------
-template <int N>
+// TRIG = false: the caller steps the env right away (fused auto-reset), so the headings' sin / cos -- recomputed by the
+// kinematics of that step -- are not evaluated here.
+template <int N, bool TRIG = true>
 __device__ __forceinline__ void env_reset(const DevParams &p, const double *T, int b, int t, int gshift, int init,
                                           Env<N> &e) {
     if (p.variant == 1 && init) {  // flight_env.py:84-86
@@ -927,7 +929,7 @@ __device__ __forceinline__ void env_reset(const DevParams &p, const double *T, i
 #pragma unroll
     for (int i = 0; i < N; i++) {
         start_pose<N>(p, i, e.ax[i], e.ay[i], e.yaw[i]);
-        trig_heading(T, e.yaw[i], e.sn[i], e.cs[i]);
+        if (TRIG) trig_heading(T, e.yaw[i], e.sn[i], e.cs[i]);
         const double ddx = e.tx - e.ax[i], ddy = e.ty - e.ay[i];
         any_in_range = any_in_range | (t < p.n_targets && ddx * ddx + ddy * ddy <= p.view_r2);
     }
@@ -1158,7 +1160,7 @@ __device__ __forceinline__ void step_once(const DevParams &p, const double *T, c
         e.flags &= ~(FLAG_DIRTY | FLAG_RESET_PASS);  // pending-map-update flags describe THIS launch only
         if (done && (io.flags & CS_AUTO_RESET)) {
             const unsigned long long words_before = e.words;
-            env_reset<N>(p, T, b, t, gshift, 0, e);
+            env_reset<N, false>(p, T, b, t, gshift, 0, e);
             if (VARIANT == 1) {  // flight: the map kernel must replay the reset-time update before this step's
                 e.newly_reset = e.newly;
                 e.flags |= FLAG_RESET_PASS;
@@ -1515,7 +1517,7 @@ __global__ __launch_bounds__(DUO_BLOCK, 2) void k_rollout_duo(DevParams p, StepI
             e.flags &= ~(FLAG_DIRTY | FLAG_RESET_PASS);
             if (done && auto_reset) {
                 const unsigned long long words_before = e.words;
-                env_reset<N>(p, T, b, t, gshift, 0, e);
+                env_reset<N, false>(p, T, b, t, gshift, 0, e);
                 reinterpret_cast<double2 *>(p.tgt + (size_t)b * G * 2)[t] = make_double2(e.tx, e.ty);
                 const unsigned long long used = e.words - words_before;   // its draw slots leave the tape
                 tape_shift<8>(tape, used < 2ull * 319ull ? (int)(used >> 1) : 319);
@@ -2162,7 +2164,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO i
                 g.tx = g.ty = 0.0;
                 if (src >= 0) {
                     const int br = b0 + src;
-                    env_reset<N>(p, T, br, t16, gshift, 0, g);
+                    env_reset<N, false>(p, T, br, t16, gshift, 0, g);
                     reinterpret_cast<double2 *>(p.tgt + (size_t)br * G * 2)[t16] = make_double2(g.tx, g.ty);
                     if (t16 < p.n_targets) {
                         float *rs = tile + (size_t)src * W + 4 * N + 3 * t16;
