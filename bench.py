@@ -75,6 +75,11 @@ def parse_args(argv=None):
                     help="flight_easy kernel: 16 lanes per env (solo / duo wavefront roles, or chosen by batch), one lane "
                          "per env, or everything by batch size")
     ap.add_argument("--min-gpu-s", type=float, default=MIN_GPU_S)
+    ap.add_argument("--pg", default="auto", choices=["auto", "on", "off"],
+                    help="process group at N = 1: 'on' = init_process_group('nccl') even for one rank and fail if RCCL does "
+                         "not come up; 'auto' (default) = try it, report the failure in the line and carry on without "
+                         "(the collective is outside the timed region); 'off' = none.  N > 1 always has one.")
+    ap.add_argument("--force-pg", dest="pg", action="store_const", const="on", help="same as --pg on")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU-only check of the N-rank control flow (launcher, gloo process group, metric all-gather); "
                          "no kernels run and the line says so")
@@ -150,17 +155,20 @@ def kernel_label(env_name, n, B, mode, kernel):
 
 
 def pmc_traffic(label, B, steps_per_launch):
-    """HBM bytes per launch from the committed PMC passes (profiles/traffic.json: FETCH_SIZE / WRITE_SIZE in separate
-    rocprofv3 --pmc passes, per env-step), scaled to THIS run's batch and steps per launch; None when no pass of this
-    kernel is committed."""
+    """(HBM bytes per launch, source) from the COMMITTED PMC passes (profiles/traffic.json: FETCH_SIZE / WRITE_SIZE in
+    separate rocprofv3 --pmc passes, per env-step), scaled to THIS run's batch and steps per launch.  Not measured in this
+    run -- counters need their own profiler passes -- so the line names the entry it came from.  (None, None) when no pass
+    of this kernel AT THIS NUMBER OF STEPS PER LAUNCH is committed: prologue traffic per env-step depends on the launch
+    length, so a pass taken at another length is not scaled across."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(path):
-        return None
+        return None, None
     kernels = json.load(open(path)).get("kernels") or {}
-    ent = kernels.get(f"{label}@{steps_per_launch}") or kernels.get(label)
-    if not ent:
-        return None
-    return int(ent["hbm_bytes_per_env_step"] * B * steps_per_launch)
+    key = f"{label}@{steps_per_launch}"
+    ent = kernels.get(key)
+    if ent and int(ent.get("steps_per_launch", -1)) == steps_per_launch:
+        return int(ent["hbm_bytes_per_env_step"] * B * steps_per_launch), f"profiles/traffic.json[{key!r}]"
+    return None, None
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
@@ -179,8 +187,9 @@ def cpu_baseline(env_name, n, batch, budget_s=10.0):
     bounded sample of the same workload: same batch, auto-reset, obs+state emission, x*x squares (its fast mode).
     flight_easy: orc_batch_rollout_rep -- ONE OpenMP region per 400 steps (the 100-step action table walked four times),
     env-major, so the fork/join cost is paid once per 400 steps and an env stays in its core's cache.  Thread counts from
-    1 to all logical CPUs are calibrated first; `value` is the BEST of them (`cores` = that thread count), the others
-    are listed in `thread_scaling_env_steps_per_s`."""
+    1 to all logical CPUs are calibrated first (median of three regions each); the two best share the time budget and
+    `value` is the MEDIAN per-region rate of the better one (`cores` = that thread count); the others are listed in
+    `thread_scaling_env_steps_per_s`."""
     import numpy as np
     from oracle import oracle as orc
     max_threads = max(1, min(orc.OracleBatch.max_threads(), os.cpu_count() or 1))
@@ -196,33 +205,35 @@ def cpu_baseline(env_name, n, batch, budget_s=10.0):
         acts = np.random.RandomState(1).randint(0, 3, size=(T, B, n)).astype(np.int32)
         out = ob.rollout(acts, auto_reset=True, freeze_done=False, threads=max_threads)   # warm-up + buffers
 
-        def run(th, reps):
-            t0 = time.perf_counter()
+        def regions(th, reps, rep=R):
+            """`reps` OpenMP regions of T * rep steps on `th` threads, each timed on its own: env-steps/s per region."""
+            rates = []
             for _ in range(reps):
-                ob.rollout(acts, auto_reset=True, freeze_done=False, threads=th, out=out, repeat=R)
-            dt = time.perf_counter() - t0
-            return B * T * R * reps / dt, dt
+                t0 = time.perf_counter()
+                ob.rollout(acts, auto_reset=True, freeze_done=False, threads=th, out=out, repeat=rep)
+                rates.append(B * T * rep / (time.perf_counter() - t0))
+            return rates
 
         cands = sorted({1, 2, 4, 8, 16, 32, 64, max_threads // 2, max_threads} & set(range(1, max_threads + 1)))
         scaling = {}
-        for th in cands:   # calibration: one region each, except the slow single thread (a quarter region's worth)
-            if th == 1:
-                t0 = time.perf_counter()
-                ob.rollout(acts, auto_reset=True, freeze_done=False, threads=1, out=out, repeat=1)
-                scaling["1"] = B * T / (time.perf_counter() - t0)
-            else:
-                scaling[str(th)] = run(th, 1)[0]
-        # the two best calibration points share the budget (one-region calibrations are noisy at high thread counts);
-        # the better sustained rate is the reported value
+        for th in cands:   # calibration: the MEDIAN of three regions per thread count (single regions are noisy at high
+            #                thread counts: SMT siblings, 4096 envs over 128 threads); the slow single thread runs quarter regions
+            scaling[str(th)] = statistics.median(regions(th, 3, rep=1 if th == 1 else R))
+        # the two best calibration points share the budget; the reported value is the MEDIAN region rate of the better one
+        # (repeatable to a few percent, where a mean over one noisy burst was not)
         top = sorted(cands, key=lambda th: scaling[str(th)], reverse=True)[:2]
-        value, dt, best, reps = 0.0, 0.0, top[0], 0
+        value, dt, best, reps, spread = 0.0, 0.0, top[0], 0, None
         for th in top:
             per = B * T * R / scaling[str(th)]
-            n_rep = int(max(2, min(5000, 0.5 * budget_s / max(per, 1e-6))))
-            v, d = run(th, n_rep)
+            n_rep = int(max(5, min(5000, 0.5 * budget_s / max(per, 1e-6))))
+            t0 = time.perf_counter()
+            rates = regions(th, n_rep)
+            d = time.perf_counter() - t0
+            v = statistics.median(rates)
             scaling[str(th)] = v
             if v > value:
-                value, dt, best, reps = v, d, th, n_rep
+                q = statistics.quantiles(rates, n=10) if len(rates) >= 10 else [min(rates)] * 9
+                value, dt, best, reps, spread = v, d, th, n_rep, [q[0], v, q[-1]]
     finally:
         orc.set_exact_pow(True)
     single = scaling["1"]
@@ -230,6 +241,7 @@ def cpu_baseline(env_name, n, batch, budget_s=10.0):
             "sample": f"C oracle (oracle/flight_oracle.c orc_batch_rollout_rep: one OpenMP region per {T * R} steps, "
                       f"env-major), {B} envs x {T * R * reps} steps on {best} threads (best of {cands}), auto-reset, "
                       f"obs+state emitted, {dt:.1f} s wall on {cpu_model()} ({os.cpu_count()} logical CPUs)",
+            "region_rate_p10_median_p90": spread, "statistic": "median over the timed regions",
             "single_thread_value": single, "speedup_vs_single_thread": value / single,
             "thread_scaling_env_steps_per_s": scaling}
 
@@ -238,20 +250,21 @@ def cpu_baseline(env_name, n, batch, budget_s=10.0):
 class Comm:
     """Barrier / max-over-ranks for 1..N ranks (gloo on host tensors in the shared-GPU test mode, RCCL otherwise)."""
 
-    def __init__(self, world, dev, share):
+    def __init__(self, world, dev, share, pg=None):
         import torch
         self.world, self.torch = world, torch
         self.cdev = torch.device("cpu") if share else dev
-        if world > 1:
+        self.pg = world > 1 if pg is None else pg    # a one-rank RCCL group runs the same barrier / all-reduce calls
+        if self.pg:
             import torch.distributed as dist
             self.dist = dist
 
     def barrier(self):
-        if self.world > 1:
+        if self.pg:
             self.dist.barrier()
 
     def max(self, x):
-        if self.world == 1:
+        if not self.pg:
             return float(x)
         t = self.torch.tensor([x], dtype=self.torch.float64, device=self.cdev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
@@ -340,13 +353,16 @@ def run_workload(cs, dev, comm, env_name, n, B, mode, K, W, kernel, rank=0, no_g
     alg = algorithmic_bytes_per_env_step(env_name, n, m, mode)
     label = kernel_label(env_name, n, B, mode, kernel)
     achieved = alg * B * K / t_ev / 1e9
+    traffic, traffic_source = pmc_traffic(label, B, steps_per_launch)
     res = {
         "value": B * comm.world * K / t_ev, "unit": "env-steps/s", "ms_per_step": t_ev * 1e3 / K,
         "wall_ms_per_step": t_wall * 1e3 / K, "repeats": len(ev), "timed_gpu_s": sum(ev),
         "region_ms_min_median_max": [min(ev) * 1e3, statistics.median(ev) * 1e3, max(ev) * 1e3],
         "steps_per_launch": steps_per_launch,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(label, B, steps_per_launch),
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "traffic_source": (traffic_source + ": committed rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), per "
+                                        "env-step, scaled by this run's batch x steps per launch") if traffic_source else None,
                      "kernel": label,
                      "algorithmic_bytes_per_env_step": alg,
                      "algorithmic_bytes_per_launch": alg * B * steps_per_launch,
@@ -467,13 +483,29 @@ def main():
     dev_index = 0 if share else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
-        import torch.distributed as dist
-        if share:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
-    comm = Comm(world, dev, share)
+    import torch.distributed as dist
+    pg, pg_error = False, None
+    if world > 1 or in_torchrun or a.pg != "off":
+        # one rank outside torchrun: its own rendezvous on the loopback
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            os.environ["MASTER_PORT"] = str(_free_port())
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("LOCAL_RANK", "0")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        try:
+            if share:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=dev)
+            pg = True
+        except Exception as exc:   # noqa: BLE001 -- N = 1, --pg auto: the line says so; everything else fails loudly
+            if world > 1 or in_torchrun or a.pg == "on":
+                raise
+            pg_error = f"{type(exc).__name__}: {exc}"[:300]
+            sys.stderr.write(f"bench.py: RCCL process group at world_size 1 failed ({pg_error}); continuing without\n")
+    comm = Comm(world, dev, share, pg)
 
     import cooperative_search_amd as cs
 
@@ -489,10 +521,17 @@ def main():
 
     # evaluation-metric reduction (runner.py:86-96): the path's only collective, outside the timed region
     part = env.metric_partials().clone().to(comm.cdev)
-    if world > 1:
-        gathered = [torch.zeros_like(part) for _ in range(world)]
-        dist.all_gather(gathered, part)
-        part = torch.stack(gathered).sum(0)
+    if pg:
+        try:
+            gathered = [torch.zeros_like(part) for _ in range(world)]
+            dist.all_gather(gathered, part)
+            part = torch.stack(gathered).sum(0)
+            torch.cuda.synchronize(dev)
+        except Exception as exc:   # noqa: BLE001
+            if world > 1 or in_torchrun or a.pg == "on":
+                raise
+            pg, pg_error = False, f"all_gather: {type(exc).__name__}: {exc}"[:300]
+            comm.pg = False
     part = part.cpu().numpy()
     del env
     torch.cuda.empty_cache()
@@ -507,14 +546,16 @@ def main():
                                    f"target_mode=0 ({a.workload})", "mode": mode,
                        "steps_per_launch": res["steps_per_launch"], "auto_reset": True, "emits": "obs+state every step",
                        "kernel": a.kernel, "hip_graph": mode == "step" and not a.no_graph,
-                       "backend": ("gloo (BENCH_SHARE_GPU test mode)" if share else "nccl (RCCL)") if world > 1 else None},
+                       "backend": ("gloo (BENCH_SHARE_GPU test mode)" if share else "nccl (RCCL)") if pg else None,
+                       **({"backend_error": pg_error} if pg_error else {})},
             "timing": {"clock": "HIP events on the launch stream, median over repeats of the K-step region, max over ranks",
                        "repeats": res["repeats"], "timed_gpu_s": res["timed_gpu_s"],
                        "region_ms_min_median_max": res["region_ms_min_median_max"],
                        "wall_ms_per_step": res["wall_ms_per_step"]},
             "roofline": res["roofline"],
             "eval": {"mean_episode_reward_so_far": part[0] / part[3], "win_rate_now": part[1] / part[3],
-                     "mean_targets_found_now": part[2] / part[3], "envs": int(part[3]), "world_size": world},
+                     "mean_targets_found_now": part[2] / part[3], "envs": int(part[3]), "world_size": world,
+                     "reduced_by": "all_gather over the process group" if pg else "local (no process group)"},
         }
     also = []
     if not a.no_also and a.workload == "c2" and not a.batch:
@@ -549,7 +590,7 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(env_name, n, B)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if pg:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -1,10 +1,11 @@
 """ctypes binding of libcoopsearch_hip.so (include/coopsearch.h).  No fallback: a missing library raises."""
 import ctypes as C
 import os
+import warnings
 
 from . import build as _build
 
-ABI_VERSION = 3   # CS_ABI_VERSION of include/coopsearch.h; bumped whenever an export or a struct changes
+ABI_VERSION = 4   # CS_ABI_VERSION of include/coopsearch.h; bumped whenever an export or a struct changes
 MT_STRIDE = 672    # CS_MT_STRIDE
 MAX_AGENTS = 8
 MAX_TARGETS = 16
@@ -15,7 +16,7 @@ H_WORDS_LO, H_WORDS_HI, H_CURR_REWARD, H_NEWLY_RESET = 8, 9, 10, 11
 SELECT_SOFTMAX, SELECT_SAMPLE = 1, 2
 FREEZE_DONE, AUTO_RESET, ACTIONS_I64, KERNEL_GROUP, KERNEL_LANE, KERNEL_SOLO, KERNEL_DUO = 1, 2, 4, 8, 16, 32, 64
 
-EXPORTS = ["cs_abi_version", "cs_last_error", "cs_state_layout", "cs_init", "cs_seed", "cs_reset", "cs_step",
+EXPORTS = ["cs_abi_version", "cs_source_hash", "cs_last_error", "cs_state_layout", "cs_init", "cs_seed", "cs_reset", "cs_step",
            "cs_rollout", "cs_rollout_policy", "cs_rollout_policy_flight", "cs_emit", "cs_metrics", "cs_mt_canonical", "cs_mt_advance", "cs_policy_packed_floats", "cs_policy_pack", "cs_policy_forward",
            "cs_policy_conv_features", "cs_policy_last_error", "cs_store_episodes", "cs_episodes_last_error"]
 
@@ -56,7 +57,9 @@ def library_path():
 
 
 def load():
-    """Load (building first if the in-tree .so is missing or older than its sources)."""
+    """Load (building first if the in-tree .so is missing or was built from other sources).  Staleness is decided by the
+    source hash recorded at build time (build.source_hash), not by mtimes; where hipcc is absent a library whose recorded
+    hash differs is still loaded -- with a warning -- as long as its ABI version matches (checked below)."""
     global _lib
     if _lib is not None:
         return _lib
@@ -66,14 +69,17 @@ def load():
             if not os.path.exists(path):
                 raise CoopSearchError(
                     f"{path} is missing and hipcc is not available: the HIP extension is required (no CPU fallback)")
-            raise CoopSearchError(
-                f"{path} is older than its sources and hipcc is not available to rebuild it: refusing to load a stale "
-                "library (rebuild where hipcc exists; the built .so travels with the tree)")
-        _build.build_extension()
+            warnings.warn(f"{path} was not built from the sources present here (recorded source hash "
+                          f"{_build._recorded_hash(path)!r}, sources {_build.source_hash()!r}) and hipcc is not available to "
+                          "rebuild it: loading it as it is (the ABI version is checked)", RuntimeWarning, stacklevel=2)
+        else:
+            _build.build_extension()
     L = C.CDLL(path)
     vp = C.c_void_p
     L.cs_abi_version.restype = C.c_int
     L.cs_last_error.restype = C.c_char_p
+    if hasattr(L, "cs_source_hash"):
+        L.cs_source_hash.restype = C.c_char_p
     L.cs_state_layout.argtypes = [C.POINTER(CsConfig), C.POINTER(CsLayout)]
     L.cs_init.argtypes = [C.POINTER(CsConfig), vp, vp]
     L.cs_seed.argtypes = [C.POINTER(CsConfig), vp, vp, vp]
@@ -98,7 +104,7 @@ def load():
     L.cs_policy_conv_features.argtypes = [vp] * 7 + [C.c_int64, C.c_int, vp, vp]
     for name in EXPORTS:
         fn = getattr(L, name)
-        if name not in ("cs_abi_version", "cs_last_error", "cs_policy_packed_floats", "cs_policy_last_error",
+        if name not in ("cs_abi_version", "cs_source_hash", "cs_last_error", "cs_policy_packed_floats", "cs_policy_last_error",
                         "cs_episodes_last_error"):
             fn.restype = C.c_int
     if L.cs_abi_version() != ABI_VERSION:
@@ -113,22 +119,45 @@ _ops = None
 
 def torch_ops():
     """torch.ops.coopsearch (csrc/torch_ops.cpp): tensor-level ops over the same C ABI -- device / dtype / contiguity
-    checks in C++ (TORCH_CHECK), stream = torch's current HIP stream.  Builds coopsearch_torch.so first when it is missing
-    or stale; no fallback: a missing library with no compiler raises."""
+    checks in C++ (TORCH_CHECK), stream = torch's current HIP stream, the tensors' device made current.  Builds
+    coopsearch_torch.so (g++: host code only) first when it is missing or was built from other sources; raises when it can
+    neither be built nor loaded -- `pick_binding` turns that into the ctypes route for callers that did not ask for torch."""
     global _ops
     if _ops is not None:
         return _ops
     import torch
     load()   # libcoopsearch_hip.so first: coopsearch_torch.so links it
     if _build.torch_ops_stale():
-        if _build.hipcc_path() is None and not os.path.exists(_build.TORCH_LIB_PATH):
-            raise CoopSearchError(f"{_build.TORCH_LIB_PATH} is missing and there is no compiler to build it")
-        _build.build_torch_ops()
+        if _build.cxx_path() is None:
+            if not os.path.exists(_build.TORCH_LIB_PATH):
+                raise CoopSearchError(f"{_build.TORCH_LIB_PATH} is missing and there is no g++ to build it")
+            warnings.warn(f"{_build.TORCH_LIB_PATH} was not built from the torch_ops.cpp present here and there is no g++ "
+                          "to rebuild it: loading it as it is (the ABI version is checked)", RuntimeWarning, stacklevel=2)
+        else:
+            _build.build_torch_ops()
     torch.ops.load_library(_build.TORCH_LIB_PATH)
     if int(torch.ops.coopsearch.abi_version()) != ABI_VERSION:
         raise CoopSearchError(f"{_build.TORCH_LIB_PATH}: ABI version mismatch (stale library)")
     _ops = torch.ops.coopsearch
     return _ops
+
+
+def pick_binding(binding=None):
+    """'torch' | 'ctypes' | None -> (name, torch.ops.coopsearch or None).  None = the torch op layer when it can be built /
+    loaded, else the ctypes route with a warning (same library, same kernels); an experimental library (COOPSEARCH_LIB) is
+    only reachable through ctypes.  An explicit 'torch' raises when the op library is unavailable."""
+    if binding not in (None, "torch", "ctypes"):
+        raise ValueError("binding must be 'torch' (torch.ops.coopsearch, csrc/torch_ops.cpp) or 'ctypes'")
+    if binding == "ctypes" or (binding is None and os.environ.get("COOPSEARCH_LIB")):
+        return "ctypes", None
+    try:
+        return "torch", torch_ops()
+    except Exception as exc:   # noqa: BLE001 -- compiler missing, torch headers missing, dlopen failure, ABI mismatch
+        if binding == "torch":
+            raise
+        warnings.warn(f"torch.ops.coopsearch is unavailable ({type(exc).__name__}: {exc}); using the ctypes binding of the "
+                      "same library", RuntimeWarning, stacklevel=3)
+        return "ctypes", None
 
 
 def check(rc):

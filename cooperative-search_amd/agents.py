@@ -130,7 +130,7 @@ class FusedAgents:
         self._C, self._lib = C, _lib
         self._L = _lib.load()
         # torch.ops.coopsearch.* (checks in C++, torch's stream) unless an experimental library is selected
-        self._ops = None if os.environ.get("COOPSEARCH_LIB") else _lib.torch_ops()
+        self._ops = _lib.pick_binding(None)[1]
         self.args, self.batch, self.device = args, int(batch), torch.device(device)
         self.n_agents, self.n_actions, self.cells = args.n_agents, args.n_actions, cells
         self.rows = self.batch * self.n_agents
@@ -170,13 +170,18 @@ class FusedAgents:
         if rc != 0:
             raise self._lib.CoopSearchError(self._L.cs_policy_last_error().decode())
 
+    def _on_device(self):
+        """ctypes route: the launches go to the process's current device, so this object's device is made current."""
+        return torch.cuda.device(self.device)
+
     def _conv_features(self, maps, map_stride, n_maps, feat):
         if self._ops is not None:
             self._ops.policy_conv_features(*self.conv_w, maps, int(map_stride), int(n_maps), feat)
             return
         vp = lambda t: self._C.c_void_p(t.data_ptr())
-        self._check(self._L.cs_policy_conv_features(*[vp(w) for w in self.conv_w], vp(maps), map_stride, n_maps,
-                                                    vp(feat), self._stream()))
+        with self._on_device():
+            self._check(self._L.cs_policy_conv_features(*[vp(w) for w in self.conv_w], vp(maps), map_stride, n_maps,
+                                                        vp(feat), self._stream()))
 
     def init_hidden(self):
         self.hidden.zero_()
@@ -217,10 +222,11 @@ class FusedAgents:
                                      self.seed, self.calls, self.row0, sel)
             self.calls += 1
             return out
-        self._check(self._L.cs_policy_forward(vp(self.packed), vp(obs), width, self.cells, vp(last),
-                                              vp(self.feat) if self.conv else None, self.n_agents, vp(self.hidden),
-                                              vp(self.q) if want_q else None, vp(out), self.rows, self.n_agents,
-                                              self.n_actions, eps, self.seed, self.calls, self.row0, sel, self._stream()))
+        with self._on_device():
+            self._check(self._L.cs_policy_forward(vp(self.packed), vp(obs), width, self.cells, vp(last),
+                                                  vp(self.feat) if self.conv else None, self.n_agents, vp(self.hidden),
+                                                  vp(self.q) if want_q else None, vp(out), self.rows, self.n_agents,
+                                                  self.n_actions, eps, self.seed, self.calls, self.row0, sel, self._stream()))
         self.calls += 1
         return out
 
@@ -239,10 +245,11 @@ class FusedAgents:
                                      self.q if want_q else None, self.actions, self.rows, self.n_agents, self.n_actions, 0.0,
                                      self.seed, self.calls, self.row0, 0)
             return self.actions
-        self._check(self._L.cs_policy_forward(vp(self.packed), vp(x), x.stride(0), self.cells, None,
-                                              vp(feat) if self.conv else None, 1, vp(self.hidden),
-                                              vp(self.q) if want_q else None, vp(self.actions), self.rows, self.n_agents,
-                                              self.n_actions, 0.0, self.seed, self.calls, self.row0, 0, self._stream()))
+        with self._on_device():
+            self._check(self._L.cs_policy_forward(vp(self.packed), vp(x), x.stride(0), self.cells, None,
+                                                  vp(feat) if self.conv else None, 1, vp(self.hidden),
+                                                  vp(self.q) if want_q else None, vp(self.actions), self.rows, self.n_agents,
+                                                  self.n_actions, 0.0, self.seed, self.calls, self.row0, 0, self._stream()))
         return self.actions
 
     def policy(self, epsilon=0.0, evaluate=True):

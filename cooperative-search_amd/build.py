@@ -1,6 +1,7 @@
 """Builds csrc/libcoopsearch_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
 import contextlib
 import fcntl
+import hashlib
 import os
 import shutil
 import subprocess
@@ -9,7 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB_PATH = os.environ.get("COOPSEARCH_LIB") or os.path.join(CSRC, "libcoopsearch_hip.so")  # override: experiments only
-TORCH_LIB_PATH = os.path.join(CSRC, "coopsearch_torch.so")   # torch.ops.coopsearch.*: the op layer over the C ABI
+# torch.ops.coopsearch.*: the op layer over the C ABI (override: the sanitizer build of tests/test_sanitizers_cpu.py)
+TORCH_LIB_PATH = os.environ.get("COOPSEARCH_TORCH_LIB") or os.path.join(CSRC, "coopsearch_torch.so")
 SOURCES = ["coopsearch.hip", "policy.hip", "episodes.hip", "policy_dev.h", "trig_table.inc"]
 HEADERS = [os.path.join(ROOT, "include", "coopsearch.h")]
 
@@ -21,14 +23,43 @@ def hipcc_path():
     return None
 
 
+def _hash_files(paths):
+    h = hashlib.sha256()
+    for d in paths:
+        h.update(os.path.basename(d).encode() + b"\0")
+        with open(d, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    return h.hexdigest()[:16]
+
+
+def source_hash():
+    """Hash of everything libcoopsearch_hip.so is compiled from.  The build embeds it (cs_source_hash()) and writes it
+    next to the library (<lib>.srchash): staleness is decided by CONTENT, never by mtime -- the .so files are git-ignored
+    and travel by copy (rsync, gpurun snapshot, checkout), so their mtimes relative to the sources mean nothing."""
+    return _hash_files([os.path.join(CSRC, s) for s in SOURCES] + HEADERS)
+
+
+def torch_ops_source_hash():
+    return _hash_files([os.path.join(CSRC, "torch_ops.cpp")] + HEADERS)
+
+
+def _recorded_hash(lib_path):
+    try:
+        with open(lib_path + ".srchash") as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
 def is_stale():
+    """True when the in-tree library is missing or was built from other sources than the ones present (recorded hash
+    differs or is absent)."""
     if os.environ.get("COOPSEARCH_LIB"):
         return False
     if not os.path.exists(LIB_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    return _recorded_hash(LIB_PATH) != source_hash()
 
 
 @contextlib.contextmanager
@@ -55,21 +86,28 @@ def build_extension(force=False, verbose=False):
         if not force and not is_stale():  # another process built it while we waited
             return LIB_PATH
         tmp = f"{LIB_PATH}.tmp.{os.getpid()}"
+        digest = source_hash()
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-               "-I", os.path.join(ROOT, "include"), os.path.join(CSRC, "coopsearch.hip"), os.path.join(CSRC, "policy.hip"), os.path.join(CSRC, "episodes.hip"), "-o", tmp]
+               f'-DCS_SOURCE_HASH="{digest}"', "-I", os.path.join(ROOT, "include"), os.path.join(CSRC, "coopsearch.hip"), os.path.join(CSRC, "policy.hip"), os.path.join(CSRC, "episodes.hip"), "-o", tmp]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd, cwd=CSRC)
         os.replace(tmp, LIB_PATH)
+        with open(LIB_PATH + ".srchash", "w") as f:
+            f.write(digest + "\n")
     return LIB_PATH
 
 
 def torch_ops_stale():
+    if os.environ.get("COOPSEARCH_TORCH_LIB"):
+        return False
     if not os.path.exists(TORCH_LIB_PATH):
         return True
-    t = os.path.getmtime(TORCH_LIB_PATH)
-    deps = [os.path.join(CSRC, "torch_ops.cpp")] + HEADERS
-    return any(os.path.getmtime(d) > t for d in deps)
+    return _recorded_hash(TORCH_LIB_PATH) != torch_ops_source_hash()
+
+
+def cxx_path():
+    return shutil.which("g++") or shutil.which("c++")
 
 
 def build_torch_ops(force=False, verbose=False):
@@ -80,7 +118,7 @@ def build_torch_ops(force=False, verbose=False):
     build_extension()
     import torch
     from torch.utils import cpp_extension as ce
-    cxx = shutil.which("g++") or shutil.which("c++")
+    cxx = cxx_path()
     if cxx is None:
         raise RuntimeError("g++ not found: cannot build coopsearch_torch.so")
     tlib = ce.library_paths()[0]
@@ -99,6 +137,8 @@ def build_torch_ops(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd, cwd=CSRC)
         os.replace(tmp, TORCH_LIB_PATH)
+        with open(TORCH_LIB_PATH + ".srchash", "w") as f:
+            f.write(torch_ops_source_hash() + "\n")
     return TORCH_LIB_PATH
 
 

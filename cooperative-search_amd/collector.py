@@ -39,14 +39,16 @@ def assemble_episodes(o, s, u, r, term, n_actions, out=None, slots=None):
             raise ValueError("assemble_episodes: tensors must be contiguous and on one device")
     if any(out[k].dtype != torch.float32 or out[k].shape[1] != T for k in KEYS) or u.dtype != torch.int64:
         raise ValueError("assemble_episodes: destinations must be float32 [slots, T, ...] and u int64")
-    if not os.environ.get("COOPSEARCH_LIB"):   # torch.ops.coopsearch.store_episodes: checks in C++, torch's stream
-        _lib.torch_ops().store_episodes(o, s, u, r, term.view(torch.uint8), slots, A, [out[k] for k in KEYS])
+    ops = _lib.pick_binding(None)[1]
+    if ops is not None:   # torch.ops.coopsearch.store_episodes: checks in C++, torch's stream
+        ops.store_episodes(o, s, u, r, term.view(torch.uint8), slots, A, [out[k] for k in KEYS])
         return out
     L = _lib.load()
     eo = _lib.CsEpisodeOut(**{k: out[k].data_ptr() for k in KEYS})
-    rc = L.cs_store_episodes(B, T, n, A, w, S, o.data_ptr(), s.data_ptr(), u.data_ptr(), r.data_ptr(),
-                             term.view(torch.uint8).data_ptr(), slots.data_ptr() if slots is not None else None,
-                             C.byref(eo), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    with torch.cuda.device(dev):   # the launch goes to the process's current device
+        rc = L.cs_store_episodes(B, T, n, A, w, S, o.data_ptr(), s.data_ptr(), u.data_ptr(), r.data_ptr(),
+                                 term.view(torch.uint8).data_ptr(), slots.data_ptr() if slots is not None else None,
+                                 C.byref(eo), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     if rc != 0:
         raise _lib.CoopSearchError(L.cs_episodes_last_error().decode())
     return out

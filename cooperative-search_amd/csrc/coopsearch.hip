@@ -2939,11 +2939,10 @@ inline bool use_lane_kernel(const cs_config *c, int flags) {
     return c->batch >= 32768;
 }
 
-// 16-lanes-per-env rollout: the kinematics / detection wavefront pair wins while the batch leaves a wave slot per SIMD
-// empty (profiles/r02_batch_sweep.md: 3 agents, B = 4096: 1.59e9 vs 1.49e9 env-steps/s, B = 16384: 1.69e9 vs 2.43e9;
-// 5 agents, B = 4096: 1.07e9 vs 0.89e9, B = 16384: 1.14e9 vs 1.43e9; teams of 7 and 8 spill in the pair)
-// the pair kernel pays while its two wavefronts per four envs still find a SIMD each (1024 SIMDs x 2 wave slots at these
-// register counts): measured crossover at 4096 envs -- 4608: pair 3.40 us per step, one-wavefront kernel 3.18 (3 agents)
+// 16-lanes-per-env rollout: the kinematics / detection wavefront pair pays while its two wavefronts per four envs still
+// find a SIMD each (1024 SIMDs x 2 wave slots at these register counts); teams of 7 and 8 spill in the pair.  Measured
+// crossover at 4096 envs (profiles/r02_batch_sweep.md; 3 agents at 4608 envs: pair 3.40 us per step, one-wavefront kernel
+// 3.18).
 inline bool duo_pays(const cs_config *c) { return c->n_agents <= 6 && c->batch <= 4096; }
 
 // Rows with at least this many twisted words ahead are left alone by the pre-pass of a T-step rollout: enough for the
@@ -2977,6 +2976,10 @@ inline unsigned env_blocks(const DevParams &p) { return (unsigned)(((size_t)p.B 
 extern "C" {
 
 int cs_abi_version(void) { return CS_ABI_VERSION; }
+#ifndef CS_SOURCE_HASH
+#define CS_SOURCE_HASH ""
+#endif
+const char *cs_source_hash(void) { return CS_SOURCE_HASH; }
 const char *cs_last_error(void) { return g_err; }
 
 int cs_state_layout(const cs_config *cfg, cs_layout *out) {
@@ -3076,8 +3079,9 @@ int cs_rollout(const cs_config *cfg, void *state_dev, const void *actions_dev, i
     if (T < 1) return fail(CS_E_ARG, "T must be >= 1");
     if (!actions_dev || !reward_dev || !terminated_dev || !win_dev) return fail(CS_E_ARG, "null rollout buffer");
     if (cfg->variant == 1) {
-        // flight: the map update is its own bandwidth-bound kernel, so a rollout is T (k_step, k_map) pairs enqueued
-        // back to back by this one call, each writing its own [t] slice of the outputs
+        // flight: k_step for step 0, then T - 1 launches of k_flight_pipe (the map sweep of step t beside the kinematics /
+        // detection of step t + 1), then k_map for the last step's sweep -- enqueued back to back by this one call, each
+        // writing its own [t] slice of the outputs
         hipStream_t s = (hipStream_t)stream;
         const size_t n = (size_t)cfg->n_agents, W = 4 * n + 3 * (size_t)cfg->n_targets, B = (size_t)p.B;
         const size_t obs_w = n * ((size_t)p.cells + 4), act_w = n * ((flags & CS_ACTIONS_I64) ? 8 : 4);

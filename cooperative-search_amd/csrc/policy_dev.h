@@ -46,7 +46,8 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
 // per-row random bits of one selection: counter-based, keyed by (seed, step, GLOBAL row) -- global, so that a sharded
 // batch draws the same exploration noise whatever the split (row = (env_offset + env) * n_agents + agent)
 __device__ __forceinline__ unsigned long long row_bits(unsigned long long seed, unsigned step, unsigned long long grow) {
-    return mix64(seed ^ mix64(((unsigned long long)step << 40) ^ grow));
+    // the three fields are hashed separately: no bit of the 32-bit step counter or of the 64-bit row is shifted out
+    return mix64(seed ^ mix64((unsigned long long)step) ^ mix64(grow * 0x9e3779b97f4a7c15ull));
 }
 
 // epsilon-greedy on top of the greedy choice `arg` (agent/agent.py:70-75): with probability epsilon a uniform action
@@ -79,9 +80,23 @@ __device__ __forceinline__ int select_action(QF qf, int n_actions, int sel, floa
         }
     }
     if (!(sel & CS_SELECT_SOFTMAX)) return epsilon_greedy(arg, epsilon, seed, step, grow, n_actions);
-    if (!(sel & CS_SELECT_SAMPLE)) return arg;   // argmax(prob) = argmax(q): prob is increasing in q
     float sum = 0.0f;
     for (int a = 0; a < n_actions; a++) sum += __expf(qf(a) - best);
+    if (!(sel & CS_SELECT_SAMPLE)) {
+        // argmax over the float32 prob, like agent.py:93 -- not over q: two q values close enough to round to the same
+        // prob tie there, and the first of them wins
+        const float inv0 = (1.0f - epsilon) / sum, uni0 = epsilon / (float)n_actions;
+        float pbest = -1.0f;
+        int parg = 0;
+        for (int a = 0; a < n_actions; a++) {
+            const float pa = __expf(qf(a) - best) * inv0 + uni0;
+            if (pa > pbest) {
+                pbest = pa;
+                parg = a;
+            }
+        }
+        return parg;
+    }
     const float u = (float)(row_bits(seed, step, grow) >> 40) * (1.0f / 16777216.0f);   // [0, 1)
     const float inv = (1.0f - epsilon) / sum, uni = epsilon / (float)n_actions;
     float cum = 0.0f;

@@ -10,6 +10,7 @@
 // Registered as torch.ops.coopsearch.* (torch.ops.load_library on the in-tree coopsearch_torch.so).  The ctypes
 // binding (cooperative-search_amd/_lib.py) stays as the torch-free route to the same C ABI.
 #include <ATen/hip/HIPContext.h>
+#include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 #include <torch/types.h>
@@ -55,7 +56,17 @@ void check_state(const cs_config &c, const Tensor &state) {
                 "coopsearch: state must be a contiguous GPU uint8 tensor of at least ", lay.total_bytes, " bytes");
 }
 
-void *stream_of(const Tensor &state) { return c10::hip::getCurrentHIPStream(state.device().index()).stream(); }
+// The cs_* entry points launch on whatever device is current in the process: make the tensors' device current for the
+// duration of the call (the temporary lives to the end of the full expression `ok(cs_...(..., stream_of(t)))`) and hand
+// over torch's current stream ON THAT DEVICE -- an env on cuda:1 works while cuda:0 is current.
+struct StreamOn {
+    c10::hip::HIPGuard guard;
+    void *stream;
+    explicit StreamOn(const Tensor &t)
+        : guard(t.device()), stream(c10::hip::getCurrentHIPStream(t.device().index()).stream()) {}
+    operator void *() const { return stream; }
+};
+StreamOn stream_of(const Tensor &t) { return StreamOn(t); }
 
 void ok(int rc) { TORCH_CHECK(rc == CS_OK, cs_last_error()); }
 

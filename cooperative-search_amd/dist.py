@@ -30,8 +30,9 @@ def seeds_for(offset, count, base_seed=DEFAULT_BASE_SEED):
 
 def all_gather_sum(partial):
     """Sum of `partial` (any-shape tensor of partial sums) over all ranks via ONE all-gather; identity when
-    torch.distributed is not initialised.  Works on CPU tensors (gloo) and GPU tensors (nccl = RCCL)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    torch.distributed is not initialised.  Works on CPU tensors (gloo) and GPU tensors (nccl = RCCL).  A process group
+    of ONE rank still runs the collective (RCCL at world_size 1 is the same code path as at 8: tests/test_gpu_rccl.py)."""
+    if not (dist.is_available() and dist.is_initialized()):
         return partial.clone()
     parts = [torch.zeros_like(partial) for _ in range(dist.get_world_size())]
     dist.all_gather(parts, partial.contiguous())

@@ -81,12 +81,7 @@ class BatchedFlightEnv:
         if not torch.cuda.is_available():
             raise RuntimeError("BatchedFlightEnv needs a GPU: the HIP path has no CPU fallback")
         self._L = _lib.load()
-        if binding is None:   # an experimental library (COOPSEARCH_LIB) is only reachable through ctypes
-            binding = "ctypes" if os.environ.get("COOPSEARCH_LIB") else "torch"
-        if binding not in ("torch", "ctypes"):
-            raise ValueError("binding must be 'torch' (torch.ops.coopsearch, csrc/torch_ops.cpp) or 'ctypes'")
-        self.binding = binding
-        self._ops = _lib.torch_ops() if binding == "torch" else None
+        self.binding, self._ops = _lib.pick_binding(binding)
         self.args = args
         if variant is None:
             variant = "flight" if getattr(args, "env", "flight_easy") == "flight" else "flight_easy"
@@ -120,7 +115,7 @@ class BatchedFlightEnv:
         self._cfgp = C.byref(self.cfg)
         self._cfg_t = torch.frombuffer(bytearray(bytes(self.cfg)), dtype=torch.uint8)   # the struct's bytes, for the ops
         lay = _lib.CsLayout()
-        _lib.check(self._L.cs_state_layout(self._cfgp, C.byref(lay)))
+        self._call(self._L.cs_state_layout, self._cfgp, C.byref(lay))
         self.layout = lay
         B, n, m = self.batch, self.n_agents, self.target_num
         self.cells = self.map_size * self.map_size
@@ -148,7 +143,7 @@ class BatchedFlightEnv:
             assert int(self._ops.state_bytes(self._cfg_t)) == lay.total_bytes
             self._ops.env_init(self._cfg_t, self._blob)
         else:
-            _lib.check(self._L.cs_init(self._cfgp, self._blob.data_ptr(), self._stream()))
+            self._call(self._L.cs_init, self._cfgp, self._blob.data_ptr(), self._stream())
         if seeds is None:
             seeds = (DEFAULT_BASE_SEED + self.env_offset + np.arange(B, dtype=np.int64)) % (1 << 32)
         self.seed(seeds)
@@ -157,6 +152,12 @@ class BatchedFlightEnv:
     # ------------------------------------------------------------------------------------------------ plumbing
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _call(self, fn, *args):
+        """ctypes route: the cs_* entry points launch on the process's current device, so the env's device is made current
+        for the call (the torch ops do the same in C++ with a HIPGuard); an env on cuda:1 works while cuda:0 is current."""
+        with torch.cuda.device(self.device):
+            _lib.check(fn(*args))
 
     def _view(self, off, count, dtype, shape):
         itemsize = torch.empty((), dtype=dtype).element_size()
@@ -182,7 +183,7 @@ class BatchedFlightEnv:
         if self._ops is not None:
             self._ops.mt_advance(self._cfg_t, self._blob, int(min_ahead))
         else:
-            _lib.check(self._L.cs_mt_advance(self._cfgp, self._blob.data_ptr(), int(min_ahead), self._stream()))
+            self._call(self._L.cs_mt_advance, self._cfgp, self._blob.data_ptr(), int(min_ahead), self._stream())
         self._steps_since_advance = 0
 
     def mt_canonical(self):
@@ -192,7 +193,7 @@ class BatchedFlightEnv:
         if self._ops is not None:
             self._ops.mt_canonical(self._cfg_t, self._blob, out)
         else:
-            _lib.check(self._L.cs_mt_canonical(self._cfgp, self._blob.data_ptr(), out.data_ptr(), self._stream()))
+            self._call(self._L.cs_mt_canonical, self._cfgp, self._blob.data_ptr(), out.data_ptr(), self._stream())
         return out
 
     def seed(self, seeds):
@@ -204,7 +205,7 @@ class BatchedFlightEnv:
         if self._ops is not None:
             self._ops.env_seed(self._cfg_t, self._blob, t)
         else:
-            _lib.check(self._L.cs_seed(self._cfgp, self._blob.data_ptr(), t.data_ptr(), self._stream()))
+            self._call(self._L.cs_seed, self._cfgp, self._blob.data_ptr(), t.data_ptr(), self._stream())
         self._seeds_keepalive = t
 
     # ------------------------------------------------------------------------------------------- reference API
@@ -227,8 +228,8 @@ class BatchedFlightEnv:
         if self._ops is not None:
             self._ops.env_reset(self._cfg_t, self._blob, mask, bool(init), self._obs, self._state)
             return
-        _lib.check(self._L.cs_reset(self._cfgp, self._blob.data_ptr(), mptr, 1 if init else 0,
-                                    self._obs.data_ptr(), self._state.data_ptr(), self._stream()))
+        self._call(self._L.cs_reset, self._cfgp, self._blob.data_ptr(), mptr, 1 if init else 0,
+                                    self._obs.data_ptr(), self._state.data_ptr(), self._stream())
 
     def _actions(self, actions, lead_shape):
         if not torch.is_tensor(actions):
@@ -288,9 +289,9 @@ class BatchedFlightEnv:
             self._ops.env_step(self._cfg_t, self._blob, a, self._flags(a), dst["reward"], dst["terminated"].view(torch.uint8),
                                dst["win"].view(torch.uint8), dst["obs"], dst["state"])
         else:
-            _lib.check(self._L.cs_step(self._cfgp, self._blob.data_ptr(), a.data_ptr(), self._flags(a),
+            self._call(self._L.cs_step, self._cfgp, self._blob.data_ptr(), a.data_ptr(), self._flags(a),
                                        dst["reward"].data_ptr(), dst["terminated"].data_ptr(), dst["win"].data_ptr(),
-                                       dst["obs"].data_ptr(), dst["state"].data_ptr(), self._stream()))
+                                       dst["obs"].data_ptr(), dst["state"].data_ptr(), self._stream())
         return dst["reward"], dst["terminated"].view(torch.bool), dst["win"].view(torch.bool)
 
     def rollout(self, actions, emit=True, out=None, update_views=True):
@@ -319,10 +320,10 @@ class BatchedFlightEnv:
             self._ops.env_rollout(self._cfg_t, self._blob, a, self._flags(a), out["reward"], term, win,
                                   out["obs"] if emit else None, out["state"] if emit else None)
         else:
-            _lib.check(self._L.cs_rollout(self._cfgp, self._blob.data_ptr(), a.data_ptr(), T, self._flags(a),
+            self._call(self._L.cs_rollout, self._cfgp, self._blob.data_ptr(), a.data_ptr(), T, self._flags(a),
                                           out["reward"].data_ptr(), term.data_ptr(), win.data_ptr(),
                                           out["obs"].data_ptr() if emit else None,
-                                          out["state"].data_ptr() if emit else None, self._stream()))
+                                          out["state"].data_ptr() if emit else None, self._stream())
         if update_views:
             if emit:
                 self._obs.copy_(out["obs"][-1])
@@ -371,23 +372,23 @@ class BatchedFlightEnv:
                                                 out["terminated"].view(torch.uint8), out["win"].view(torch.uint8),
                                                 out["obs"] if has_obs else None, out["state"] if has_obs else None)
             else:
-                _lib.check(self._L.cs_rollout_policy_flight(
+                self._call(self._L.cs_rollout_policy_flight,
                     self._cfgp, self._blob.data_ptr(), agents.packed.data_ptr(), *[w.data_ptr() for w in agents.conv_w],
                     agents.hidden.data_ptr(), agents.actions.data_ptr(), scratch.data_ptr(), T, flags, sel_eps, agents.seed,
                     agents.calls, agents.row0, sel_flags, out["actions"].data_ptr(), out["reward"].data_ptr(),
                     out["terminated"].data_ptr(), out["win"].data_ptr(), out["obs"].data_ptr() if has_obs else None,
-                    out["state"].data_ptr() if has_obs else None, self._stream()))
+                    out["state"].data_ptr() if has_obs else None, self._stream())
         elif self._ops is not None:
             self._ops.rollout_policy(self._cfg_t, self._blob, agents.packed, agents.hidden, agents.actions, T, flags, sel_eps,
                                      agents.seed, agents.calls, agents.row0, sel_flags, out["actions"], out["reward"],
                                      out["terminated"].view(torch.uint8), out["win"].view(torch.uint8),
                                      out["obs"] if has_obs else None, out["state"] if has_obs else None)
         else:
-            _lib.check(self._L.cs_rollout_policy(
+            self._call(self._L.cs_rollout_policy,
                 self._cfgp, self._blob.data_ptr(), agents.packed.data_ptr(), agents.hidden.data_ptr(),
                 agents.actions.data_ptr(), T, flags, sel_eps, agents.seed, agents.calls, agents.row0, sel_flags,
                 out["actions"].data_ptr(), out["reward"].data_ptr(), out["terminated"].data_ptr(), out["win"].data_ptr(),
-                out["obs"].data_ptr() if has_obs else None, out["state"].data_ptr() if has_obs else None, self._stream()))
+                out["obs"].data_ptr() if has_obs else None, out["state"].data_ptr() if has_obs else None, self._stream())
         agents.calls += T
         agents.actions.copy_(out["actions"][-1])
         if update_views:
@@ -405,8 +406,8 @@ class BatchedFlightEnv:
         if self._ops is not None:
             self._ops.env_emit(self._cfg_t, self._blob, self._obs, self._state)
             return
-        _lib.check(self._L.cs_emit(self._cfgp, self._blob.data_ptr(), self._obs.data_ptr(), self._state.data_ptr(),
-                                   self._stream()))
+        self._call(self._L.cs_emit, self._cfgp, self._blob.data_ptr(), self._obs.data_ptr(), self._state.data_ptr(),
+                                   self._stream())
 
     def get_obs(self):
         """[B, n, 4] (flight: [B, n, map*map + 4], map first) float32 -- live buffer."""
@@ -448,7 +449,7 @@ class BatchedFlightEnv:
         if self._ops is not None:
             self._ops.env_metrics(self._cfg_t, self._blob, self._metrics)
             return self._metrics
-        _lib.check(self._L.cs_metrics(self._cfgp, self._blob.data_ptr(), self._metrics.data_ptr(), self._stream()))
+        self._call(self._L.cs_metrics, self._cfgp, self._blob.data_ptr(), self._metrics.data_ptr(), self._stream())
         return self._metrics
 
     def render(self):

@@ -5,8 +5,9 @@
  * reset + step + reward + obs/state emission, batched over B independent environments that live in HBM.
  * The reference has no FFI: its boundary is a duck-typed Python object.  Every
  * entry point below names the reference method it replaces (paths relative to the reference repo); the
- * Python mirror of that object protocol lives in cooperative-search_amd/env.py and binds these symbols
- * with ctypes (INTEGRATION.md shows the stub).
+ * Python mirror of that object protocol lives in cooperative-search_amd/env.py.  Two bindings sit on these symbols:
+ * torch.ops.coopsearch.* (csrc/torch_ops.cpp, the default: tensor checks in C++, torch's current HIP stream) and
+ * ctypes (_lib.py, the torch-free route; INTEGRATION.md shows both stubs).
  *
  * Conventions
  *   - plain C types only; every *_dev pointer is DEVICE memory owned by the caller (e.g. a torch tensor's
@@ -31,7 +32,8 @@
 extern "C" {
 #endif
 
-#define CS_ABI_VERSION 3   /* 2: cs_layout.ahead_off (pre-twisted MT words), cs_mt_canonical; 3: cs_layout.job_off */
+#define CS_ABI_VERSION 4   /* 2: cs_layout.ahead_off (pre-twisted MT words), cs_mt_canonical; 3: cs_layout.job_off;
+                              4: cs_source_hash, CS_KERNEL_OCT */
 #define CS_MAX_AGENTS 8
 #define CS_MAX_TARGETS 16
 #define CS_MAX_MAP 64
@@ -129,6 +131,9 @@ enum {
 };
 
 int cs_abi_version(void);
+/* Hash of the sources this library was compiled from (cooperative-search_amd/build.py:source_hash; "" for a build that
+ * did not pass it): how the loader tells a library built from other sources, instead of comparing file mtimes. */
+const char *cs_source_hash(void);
 const char *cs_last_error(void);
 
 /* Fills `out` with the state-blob layout for cfg (cfg->batch envs).  Host only. */
@@ -216,7 +221,10 @@ int cs_policy_pack(const float *fc1_w, const float *fc1_b, const float *w_ih, co
  * select = 0: argmax_a q (first maximum), or with probability epsilon a uniform action; CS_SELECT_SOFTMAX: the softmax
  * rule of agent.py:77-97.  Random choices come from a counter-based generator keyed by (seed, step, row0 + row): row0 =
  * global index of this call's row 0 (env_offset * n_agents for a sharded batch), so the noise does not depend on the
- * sharding. */
+ * sharding.
+ * avail_actions (agent/agent.py:70, :87 mask q / prob with the env's get_avail_agent_actions) is not an input: both envs
+ * of this path return all ones for every agent (flight_env_easy.py:184-188, flight_env.py:193-197), so the mask is the
+ * identity; a caller with a real mask applies it to q_dev and selects on its side. */
 int cs_policy_forward(const float *packed_dev, const float *obs_dev, int obs_stride, int obs_offset,
                       const int64_t *last_dev, const float *feat_dev, int rows_per_feat, float *hidden_dev, float *q_dev,
                       int64_t *actions_dev, int rows, int n_agents, int n_actions, float epsilon, uint64_t seed,

@@ -15,7 +15,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "liboracle_flight.so")
+# ORACLE_LIB: tests/test_sanitizers_cpu.py points this at the ASan / UBSan build (`make -C oracle asan`)
+_LIB_PATH = os.environ.get("ORACLE_LIB") or os.path.join(_HERE, "liboracle_flight.so")
 
 MAX_AGENTS = 8
 MAX_TARGETS = 16
@@ -36,6 +37,8 @@ class OrcConfig(C.Structure):
 def build(force=False):
     """Compile oracle/liboracle_flight.so with gcc (a few hundred ms)."""
     src = os.path.join(_HERE, "flight_oracle.c")
+    if os.environ.get("ORACLE_LIB"):
+        return _LIB_PATH
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(
             os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "flight_oracle.h")),
             os.path.getmtime(os.path.join(_HERE, "trig_table.inc"))):

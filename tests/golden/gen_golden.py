@@ -328,6 +328,7 @@ def main():
     capture_all_episodes()
     capture_replay_indices()     # replay_indices.json
     capture_rnn_forward()        # rnn_forward.npz
+    capture_random_curves()      # random_curves.json
     # (the trained-checkpoint fixtures trained_*.npz have their own, slower script: gen_trained.py)
 
 
@@ -398,6 +399,58 @@ def capture_rnn_forward():
     path = os.path.join(HERE, "rnn_forward.npz")
     np.savez_compressed(path, **out)
     print("rnn_forward.npz", f"{os.path.getsize(path)/1024:.0f} KiB")
+
+
+RANDOM_CURVE_CONFIGS = [(3, 0), (5, 0), (3, 3), (3, 2)]   # (n_agents, agent_mode), flight_easy, target_mode 0
+RANDOM_CURVE_EPISODES = 1500
+RANDOM_CURVE_INDEX = [10, 20, 40, 60, 80, 100, 150, 199]   # the reference's own print indices (runner.py:168)
+
+
+def capture_random_curves():
+    """Found-fraction curves of the imported reference env under an iid uniform random policy, the protocol of
+    `RolloutWorker.generate_replay` (common/rollout.py:143-204: reset(init=True), res[t] = target_find / target_num after
+    step t + 1, padded with 1.0 after an early termination) averaged like `collect_experiment_data` (runner.py:163-171),
+    over RANDOM_CURVE_EPISODES episodes instead of the reference's 100 -- the tight statistical pin for the batched env's
+    random-policy curves (the shipped average_res_529.npy files are 100-episode samples: s.e. 2-3 points).
+    Deterministic: env stream np.random.seed(777000 + 10 n + agent_mode), actions from RandomState(888000 + ...)."""
+    Easy, _Flight, load_targets = import_reference()
+    circle = load_targets(os.path.join(REF, "flight_targets.txt"))
+    import io, contextlib
+    out = {"episodes": RANDOM_CURVE_EPISODES, "index": RANDOM_CURVE_INDEX, "protocol":
+           "flight_easy, target_mode 0, iid uniform actions, reset(init=True) per episode, pad 1.0 after termination",
+           "curves": []}
+    for n, am in RANDOM_CURVE_CONFIGS:
+        with contextlib.redirect_stdout(io.StringIO()):
+            env = Easy(make_args("flight_easy", n, am), circle)
+        seed, aseed = 777000 + 10 * n + am, 888000 + 10 * n + am
+        np.random.seed(seed)
+        arng = np.random.RandomState(aseed)
+        T = 200
+        acc = np.zeros(T)
+        found_sum = 0
+        for _ep in range(RANDOM_CURVE_EPISODES):
+            env.reset(init=True)
+            acts = arng.randint(0, 3, size=(T, n))
+            res, terminated, step = [], False, 0
+            while not terminated and step < T:
+                _r, terminated, _w = env.step([int(a) for a in acts[step]])
+                step += 1
+                res.append(env.target_find / 15)
+            res += [1.0] * (T - len(res))
+            acc += np.array(res)
+            found_sum += env.target_find
+        curve = acc / RANDOM_CURVE_EPISODES * 100.0
+        shipped = np.load(os.path.join(REF, "result", f"flight_easy_Seed0_random_{n}a15t(AM{am}TM0)", "average_res_529.npy"))
+        out["curves"].append({"n_agents": n, "agent_mode": am, "seed": seed, "aseed": aseed,
+                              "curve": [round(float(v), 6) for v in curve],
+                              "at_index": [round(float(curve[i]), 6) for i in RANDOM_CURVE_INDEX],
+                              "shipped_100_episodes_at_index": [round(float(shipped[i]), 6) for i in RANDOM_CURVE_INDEX],
+                              "mean_targets_found": found_sum / RANDOM_CURVE_EPISODES})
+        print(f"random curve n={n} AM{am}:", np.round(curve[RANDOM_CURVE_INDEX], 2), "shipped",
+              np.round(shipped[RANDOM_CURVE_INDEX], 2), flush=True)
+    with open(os.path.join(HERE, "random_curves.json"), "w") as f:
+        json.dump(out, f)
+    print("random_curves.json written")
 
 
 def capture_all_episodes():

@@ -33,7 +33,56 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert set(syms) == set(_lib.EXPORTS), (syms, _lib.EXPORTS)
     for s in syms:
         assert hasattr(L, s), s
-    assert L.cs_abi_version() == _lib.ABI_VERSION == 3
+    assert L.cs_abi_version() == _lib.ABI_VERSION == 4
+
+
+def test_staleness_is_decided_by_source_content_not_mtime(tmp_path, monkeypatch):
+    """the .so files travel by copy, so their mtimes mean nothing.  The build records a hash of its sources
+    (embedded: cs_source_hash(); beside the library: <lib>.srchash); a newer mtime on a source changes nothing, a changed
+    byte does; and where hipcc is absent a library built from other sources is still loaded (with a warning) as long
+    as its ABI version matches."""
+    from cooperative_search_amd import build
+    L = _lib.load()
+    assert L.cs_source_hash().decode() == build.source_hash() == build._recorded_hash(build.LIB_PATH)
+    assert not build.is_stale() and not build.torch_ops_stale()
+    src = os.path.join(build.CSRC, "episodes.hip")
+    st = os.stat(src)
+    try:
+        os.utime(src, (st.st_atime, st.st_mtime + 10 ** 6))   # "newer than the .so"
+        assert not build.is_stale()
+    finally:
+        os.utime(src, (st.st_atime, st.st_mtime))
+    # other sources than the ones the library was built from
+    monkeypatch.setattr(build, "source_hash", lambda: "0" * 16)
+    assert build.is_stale()
+    monkeypatch.setattr(build, "hipcc_path", lambda: None)
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.warns(RuntimeWarning, match="not built from the sources"):
+        L2 = _lib.load()
+    assert L2.cs_abi_version() == _lib.ABI_VERSION
+    # ... and a missing library with no compiler is an error, not a fallback
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(build, "LIB_PATH", str(tmp_path / "libmissing.so"))
+    with pytest.raises(_lib.CoopSearchError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_binding_falls_back_to_ctypes_only_when_torch_was_not_asked_for(monkeypatch):
+    """without g++ / torch headers the default binding degrades to ctypes (same library, same kernels) with a
+    warning; an explicit binding='torch' raises."""
+    assert _lib.pick_binding("ctypes") == ("ctypes", None)
+    name, ops = _lib.pick_binding(None)
+    assert name == "torch" and ops is _lib.torch_ops()
+
+    def broken():
+        raise _lib.CoopSearchError("coopsearch_torch.so is missing and there is no g++ to build it")
+    monkeypatch.setattr(_lib, "torch_ops", broken)
+    with pytest.warns(RuntimeWarning, match="using the ctypes binding"):
+        assert _lib.pick_binding(None) == ("ctypes", None)
+    with pytest.raises(_lib.CoopSearchError):
+        _lib.pick_binding("torch")
+    with pytest.raises(ValueError):
+        _lib.pick_binding("pybind")
 
 
 def _cfg(**kw):

@@ -42,26 +42,32 @@ def test_collector_matches_reference_episode_dict(name, closed_loop):
     assert win.tolist() == [meta["win_tag"]] * B and found.tolist() == [meta["targets_find"]] * B
 
 
-@pytest.mark.parametrize("n,agent_mode,want,tol", [
-    # result/flight_easy_Seed0_random_*a15t(AM*TM0)/average_res_529.npy at t = 10,20,40,60,80,100,150,199
-    (3, 0, [0.00, 2.87, 47.93, 66.60, 70.13, 72.40, 79.53, 84.87], 3.5),
-    (5, 0, [0.00, 4.73, 63.33, 84.00, 86.73, 88.67, 93.13, 95.80], 3.5),
-    (3, 3, [12.40, 27.00, 48.93, 57.40, 64.67, 68.80, 75.40, 80.60], 3.5),
-    # AM2: the shipped 100-episode sample (12.13 23.53 43.27 50.60 57.47 60.53 67.73 74.47) is 2 sigma low; pinned
-    # instead to 1500 episodes of the imported reference env under iid uniform actions (same padding rule)
-    (3, 2, [11.96, 23.92, 46.22, 54.34, 60.31, 65.24, 72.56, 78.11], 2.0),
-])
-def test_random_policy_curve_matches_reference_results(n, agent_mode, want, tol):
-    """The reference's shipped curves are means of 100 replays (s.e. 2-3 points); 4096 on-device episodes pin them
-    to +-3.5 points at every printed index (SURVEY.md section 6.1 reproduces them from the imported reference)."""
+def _random_curves():
+    """tests/golden/random_curves.json: 1500 episodes of the IMPORTED reference env under iid uniform actions per
+    configuration (gen_golden.py:capture_random_curves, regenerated bit-identically by its main()), next to the 100-episode
+    curves the reference ships (result/flight_easy_Seed0_random_*a15t(AM*TM0)/average_res_529.npy)."""
+    with open(os.path.join(os.path.dirname(__file__), "golden", "random_curves.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("n,agent_mode", [(3, 0), (5, 0), (3, 3), (3, 2)])
+def test_random_policy_curve_matches_reference_results(n, agent_mode):
+    """4096 on-device episodes against (a) the 1500-episode curve of the imported reference (s.e. <= 0.9 points: +-2.0 at
+    every printed index) and (b) the curve the reference ships (mean of 100 replays, s.e. 2-3 points: +-3.5; for AM2 the
+    shipped sample is 2 sigma low at four indices -- its own 1500-episode rerun says so -- and gets +-5.5)."""
+    rc = _random_curves()
+    ent = [c for c in rc["curves"] if c["n_agents"] == n and c["agent_mode"] == agent_mode][0]
+    idx = rc["index"]
     env = cs.BatchedFlightEnv(cs.make_env_args("flight_easy", n_agents=n, agent_mode=agent_mode), batch=4096)
     g = torch.Generator("cuda").manual_seed(123)
     curve = cs.collect_experiment_data(env, cs.random_policy(g))
-    got = curve[[10, 20, 40, 60, 80, 100, 150, 199]]
+    got = curve[idx]
     assert curve.shape == (200,) and (np.diff(curve) >= -1e-9).all()
-    np.testing.assert_allclose(got, want, rtol=0, atol=tol)
+    np.testing.assert_allclose(got, ent["at_index"], rtol=0, atol=2.0)
+    np.testing.assert_allclose(curve, ent["curve"], rtol=0, atol=2.5)          # the whole curve, not only eight points
+    np.testing.assert_allclose(got, ent["shipped_100_episodes_at_index"], rtol=0, atol=5.5 if agent_mode == 2 else 3.5)
     win_rate, reward, found = cs.evaluate(env, cs.random_policy(g))
-    assert 0.0 <= win_rate <= 1.0 and abs(found / 15 * 100 - want[-1]) < tol + 0.5 and reward < 0
+    assert 0.0 <= win_rate <= 1.0 and abs(found / 15 * 100 - ent["at_index"][-1]) < 2.5 and reward < 0
 
 
 @pytest.mark.parametrize("env_name", ["flight_easy", "flight"])

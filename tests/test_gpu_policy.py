@@ -329,7 +329,8 @@ def _row_uniform(seed, step, rows):
         z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
         z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
         return z ^ (z >> 31)
-    return np.array([(mix64(seed ^ mix64(((step << 40) ^ int(r)) & M)) >> 40) / 16777216.0 for r in rows], dtype=np.float64)
+    return np.array([(mix64(seed ^ mix64(step & 0xFFFFFFFF) ^ mix64((int(r) * 0x9E3779B97F4A7C15) & M)) >> 40) / 16777216.0
+                     for r in rows], dtype=np.float64)
 
 
 @pytest.mark.parametrize("eps", [0.0, 0.25])
@@ -408,7 +409,56 @@ def _trained(tag):
 IDX = [10, 20, 40, 60, 80, 100, 150, 199]   # the indices runner.py:168 prints
 
 
-@pytest.mark.parametrize("tag", ["easy3_qmix", "easy5_qmix", "easy3_reinforce"])
+EASY_TAGS = ["easy3_qmix", "easy5_qmix", "easy3_reinforce", "easy3_dop", "easy5_dop", "easy3_qmix_am3", "easy3_qmix_am2"]
+FLIGHT_TAGS = ["flight3_qmix", "flight1_qmix", "flight5_qmix", "flight3_reinforce"]
+
+
+def _load_net(z, args):
+    net = AgentRNN(rnn_input_shape(args), args)
+    net.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w_")})
+    return net
+
+
+@pytest.mark.parametrize("tag", EASY_TAGS + FLIGHT_TAGS)
+def test_trained_checkpoint_exact_trajectories(tag):
+    """next to the statistical curves, EXACT closed-loop trajectories.  gen_trained.py starts its first four
+    replays of every shipped checkpoint from recorded np.random.seed values and records every action, reward and found
+    count of the reference's own env + network; the HIP env seeded identically and driven by the HIP network kernels
+    (k_rollout_policy / cs_rollout_policy_flight) must take the SAME actions and collect the SAME rewards, step for step,
+    up to the first step where the reference network's top two outputs are within 1e-3 of each other (a near-tie that fp32
+    summation order may break differently).  Covers the DOP actors (agent.py:61-62), the softmax rule's argmax branch
+    (agent.py:92-93) and the AM2 / AM3 start modes, whose resets draw (quirk Q3)."""
+    z, args, n = _trained(tag)
+    seeds = z["traj_seeds"].astype(np.uint32)
+    K, T = len(seeds), 200
+    env = cs.BatchedFlightEnv(args, batch=K, freeze_done=True, seeds=seeds)
+    cs.apply_env_info(args, env)
+    if "reinforce" in tag:
+        args.alg = "reinforce"
+    fused = FusedAgents(args, K, net=_load_net(z, args))
+    env.seed(seeds)            # the ctor's own reset(init=True) consumed RNG, like the reference's ctor
+    env.reset(init=True)
+    fused.init_hidden()
+    out = env.rollout_policy(fused, T, epsilon=0.0, evaluate=True, emit=not env.flight)
+    acts = out["actions"].cpu().numpy()
+    rew = out["reward"].cpu().numpy()
+    compared = total = 0
+    for k in range(K):
+        L = int(z["traj_len"][k])
+        tie = np.nonzero(z["traj_qgap"][k, :L] < 1e-3)[0]
+        upto = int(tie[0]) if len(tie) else L
+        assert np.array_equal(acts[:upto, k], z["traj_actions"][k, :upto]), \
+            f"{tag} episode {k}: first differing step {np.nonzero((acts[:upto, k] != z['traj_actions'][k, :upto]).any(1))[0][:1]}"
+        assert np.array_equal(rew[:upto, k], z["traj_rewards"][k, :upto].astype(np.float32)), f"{tag} episode {k}: rewards"
+        if upto == L:   # the whole episode walked in lockstep: it ends where the reference's ended
+            assert bool(out["terminated"][L - 1, k]) and (L == 1 or not bool(out["terminated"][L - 2, k]))
+            assert int(env.target_find[k]) == int(z["traj_found"][k, L - 1])
+        compared += upto
+        total += L
+    assert compared >= 0.5 * total, f"{tag}: only {compared} of {total} steps were clear of near-ties"
+
+
+@pytest.mark.parametrize("tag", EASY_TAGS)
 def test_trained_checkpoint_closed_loop_flight_easy(tag):
     """Policy-in-the-loop parity with the reference's SHIPPED checkpoints: the checkpoint's weights
     (tests/golden/trained_*.npz, written by gen_trained.py from model/<run>/<N>_rnn_net_params.pkl) drive 4096 envs through
@@ -421,8 +471,7 @@ def test_trained_checkpoint_closed_loop_flight_easy(tag):
     cs.apply_env_info(args, env)
     if "reinforce" in tag:
         args.alg = "reinforce"   # softmax rule; epsilon = 0 and evaluate -> argmax(prob), agent.py:92-93
-    net = AgentRNN(rnn_input_shape(args), args)
-    net.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w_")})
+    net = _load_net(z, args)
     fused = FusedAgents(args, B, net=net)
     env.reset(init=True)
     fused.init_hidden()
@@ -434,8 +483,12 @@ def test_trained_checkpoint_closed_loop_flight_easy(tag):
     np.testing.assert_allclose(curve[IDX], ref[IDX], rtol=0, atol=4.0,
                                err_msg=f"{tag}: ours {np.round(curve[IDX], 2)} reference replay {np.round(ref[IDX], 2)} "
                                        f"shipped result (checkpoint {int(z['shipped_num'])}) {np.round(z['shipped_curve'][IDX], 2)}")
-    # every episode of the trained policy finds all 15 targets in the reference replay; so must (nearly) all of ours
-    assert float(z["ref_found"].mean()) == 15.0 and curve[199] > 99.5
+    # where every episode of the trained policy finds all 15 targets in the reference replay, so must (nearly) all of ours
+    if float(z["ref_found"].mean()) == 15.0:
+        assert curve[199] > 99.5
+    if int(z["checkpoint"]) == int(z["shipped_num"]):   # the shipped result file was made with the shipped weights
+        np.testing.assert_allclose(curve[IDX], z["shipped_curve"][IDX], rtol=0, atol=6.0,
+                                   err_msg=f"{tag}: ours {np.round(curve[IDX], 2)} shipped {np.round(z['shipped_curve'][IDX], 2)}")
     # the two-kernel loop (cs_policy_forward + cs_step per step) walks the same trajectories
     seeds = np.arange(256, dtype=np.uint32) + 5
     env2 = cs.BatchedFlightEnv(args, batch=256, freeze_done=True, seeds=seeds)
@@ -450,20 +503,24 @@ def test_trained_checkpoint_closed_loop_flight_easy(tag):
         env2.step(a)
 
 
-def test_trained_checkpoint_closed_loop_flight():
-    """flight (probability-map observation, conv front end): checkpoint 70 of the shipped QMIX run, the one its shipped
-    result file average_res_70.npy was made with.  1024 envs through cs_policy_conv_features + cs_policy_forward + cs_step;
-    compared with the reference replay of the same weights (30 episodes) and with the shipped curve (100 episodes)."""
-    z, args, n = _trained("flight3_qmix")
+@pytest.mark.parametrize("tag", FLIGHT_TAGS)
+def test_trained_checkpoint_closed_loop_flight(tag):
+    """flight (probability-map observation, conv front end): the shipped QMIX checkpoints of the 3-, 1- and 5-agent runs
+    (each the one its shipped result file average_res_<N>.npy was made with) and the shipped REINFORCE run.  1024 envs
+    through cs_policy_conv_features + cs_policy_forward + cs_step; compared with the reference replay of the same weights
+    (20-30 episodes: s.e. up to 4 points) and, where one exists, with the shipped curve (100 episodes)."""
+    z, args, n = _trained(tag)
     B = 1024
     env = cs.BatchedFlightEnv(args, batch=B, freeze_done=True)
     cs.apply_env_info(args, env)
-    net = AgentRNN(rnn_input_shape(args), args)
-    net.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w_")})
-    fused = FusedAgents(args, B, net=net)
+    if "reinforce" in tag:
+        args.alg = "reinforce"
+    fused = FusedAgents(args, B, net=_load_net(z, args))
     curve = cs.collect_experiment_data(env, fused.policy(evaluate=True))
-    assert int(z["checkpoint"]) == int(z["shipped_num"]) == 70
-    msg = (f"ours {np.round(curve[IDX], 2)} reference replay {np.round(z['ref_curve'][IDX], 2)} "
+    msg = (f"{tag}: ours {np.round(curve[IDX], 2)} reference replay {np.round(z['ref_curve'][IDX], 2)} "
            f"shipped {np.round(z['shipped_curve'][IDX], 2)}")
-    np.testing.assert_allclose(curve[IDX], z["shipped_curve"][IDX], rtol=0, atol=5.0, err_msg=msg)
-    np.testing.assert_allclose(curve[IDX], z["ref_curve"][IDX], rtol=0, atol=7.0, err_msg=msg)
+    if int(z["shipped_num"]) >= 0:
+        assert int(z["checkpoint"]) == int(z["shipped_num"])
+        np.testing.assert_allclose(curve[IDX], z["shipped_curve"][IDX], rtol=0, atol=5.0 if tag == "flight3_qmix" else 7.0,
+                                   err_msg=msg)
+    np.testing.assert_allclose(curve[IDX], z["ref_curve"][IDX], rtol=0, atol=7.0 if tag == "flight3_qmix" else 9.0, err_msg=msg)

@@ -14,15 +14,20 @@ raw = json.load(open(raw_path))
 # bench label -> (workload tag of pmc_traffic.sh, kernels of that run that make up the label)
 # FETCH_SIZE is doubled for the map-streaming kernels (16 B/lane coalesced stream: gfx950 reports exactly half,
 # MI355X_MICROARCH.md section HBM) and left raw elsewhere (uncalibrated width).
+# (bench label @ steps per launch, workload tag, kernels, steps per launch of that pass): bench.py only uses an entry for
+# a run with the SAME number of steps per launch (prologue traffic per env-step depends on the launch length)
 LABELS = [
-    ("k_rollout_duo<3>", "c2_rollout", ["k_rollout_duo<3>"]),
-    ("k_rollout_duo<3>@20", "c2_rollout20", ["k_rollout_duo<3>"]),
-    ("k_step<3,0>", "c2_step", ["k_step<3, 0>"]),
-    ("k_rollout<5>", "c3_rollout", ["k_rollout<5>"]),
-    ("k_rollout_lane<5>", "c5s_rollout", ["k_rollout_lane<5, true>", "k_rollout_lane<5, false>"]),
-    ("k_rollout_lane<3>", "lane3_rollout", ["k_rollout_lane<3, true>", "k_rollout_lane<3, false>"]),
-    ("k_step<3,1> + k_map<3>", "c4_step", ["k_map<3>", "k_step<3, 1>"]),
-    ("k_flight_pipe<3>", "c4_rollout", ["k_flight_pipe<3>", "k_map<3>", "k_step<3, 1>"]),
+    ("k_rollout_duo<3>@100", "c2_rollout", ["k_rollout_duo<3>"], 100),
+    ("k_rollout_duo<3>@20", "c2_rollout20", ["k_rollout_duo<3>"], 20),
+    ("k_step<3,0>@1", "c2_step", ["k_step<3, 0>"], 1),
+    ("k_rollout<5>@100", "c3_rollout", ["k_rollout<5>"], 100),
+    ("k_rollout_oct<5>@100", "c3_oct", ["k_rollout_oct<5>"], 100),
+    ("k_rollout_oct<5>@100", "c5_oct", ["k_rollout_oct<5>"], 100),
+    ("k_rollout_oct<3>@100", "oct3_rollout", ["k_rollout_oct<3>"], 100),
+    ("k_rollout_lane<5>@100", "c5s_rollout", ["k_rollout_lane<5, true>", "k_rollout_lane<5, false>"], 100),
+    ("k_rollout_lane<3>@100", "lane3_rollout", ["k_rollout_lane<3, true>", "k_rollout_lane<3, false>"], 100),
+    ("k_step<3,1> + k_map<3>@1", "c4_step", ["k_map<3>", "k_step<3, 1>"], 1),
+    ("k_flight_pipe<3>@1", "c4_rollout", ["k_flight_pipe<3>", "k_map<3>", "k_step<3, 1>"], 1),
 ]
 DOUBLED = ("k_map", "k_flight_pipe")
 
@@ -32,24 +37,26 @@ def part(tag, kernel):
     k = ent["kernels"].get(kernel)
     if k is None:
         return None
+    if "FETCH_SIZE_KB_total" not in k or "WRITE_SIZE_KB_total" not in k:
+        raise SystemExit(f"{tag} / {kernel}: a PMC pass is missing (FETCH_SIZE or WRITE_SIZE) -- refusing a partial summary")
     f = 2.0 if kernel.startswith(DOUBLED) else 1.0
-    fetch = k.get("FETCH_SIZE_KB_total", 0.0) * 1024 * f / ent["env_steps"]
-    write = k.get("WRITE_SIZE_KB_total", 0.0) * 1024 / ent["env_steps"]
+    fetch = k["FETCH_SIZE_KB_total"] * 1024 * f / ent["env_steps"]
+    write = k["WRITE_SIZE_KB_total"] * 1024 / ent["env_steps"]
     return {"FETCH_SIZE_bytes_per_env_step": round(fetch, 1), "WRITE_SIZE_bytes_per_env_step": round(write, 1),
             "hbm_bytes_per_env_step": round(fetch + write, 1), "measured_on": tag, "kernel": kernel,
             "launches": k.get("launches"), "env_steps": ent["env_steps"]}
 
 
 kernels = {}
-for label, tag, names in LABELS:
-    if tag not in raw:
+for label, tag, names, spl in LABELS:
+    if tag not in raw or label in kernels:
         continue
     parts = [p for p in (part(tag, k) for k in names) if p]
     if not parts:
         continue
     ent = {k: round(sum(p[k] for p in parts), 1) for k in
            ("FETCH_SIZE_bytes_per_env_step", "WRITE_SIZE_bytes_per_env_step", "hbm_bytes_per_env_step")}
-    ent.update(measured_on=tag, env_steps=raw[tag]["env_steps"])
+    ent.update(measured_on=tag, env_steps=raw[tag]["env_steps"], steps_per_launch=spl)
     if len(parts) > 1:
         ent["parts"] = parts
     else:
