@@ -71,9 +71,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads reported under 'also'")
-    ap.add_argument("--kernel", default="auto", choices=["auto", "group", "solo", "duo", "lane"],
-                    help="flight_easy kernel: 16 lanes per env (solo / duo wavefront roles, or chosen by batch), one lane "
-                         "per env, or everything by batch size")
+    ap.add_argument("--kernel", default="auto", choices=["auto", "group", "solo", "duo", "oct", "lane"],
+                    help="flight_easy kernel: 16 lanes per env (solo / duo wavefront roles, or chosen by batch), 8 lanes per env "
+                         "(oct), one lane per env, or everything by batch size")
     ap.add_argument("--min-gpu-s", type=float, default=MIN_GPU_S)
     ap.add_argument("--pg", default="auto", choices=["auto", "on", "off"],
                     help="process group at N = 1: 'on' = init_process_group('nccl') even for one rank and fail if RCCL does "
@@ -143,13 +143,16 @@ def largest_divisor_leq(k, cap):
 
 def kernel_label(env_name, n, B, mode, kernel):
     """The kernel cs_step / cs_rollout dispatches to (csrc/coopsearch.hip: use_lane_kernel, duo_pays)."""
-    lane = env_name == "flight_easy" and (kernel == "lane" or (kernel == "auto" and B >= 32768))
+    lane_from = 65536 if mode == "rollout" else 32768   # CS_LANE_FROM (rollout); single steps: 32768
+    lane = env_name == "flight_easy" and (kernel == "lane" or (kernel == "auto" and B >= lane_from))
     if env_name == "flight":   # rollout call: step t + 1 rides inside the map sweep of step t, one launch per step
         return f"k_flight_pipe<{n}>" if mode == "rollout" else f"k_step<{n},1> + k_map<{n}>"
     if lane:
         return f"k_rollout_lane<{n}>"
     if mode == "step":
         return f"k_step<{n},0>"
+    if kernel == "oct" or (kernel == "auto" and B > 4096):
+        return f"k_rollout_oct<{n}>"
     duo = kernel == "duo" or (kernel in ("auto", "group") and n <= 6 and B <= 4096)
     return f"k_rollout_duo<{n}>" if duo else f"k_rollout<{n}>"
 

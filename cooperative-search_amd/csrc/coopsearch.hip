@@ -63,6 +63,21 @@ struct DevParams {
     float thr32, eps32;  // lane kernel's fp32 pre-filter of the sensor test, in normalised coordinates
 };
 
+// The kernel's own DevParams as it sits in the kernarg segment (every kernel here takes it as its FIRST argument), behind
+// a pointer the compiler cannot see through.  Cold paths (resets, row top-ups, epilogues) read their fields through this
+// view: the loads then happen where they are written, instead of every field being loaded at kernel entry and held in
+// SGPRs across the rollout loops, where the hot paths' own uniforms already fill the scalar file (spills show up as
+// v_readlane / v_writelane traffic inside the loops).
+__device__ __forceinline__ const DevParams &cold_params() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const void *q = (const void *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(q));
+#else
+    const void *q = nullptr;   // host pass: never executed
+#endif
+    return *reinterpret_cast<const DevParams *>(q);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // MT19937, circular form.  At cursor k, entries < k belong to the next block, entries >= k to the current
 // one -- exactly the intermediate states of NumPy's in-place block twist -- so outputs are bit-identical to
@@ -847,18 +862,14 @@ __device__ __forceinline__ void start_pose(const DevParams &p, int i, double &x,
 // reset: flight_env_easy.py:79-182 / flight_env.py:83-191.  Group-cooperative; ends with the reset-time
 // detection pass (quirk Q3) whose reward is discarded.
 // ---------------------------------------------------------------------------------------------------------
-// TRIG = false: the caller steps the env right away (fused auto-reset), so the headings' sin / cos -- recomputed by the
-// kinematics of that step -- are not evaluated here.
-template <int N, bool TRIG = true>
-__device__ __forceinline__ void env_reset(const DevParams &p, const double *T, int b, int t, int gshift, int init,
-                                          Env<N> &e) {
-    if (p.variant == 1 && init) {  // flight_env.py:84-86
-        float4 *m4 = reinterpret_cast<float4 *>(p.prob + (size_t)b * p.cells);
-        for (int c = t; c < p.cells / 4; c += G) m4[c] = make_float4(0.5f, 0.5f, 0.5f, 0.5f);
-    }
-    unsigned *mt = p.mt + (size_t)b * MT_STRIDE;
+// Target placement of a reset (flight_env_easy.py:95-134) for the env whose 16-lane group this is: lane t gets target t's
+// position in (mx, my); the env's MT19937 cursor / word count / pre-twisted count advance by what the reference's
+// sequential algorithm consumes.  No agent state involved: the octet kernel calls this alone.
+__device__ __forceinline__ void reset_targets(const DevParams &p, unsigned *mt, int t, int gshift, int &mt_pos,
+                                              unsigned long long &words_total, int &ahead, double &mx, double &my) {
     const unsigned tmask = p.n_targets >= 32 ? ~0u : ((1u << p.n_targets) - 1u);
-    double mx = 0.0, my = 0.0;
+    mx = 0.0;
+    my = 0.0;
     if (p.target_mode == 0) {
         // x = a*cx (+ dx*2*(randn-0.5) for the 'f' rows), flight_env_easy.py:95-113.  np.random.randn is the legacy
         // polar method: attempts (x1, x2) are drawn until 0 < r2 < 1; the pair's SECOND value f*x2 is returned
@@ -878,7 +889,7 @@ __device__ __forceinline__ void env_reset(const DevParams &p, const double *T, i
         int taken = 0;
         while (taken < need_total) {  // group-uniform; one batch suffices ~99 % of the time for 9 jittered targets
             AttemptBatch ab;
-            ab.generate(mt, e.mt_pos, t, e.ahead);
+            ab.generate(mt, mt_pos, t, ahead);
             const double x1 = 2.0 * ab.u1 - 1.0, x2 = 2.0 * ab.u2 - 1.0;
             const double r2 = x1 * x1 + x2 * x2;
             const bool accept = !(r2 >= 1.0 || r2 == 0.0);
@@ -897,24 +908,38 @@ __device__ __forceinline__ void env_reset(const DevParams &p, const double *T, i
             // words consumed: up to and including the attempt that supplied the last needed pair, else the batch
             const int last = have >= want ? kth_set_bit16(amask, want - 1) : 15;
             const int words = 4 * (last + 1);
-            ab.commit(mt, e.mt_pos, t, words, e.ahead);
-            e.mt_pos = wrap624(e.mt_pos + words);
-            e.words += (unsigned long long)words;
-            e.ahead = e.ahead > words ? e.ahead - words : 0;
+            ab.commit(mt, mt_pos, t, words, ahead);
+            mt_pos = wrap624(mt_pos + words);
+            words_total += (unsigned long long)words;
+            ahead = ahead > words ? ahead - words : 0;
             taken += have < want ? have : want;
         }
     } else {
         // x, y = map_size*np.random.rand() per target, flight_env_easy.py:122-127
         AttemptBatch ab;
-        ab.generate(mt, e.mt_pos, t, e.ahead);
+        ab.generate(mt, mt_pos, t, ahead);
         mx = p.L * ab.u1;
         my = p.L * ab.u2;
         const int words = 4 * p.n_targets;
-        ab.commit(mt, e.mt_pos, t, words, e.ahead);
-        e.mt_pos = wrap624(e.mt_pos + words);
-        e.words += (unsigned long long)words;
-        e.ahead = e.ahead > words ? e.ahead - words : 0;
+        ab.commit(mt, mt_pos, t, words, ahead);
+        mt_pos = wrap624(mt_pos + words);
+        words_total += (unsigned long long)words;
+        ahead = ahead > words ? ahead - words : 0;
     }
+}
+
+// TRIG = false: the caller steps the env right away (fused auto-reset), so the headings' sin / cos -- recomputed by the
+// kinematics of that step -- are not evaluated here.
+template <int N, bool TRIG = true>
+__device__ __forceinline__ void env_reset(const DevParams &p, const double *T, int b, int t, int gshift, int init,
+                                          Env<N> &e) {
+    if (p.variant == 1 && init) {  // flight_env.py:84-86
+        float4 *m4 = reinterpret_cast<float4 *>(p.prob + (size_t)b * p.cells);
+        for (int c = t; c < p.cells / 4; c += G) m4[c] = make_float4(0.5f, 0.5f, 0.5f, 0.5f);
+    }
+    unsigned *mt = p.mt + (size_t)b * MT_STRIDE;
+    double mx, my;
+    reset_targets(p, mt, t, gshift, e.mt_pos, e.words, e.ahead, mx, my);
     e.tx = mx;
     e.ty = my;
     norm_target(p, e);
@@ -979,7 +1004,9 @@ __device__ int g_tl_step_dummy;
 #define LANE_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && s < 64) g_stamps[s][k] = __builtin_readcyclecounter(); } while (0)
 #define DUO_STAMP(k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && s < 64) g_stamps[s][k] = __builtin_readcyclecounter(); } while (0)
 #define DUO_MARK(row, k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_stamps[row][k] = __builtin_readcyclecounter(); } while (0)
+#define OCT_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && s < 64) g_stamps[s][k] = __builtin_readcyclecounter(); } while (0)
 #else
+#define OCT_STAMP(k) do {} while (0)
 #define DUO_STAMP(k) do {} while (0)
 #define DUO_MARK(row, k) do {} while (0)
 #define CS_STAMP(k) do {} while (0)
@@ -1828,6 +1855,12 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io
 #ifndef CS_LANE_REFRESH_MAX_N
 #define CS_LANE_REFRESH_MAX_N 5   /* measured at B = 262144: 4 agents 29.9 -> 34-38 %, 5 agents 23.5 -> 28 % */
 #endif
+#ifndef CS_LANE_FROM
+#define CS_LANE_FROM 65536      /* default kernel of cs_rollout / cs_step from this many envs: one env per lane */
+#endif
+#ifndef CS_OCT_FROM
+#define CS_OCT_FROM 4096        /* cs_rollout above this many envs (and below CS_LANE_FROM): one env per 8 lanes */
+#endif
 constexpr int LANE_REFILL = 192;   // words twisted per refill (<= 227: independent of each other)
 constexpr int LANE_REFILL_MAX = 192;
 #ifndef CS_LANE_CHUNK
@@ -2396,6 +2429,610 @@ __global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO i
 }
 
 
+// =========================================================================================================
+// Octet path (flight_easy): one environment per EIGHT lanes, 8 per wavefront -- the rollout kernel between the
+// 16-lane pair kernel (B <= 4096) and the HBM regime.
+//
+// The 16-lane kernels replicate all n agents in every lane (5 doubles per agent and lane: 252 VGPRs at 5 agents, two
+// wavefronts per SIMD), so from 8192 envs up a batch no longer fits the chip in one resident round and a 100-step
+// launch runs its rounds one after the other (profiles/r02_batch_sweep.md: 2x per step from 8192 to 16384 envs).
+// Here nothing about an env is replicated except its header:
+//   * lane t < n of the octet OWNS agent t (n <= 8 = lanes): its position, heading and the two correctly rounded
+//     trig evaluations of a step live in that lane only; the team's positions meet in LDS (OctShared.pos) for the
+//     proximity test and for the sensor tests;
+//   * lane t owns targets t and t + 8 (<= 16 targets): 2n sensor tests per lane, the in-range mask of an agent is two
+//     ballots, a prefix popcount of the octet's 16 bits gives every in-range pair its draw slot in the reference's
+//     agent-major order, exactly as in the 16-lane kernels; draws are bits of the env's hit tape;
+//   * kinematics: every agent is first moved as if the repulsion were zero and every ordered pair (i, j) is tested the
+//     way the reference would test it (agent i's pre-move position against j's already moved position if j < i);
+//     an octet with a pair in range (3-14 % of env-steps) loads the team into registers and runs the reference's
+//     sequential loop (quirk Q7) with the repulsion as a loop over the neighbours that ARE in range;
+//   * the get_state rows of the wavefront's 8 envs sit in a persistent LDS tile (targets' normalised coordinates are
+//     written once per episode, found flags when they change, the agents' four floats every step) and leave as
+//     float4 chunks, non-temporal; the next step's actions are requested before the step's stores (one in-order
+//     counter for loads and stores: the wait for the actions then never waits for a store);
+//   * resets run wave-cooperatively on the 16-lane reset code above (four resetting envs per round, one per 16-lane
+//     group), results handed back through LDS / shuffles; MT19937 rows are topped up in place, whole wavefront on one
+//     row, when an env is about to run out of twisted words.
+// ~45 persistent VGPRs per lane instead of ~130: four and more wavefronts per SIMD, i.e. 32768+ envs in one resident
+// round, and per-env arithmetic that is exactly the 16-lane kernels' (same functions / same expression order), so
+// the results are bit-identical (tests/test_gpu_parity.py runs all kernels against the oracle and each other).
+// =========================================================================================================
+#ifndef CS_OCT_WAVES
+#define CS_OCT_WAVES 3                     /* wavefronts per SIMD the register budget must allow (168 VGPRs): measured 2 / 3 / 4,
+                                              3 agents 16384 envs 3.00 / 3.10 / 3.25 us per step, 32768: 6.04 / 5.62 / 5.58;
+                                              5 agents 16384: 4.51 / 4.63 / 4.87, 32768: 8.34 / 7.67 / 7.37 (at 4 the cold paths spill) */
+#endif
+constexpr int OG = 8;                      // lanes per env
+constexpr int OCT_ENVS = 64 / OG;          // envs per wavefront
+constexpr int OCT_BLOCK = 256;             // 4 wavefronts = 32 envs
+constexpr int OCT_PAD = CS_MAX_AGENTS + 1; // row of 8 double2 padded to 144 bytes: the 8 octets' rows fall in distinct banks
+
+struct __attribute__((aligned(16))) OctShared {
+    double2 pos[OCT_ENVS][OCT_PAD];        // current (x, y) of agent j of octet o
+    double2 tgt[OCT_ENVS][CS_MAX_TARGETS]; // reset: the new targets on their way from the 16-lane group to the octet
+    float tile[OCT_ENVS * TILE_W];         // get_state rows of the 8 envs, stride W = 4n + 3m floats
+    float reward[OCT_ENVS];
+    int term[OCT_ENVS], win[OCT_ENVS];
+    unsigned rowbuf[MT_N];                 // one MT19937 row (top-ups)
+};
+
+template <int N>
+struct EnvO {
+    double x, y, yaw, cs, sn;              // this lane's agent (lanes t < N)
+    double tx[2], ty[2];                   // targets t and t + 8
+    unsigned found, newly, newly_reset;    // octet-uniform from here on
+    int target_find, flags, time_step, total_reward, mt_pos, episodes, curr_reward, ahead;
+    unsigned long long words;
+};
+
+// The octet's slice of a wavefront ballot (bit k = lane 8 o + k)
+__device__ __forceinline__ unsigned oct_slice(unsigned long long ballot, int sh8) { return (unsigned)(ballot >> sh8) & 0xffu; }
+
+// trig_heading for TWO headings at once (a step's new heading and its wall reflection).  Same arithmetic per heading, value for
+// value; the difference is control flow: trig_heading ends in a branch for off-grid headings (only reachable by editing the raw
+// state), which splits the two evaluations into separate basic blocks that the compiler schedules one after the other --
+// two dependent chains of ~25 fp64 operations in series.  Here both on-grid evaluations sit in one block (the chains
+// interleave) and ONE rarely-taken branch afterwards redoes whichever heading was off the grid.
+__device__ __forceinline__ void trig_heading_pair(const double *T, double ya, double yb, double &sa, double &ca, double &sb,
+                                                  double &cb) {
+    double dh[2], s[2], c[2];
+    const double *rr[2];
+    const double y[2] = {ya, yb};
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        int k = (int)(y[q] * 5.729577951308232 + 0.5);  // 18/pi
+        k = k < 0 ? 0 : (k > 36 ? 36 : k);
+        const double *r = T + k * TRIG_COLS;
+        const double t = y[q] - r[0];  // exact (Sterbenz) for headings on the pi/18 grid
+        const double d = t - r[1];
+        const double bb = d - t;
+        const double err = (t - (d - bb)) + ((-r[1]) - bb);  // TwoSum tail
+        const double dl = err - r[2];
+        s[q] = r[3] + ((r[4] + d * (r[5] - 0.5 * d * r[3])) + dl * r[5]);
+        c[q] = r[5] + ((r[6] - d * (r[3] + 0.5 * d * r[5])) - dl * r[3]);
+        dh[q] = d;
+        rr[q] = r;
+    }
+    if (__builtin_expect((fabs(dh[0]) > 1e-6) | (fabs(dh[1]) > 1e-6), 0)) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            if (fabs(dh[q]) > 1e-6) {   // off-grid heading: the series of trig_heading, same operations
+                const double d = dh[q], d2 = d * d;
+                const double sd = d * (1.0 + d2 * (-1.0 / 6 + d2 * (1.0 / 120 + d2 * (-1.0 / 5040 + d2 * (1.0 / 362880)))));
+                const double cd = 1.0 + d2 * (-0.5 + d2 * (1.0 / 24 + d2 * (-1.0 / 720 + d2 * (1.0 / 40320 + d2 * (-1.0 / 3628800)))));
+                s[q] = rr[q][3] * cd + rr[q][5] * sd;
+                c[q] = rr[q][5] * cd - rr[q][3] * sd;
+            }
+        }
+    }
+    sa = s[0];
+    ca = c[0];
+    sb = s[1];
+    cb = c[1];
+}
+
+// 64-bit DPP move: lane L of every 16-lane row receives the value of lane L - k (row_shr:k) / L + k (row_shl:k)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u & 0xffffffffull), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
+}
+// lane I of every octet receives the value of lane J of the same octet (octets are aligned halves of the 16-lane DPP rows)
+template <int I, int J>
+__device__ __forceinline__ double oct_from(double v) {
+    static_assert(I != J && I >= 0 && J >= 0 && I < OG && J < OG, "lanes of one octet");
+    return dpp_f64<(I > J) ? (0x110 | (I - J)) : (0x100 | (J - I))>(v);   // row_shr : row_shl
+}
+// fx, fy in lane I = sum over the neighbours J != I, ASCENDING J like the reference's loop (flight_env_easy.py:296-300), of
+// the contributions (tx, ty) lane J computed.  Contributions of neighbours out of range are +0.0, which never changes a
+// partial sum (no term and no partial sum is ever -0.0: force_k > 0, x - x = +0.0), so padding with them is exact.
+template <int N, int I, int J = 0>
+struct OctForceSum {
+    static __device__ __forceinline__ void run(double tx, double ty, double &fx, double &fy) {
+        if constexpr (J < N) {
+            if constexpr (J != I) {
+                fx += oct_from<I, J>(tx);
+                fy += oct_from<I, J>(ty);
+            }
+            OctForceSum<N, I, J + 1>::run(tx, ty, fx, fy);
+        }
+    }
+};
+
+struct OctKin {   // one lane's agent during the kinematics of a step
+    double cx, cy;       // current position: the new one once the agent's own stage has run (quirk Q7)
+    double c1, s1;       // cos / sin of the new heading
+    double xf, yf;       // the move with zero repulsion, (x + v*cos) + 0.0, wall rule applied: what most stages commit
+    bool hitf;
+    bool hit;            // wall flag of the position in (cx, cy) once the own stage has run
+};
+
+// Stage I of the reference's sequential loop over agents (flight_env_easy.py:260-290, quirk Q7), for all 8 envs of the
+// wavefront at once: every OTHER agent J tests itself against agent I's pre-move position -- its own position being the
+// already-moved one if J < I -- and, if it is within force_dist, computes its term of I's repulsion (:293-301); the terms
+// meet in lane I (ordered DPP sum); lane I moves its agent, applies the wall rule and becomes "already moved" for the
+// later stages.  The two fp64 divisions run only if SOME env of the wavefront has such a neighbour in this stage.
+template <int N, int I>
+struct OctStage {
+    static __device__ __forceinline__ void run(const DevParams &p, const OctShared &sh, int o, int t, bool act_lane, OctKin &k) {
+        if constexpr (I < N) {
+            const double2 pi = sh.pos[o][I];   // agent I's position BEFORE its move (sh.pos is rewritten after the loop)
+            const double xi = pi.x, yi = pi.y;
+            const double dx = k.cx - xi, dy = k.cy - yi;
+            const bool inr = act_lane & (t != I) & (dx * dx + dy * dy < p.force_d2) & ((k.cx != xi) | (k.cy != yi));
+            if (__ballot(inr)) {   // wave-uniform
+                const double ex = xi - k.cx, ey = yi - k.cy;
+                const double den = ex * ex + ey * ey;
+                const double tx = inr ? p.force_k * ex / den : 0.0;
+                const double ty = inr ? p.force_k * ey / den : 0.0;
+                double fx = 0.0, fy = 0.0;
+                OctForceSum<N, I>::run(tx, ty, fx, fy);
+                const double x = (k.cx + p.velocity * k.c1) + fx;   // lane I: (x + v*cos) + f_x on its pre-move position
+                const double y = (k.cy + p.velocity * k.s1) + fy;
+                const bool h = (x < 0.0) | (x > p.L) | (y < 0.0) | (y > p.L);    // flight_env_easy.py:278
+                if (t == I) {
+                    k.cx = h ? fmin(fmax(x, 0.0), p.L) : x;
+                    k.cy = h ? fmin(fmax(y, 0.0), p.L) : y;
+                    k.hit = h;
+                }
+            } else if (t == I) {   // no neighbour in range anywhere: f = 0, the move is (x + v*cos) + 0.0
+                k.cx = k.xf;
+                k.cy = k.yf;
+                k.hit = k.hitf;
+            }
+            OctStage<N, I + 1>::run(p, sh, o, t, act_lane, k);
+        }
+    }
+};
+
+// Kinematics of one step for the octet's env (flight_env_easy.py:255-301); `act` = this lane's agent's action.
+// Returns the octet's out_flag bits.  Lanes t >= N hold no agent and take no part in any decision.
+template <int N>
+__device__ __forceinline__ unsigned oct_kinematics(const DevParams &p, const double *T, const OctShared &sh, int o, int t, int sh8,
+                                                   bool stepping, int act, EnvO<N> &e) {
+    const double PI = 3.141592653589793, TWO_PI = 2.0 * 3.141592653589793, THREE_PI = 3.0 * 3.141592653589793;
+    const double DYAW = 3.141592653589793 / 18.0;
+    const bool upd = (t < N) & stepping;
+    double yaw = e.yaw;
+    yaw = act == 1 ? yaw + DYAW : (act == 2 ? yaw + -DYAW : yaw);  // dyaw = [0, pi/18, -pi/18][act]
+    yaw = yaw > TWO_PI ? yaw - TWO_PI : (yaw < 0.0 ? yaw + TWO_PI : yaw);
+    const double yw = yaw, yr = (yaw <= PI) ? PI - yaw : THREE_PI - yaw;
+    double s1, c1, s2, c2;
+    trig_heading_pair(T, yw, yr, s1, c1, s2, c2);
+    // the move every agent makes unless a neighbour is within force_dist: (x + v*cos) + 0.0 -- the "+ 0.0" so that even
+    // signed zeros agree with the reference's `x += force[0]`
+    const double xt = (e.x + p.velocity * c1) + 0.0, yt = (e.y + p.velocity * s1) + 0.0;
+    const bool hitf = (xt < 0.0) | (xt > p.L) | (yt < 0.0) | (yt > p.L);    // flight_env_easy.py:278
+    OctKin k{e.x, e.y, c1, s1, hitf ? fmin(fmax(xt, 0.0), p.L) : xt, hitf ? fmin(fmax(yt, 0.0), p.L) : yt, hitf, false};
+    OctStage<N, 0>::run(p, sh, o, t, upd, k);
+    e.x = upd ? k.cx : e.x;
+    e.y = upd ? k.cy : e.y;
+    e.yaw = upd ? (k.hit ? yr : yw) : e.yaw;
+    e.cs = upd ? (k.hit ? c2 : c1) : e.cs;
+    e.sn = upd ? (k.hit ? s2 : s1) : e.sn;
+    return oct_slice(__ballot(k.hit & upd), sh8);
+}
+
+// Detection pass + reward (flight_env_easy.py:223-253) for the octet's env on the positions in sh.pos; draws from the hit
+// tape, which the caller guarantees to cover a step's worst case.  Returns curr_reward.
+template <int N>
+__device__ __forceinline__ int oct_detect(const DevParams &p, const OctShared &sh, int o, int t, int sh8, bool stepping,
+                                          EnvO<N> &e, unsigned (&tape)[TAPE_DW]) {
+    constexpr int MAXDW = (N * CS_MAX_TARGETS) / 32 < 1 ? 1 : (N * CS_MAX_TARGETS) / 32;   // draws of one pass, in dwords
+    const bool has0 = stepping & (t < p.n_targets), has1 = stepping & (t + OG < p.n_targets);
+    bool inr0[N], inr1[N];
+    int rank0[N], rank1[N];
+    int base = 0;
+    const unsigned below0 = (1u << t) - 1u, below1 = (1u << (t + OG)) - 1u;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const double2 a = sh.pos[o][i];
+        const double dx0 = e.tx[0] - a.x, dy0 = e.ty[0] - a.y, dx1 = e.tx[1] - a.x, dy1 = e.ty[1] - a.y;
+        inr0[i] = has0 & (dx0 * dx0 + dy0 * dy0 <= p.view_r2);   // (t_x-x)**2 + (t_y-y)**2 <= view_range**2
+        inr1[i] = has1 & (dx1 * dx1 + dy1 * dy1 <= p.view_r2);
+        const unsigned gm = oct_slice(__ballot(inr0[i]), sh8) | (oct_slice(__ballot(inr1[i]), sh8) << OG);
+        rank0[i] = base + __popc(gm & below0);   // agent-major order of the reference's double loop
+        rank1[i] = base + __popc(gm & below1);
+        base += __popc(gm);
+    }
+    // draw slot r = bit r of the tape: one 64-bit shift (teams of up to 4 never reach slot 64; up to 8: slot 127)
+    const unsigned long long t64a = (unsigned long long)tape[0] | ((unsigned long long)tape[1] << 32);
+    const unsigned long long t64b = (unsigned long long)tape[2] | ((unsigned long long)tape[3] << 32);
+    auto slot = [&](int r) __attribute__((always_inline)) {
+        if (N * CS_MAX_TARGETS <= 64) return (bool)((t64a >> r) & 1ull);
+        return (bool)(((r >= 64 ? t64b : t64a) >> (r & 63)) & 1ull);
+    };
+    bool hit0 = false, hit1 = false;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        hit0 = hit0 | (inr0[i] & slot(rank0[i]));
+        hit1 = hit1 | (inr1[i] & slot(rank1[i]));
+    }
+    e.mt_pos = wrap624(e.mt_pos + 2 * base);
+    e.words += (unsigned long long)(2 * base);
+    e.ahead -= 2 * base;
+    tape_shift<MAXDW>(tape, base);
+    // flight_env_easy.py:238-247
+    const bool new0 = hit0 & !((e.found >> t) & 1u), new1 = hit1 & !((e.found >> (t + OG)) & 1u);
+    const unsigned newly = oct_slice(__ballot(new0), sh8) | (oct_slice(__ballot(new1), sh8) << OG);
+    int r = 0;
+    if (stepping) {
+        const int cnt = __popc(newly);
+        r = -1 + 10 * cnt;   // MOVE_COST, FIND_ONE_TGT
+        e.found |= newly;
+        e.newly = newly;
+        e.target_find += cnt;
+        if (cnt > 0 && e.target_find == p.n_targets && !(e.flags & FLAG_WIN)) {
+            r += 100;  // FIND_ALL_TGT
+            e.flags |= FLAG_WIN;
+        }
+        r -= __popc(((unsigned)e.flags >> 8) & 0xffu);  // OUT_PUNISH per agent with out_flag set
+        e.curr_reward = r;
+        e.flags |= FLAG_DIRTY;
+    }
+    return r;
+}
+
+// The wavefront tops up the MT19937 rows of those of its 8 envs that have fewer than `min_ahead` twisted words left or no
+// matching tape -- whole wavefront on one row at a time, like group_wave_advance -- and hands the new tape to the env's
+// octet by ballot.
+template <int N>
+__device__ __forceinline__ void oct_wave_advance(const DevParams &p, int wave_b0, int nvalid, int lane, int min_ahead,
+                                                 unsigned *rowbuf, EnvO<N> &e, unsigned (&tape)[TAPE_DW], bool &tape_ok) {
+    const int o = lane >> 3;
+#pragma unroll 1
+    for (int g = 0; g < OCT_ENVS; g++) {
+        const int pos = __shfl(e.mt_pos, OG * g), a = __shfl(e.ahead, OG * g);
+        const int ok = __shfl(tape_ok ? 1 : 0, OG * g);
+        if (g >= nvalid || (ok && a >= min_ahead)) continue;   // wave-uniform
+        unsigned *m = p.mt + (size_t)(wave_b0 + g) * MT_STRIDE;
+        RowRegs rr;
+        row_load(m, lane, rr);
+        row_to_lds(rr, rowbuf, lane);
+        row_twist_ahead(rowbuf, m, pos, a < 0 ? 0 : a, lane);
+#pragma unroll
+        for (int it = 0; it < TAPE_DW / 2; it++) {
+            const unsigned long long bm = row_slot_hits(p, rowbuf, pos, it, lane);
+            if (o == g) {
+                tape[2 * it] = (unsigned)(bm & 0xffffffffull);
+                tape[2 * it + 1] = (unsigned)(bm >> 32);
+            }
+        }
+        if (o == g) {
+            e.ahead = MT_N;
+            tape_ok = true;
+        }
+    }
+    drain_vmem();
+}
+
+// VEC: every wavefront of the launch is full and every step's block of get_state rows is 16-byte aligned (the host splits a
+// batch into a VEC launch and a plain one for the last < 8 envs).  EMIT: obs and state are both written -- then every
+// store of a step is unconditional, the number of stores between the action prefetch and its use is a compile-time constant
+// and the wait for the actions never waits for a store (with the stores behind `if (io.obs)` the compiler has to assume
+// the shortest path and waits for the first stores of the step to be acknowledged: +0.4 us per step).
+template <int N, bool VEC, bool EMIT>
+__global__ __launch_bounds__(OCT_BLOCK, CS_OCT_WAVES) void k_rollout_oct(DevParams p, StepIO io) {
+    __shared__ double T[TRIG_ROWS * TRIG_COLS];
+    __shared__ OctShared shared[OCT_BLOCK / 64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int o = lane >> 3, sh8 = lane & ~(OG - 1);
+    int t = lane & (OG - 1);   // (not const: made opaque once per step, see the loop)
+    const int wave_b0 = io.env0 + (blockIdx.x * (OCT_BLOCK / 64) + wave) * OCT_ENVS;
+    const int b_end = io.env0 + io.env_n;
+    const int b = wave_b0 + o;
+    const bool live = VEC || b < b_end;   // a VEC launch has only full wavefronts (the early return below takes the empty ones)
+    const int nvalid = b_end - wave_b0 < OCT_ENVS ? b_end - wave_b0 : OCT_ENVS;   // <= 0: a wavefront without envs
+    const int W = 4 * N + 3 * p.n_targets;
+    bool ag = t < N;
+    const bool auto_reset = io.flags & CS_AUTO_RESET, freeze = io.flags & CS_FREEZE_DONE;
+    OctShared &sh = shared[wave];
+    EnvO<N> e;
+    // ---- everything the first step waits for is requested before the barrier that publishes the trig table
+    const size_t bl = live ? (size_t)b : (size_t)io.env0;
+    {
+        const int4 *h4 = reinterpret_cast<const int4 *>(p.hdr + bl * CS_H_WORDS);
+        const int4 h0 = h4[0], h1 = h4[1], h2 = h4[2];
+        e.found = (unsigned)h0.x;
+        e.newly = (unsigned)h0.y;
+        e.target_find = h0.z;
+        e.flags = h0.w;
+        e.time_step = h1.x;
+        e.total_reward = h1.y;
+        e.mt_pos = h1.z;
+        e.episodes = h1.w;
+        e.words = (unsigned long long)(unsigned)h2.x | ((unsigned long long)(unsigned)h2.y << 32);
+        e.curr_reward = h2.z;
+        e.newly_reset = (unsigned)h2.w;
+        e.ahead = p.ahead[bl];
+        const double4 a = reinterpret_cast<const double4 *>(p.agent + bl * CS_MAX_AGENTS * 4)[t];
+        e.x = a.x;
+        e.y = a.y;
+        e.yaw = a.z;
+        const double2 *t2 = reinterpret_cast<const double2 *>(p.tgt + bl * G * 2);
+        const double2 ta = t2[t], tb = t2[t + OG];
+        e.tx[0] = ta.x;
+        e.ty[0] = ta.y;
+        e.tx[1] = tb.x;
+        e.ty[1] = tb.y;
+    }
+    const TapeRaw traw = tape_fetch(p, (int)bl);
+    const int aidx = ag ? t : N - 1;   // lanes without an agent repeat the last agent's (valid) address
+    const int astride = (io.flags & CS_ACTIONS_I64) ? 2 : 1;
+    const int *ap = reinterpret_cast<const int *>(io.actions) + (bl * N + aidx) * astride;   // this lane's action of step 0
+    const size_t astep = (size_t)p.B * N * astride;
+    int act = ap[0];
+    if (io.T > 1) ap += astep;
+    int act_next = ap[0];   // one step ahead of its use
+    if (io.T > 2) ap += astep;   // -> step 2 (or the last step: short launches re-read it, the value is never used)
+    load_trig_to_lds(T);
+    if (nvalid <= 0) return;   // wave-uniform
+    if (!live) {   // a lane without an env never steps, resets or asks for a top-up
+        e.target_find = 0;
+        e.time_step = 0;
+        e.ahead = 1 << 20;
+    }
+    unsigned tape[TAPE_DW];
+    bool tape_ok = tape_finish(p, traw, e, tape) || !live;
+    trig_heading(T, e.yaw, e.sn, e.cs);   // what a frozen env keeps emitting
+    // ---- persistent rows: agents' floats, targets' normalised coordinates and found flags (get_state, :190-216)
+    float *row = sh.tile + o * W;
+    auto put_agent = [&]() __attribute__((always_inline)) {
+        if (ag) {
+            row[4 * t + 0] = (float)((e.x - p.mid) * p.inv_half);
+            row[4 * t + 1] = (float)((e.y - p.mid) * p.inv_half);
+            row[4 * t + 2] = (float)e.cs;
+            row[4 * t + 3] = (float)e.sn;
+        }
+    };
+    auto put_found = [&]() __attribute__((always_inline)) {
+        if (t < p.n_targets) row[4 * N + 3 * t + 2] = ((e.found >> t) & 1u) ? 1.0f : 0.0f;
+        if (t + OG < p.n_targets) row[4 * N + 3 * (t + OG) + 2] = ((e.found >> (t + OG)) & 1u) ? 1.0f : 0.0f;
+    };
+    if (t < p.n_targets) {
+        row[4 * N + 3 * t + 0] = (float)((e.tx[0] - p.mid) * p.inv_half);   // norm_target
+        row[4 * N + 3 * t + 1] = (float)((e.ty[0] - p.mid) * p.inv_half);
+    }
+    if (t + OG < p.n_targets) {
+        row[4 * N + 3 * (t + OG) + 0] = (float)((e.tx[1] - p.mid) * p.inv_half);
+        row[4 * N + 3 * (t + OG) + 1] = (float)((e.ty[1] - p.mid) * p.inv_half);
+    }
+    put_found();
+    put_agent();
+    sh.pos[o][t] = make_double2(e.x, e.y);
+    constexpr int LOW = 2 * N * CS_MAX_TARGETS;   // words one step can consume
+    oct_wave_advance<N>(p, wave_b0, nvalid, lane, io.min_ahead > LOW ? io.min_ahead : LOW, sh.rowbuf, e, tape, tape_ok);
+    // ---- write-out plan (loop invariant)
+    const int rows_valid = nvalid;
+    constexpr int W_MAX = 4 * N + 3 * CS_MAX_TARGETS;
+    constexpr int Q = (OCT_ENVS * W_MAX / 4 + 63) / 64;   // float4 chunks per lane of the largest tile
+    const int ol = lane < rows_valid * N ? lane : rows_valid * N - 1;
+    const int orow = ol / N, oag = ol - orow * N;
+    const int obs_lds = orow * W + 4 * oag;
+    const int rtw = (lane & 7) < rows_valid ? (lane & 7) : rows_valid - 1;
+    const int t16 = lane & (G - 1), gshift16 = lane & ~(G - 1), grp = lane >> 4;
+    float *p_rew = io.reward + wave_b0 + rtw;
+    uint8_t *p_term = io.terminated + wave_b0 + rtw, *p_win = io.win + wave_b0 + rtw;
+    v4f *p_obs = reinterpret_cast<v4f *>(io.obs + (size_t)wave_b0 * N * 4) + ol;
+    v4f *p_st = reinterpret_cast<v4f *>(io.state + (size_t)wave_b0 * W);   // VEC: the wavefront's block of rows, as float4 chunks
+    int chunk[Q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) chunk[q] = lane + 64 * q < OCT_ENVS * W / 4 - 1 ? lane + 64 * q : OCT_ENVS * W / 4 - 1;
+
+    for (int s = 0; s < io.T; s++) {
+        OCT_STAMP(0);
+        // Lane predicates that never change (t < N, t != I, t < n_targets ...) are cheaper to recompute -- one v_cmp -- than to
+        // keep: hoisted out of the loop each is an SGPR pair, ~30 SGPRs in all, which the scalar file does not have left
+        // (they came back as v_readlane pairs at every use).  Making t opaque once per step keeps the compares in the loop.
+        asm volatile("" : "+v"(t));
+        ag = t < N;
+        // the actions of step s + 2, requested a whole step before their use and BEFORE this step's stores: the wait for them
+        // never waits for a store (one in-order counter for loads and stores)
+        const int act_after = ap[0];
+        if (s + 3 < io.T) ap += astep;
+        bool done = e.target_find >= p.n_targets || e.time_step >= p.time_limit;
+        e.flags &= ~(FLAG_DIRTY | FLAG_RESET_PASS);
+        // ---- auto-reset (flight_env_easy.py:79-182).  Target placement -- the polar-gaussian attempts, 16 at a time --
+        //      runs on the 16-lane code above (reset_targets), one resetting env per 16-lane group and round; the new
+        //      targets come back through LDS, the stream position by shuffle; the agents' start poses and the reset-time
+        //      detection pass (quirk Q3) are the octet's own.
+        const unsigned long long need = __ballot(live && done && auto_reset && t == 0);   // bit 8 o'
+        if (__builtin_expect(need != 0ull, 0)) {   // cold: about one wave-step in 24
+            const DevParams &cp = cold_params();
+            const bool mine = (need >> sh8) & 1ull;
+            const int my_rank = __popcll(need & ((1ull << sh8) - 1ull));
+            unsigned long long pend = need;
+            for (int round = 0; pend; round++) {
+                unsigned long long m = pend;
+                for (int q = 0; q < grp; q++) m &= m ? m - 1 : 0ull;   // this group's env: the grp-th pending one
+                const int src = m ? __ffsll((long long)m) - 1 : -1;
+                for (int q = 0; q < 4; q++) pend &= pend ? pend - 1 : 0ull;
+                const int sl = src >= 0 ? src : lane;
+                int g_pos = __shfl(e.mt_pos, sl), g_ahead = __shfl(e.ahead, sl);
+                unsigned long long g_words = (unsigned long long)(unsigned)__shfl((int)(unsigned)(e.words & 0xffffffffull), sl) |
+                                             ((unsigned long long)(unsigned)__shfl((int)(unsigned)(e.words >> 32), sl) << 32);
+                if (src >= 0) {
+                    const int so = src >> 3, br = wave_b0 + so;
+                    double gx, gy;
+                    reset_targets(cp, cp.mt + (size_t)br * MT_STRIDE, t16, gshift16, g_pos, g_words, g_ahead, gx, gy);
+                    reinterpret_cast<double2 *>(cp.tgt + (size_t)br * G * 2)[t16] = make_double2(gx, gy);
+                    sh.tgt[so][t16] = make_double2(gx, gy);
+                    if (t16 < cp.n_targets) {
+                        float *rs = sh.tile + so * W + 4 * N + 3 * t16;
+                        rs[0] = (float)((gx - cp.mid) * cp.inv_half);   // norm_target
+                        rs[1] = (float)((gy - cp.mid) * cp.inv_half);
+                        rs[2] = 0.0f;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // the q-th pending env of this round was reset by group q: its (group-uniform) stream position comes back
+                const int q = my_rank - 4 * round;
+                const bool got = mine && q >= 0 && q < 4;
+                const int leader = got ? 16 * q : lane;
+                const int r_pos = __shfl(g_pos, leader), r_ahead = __shfl(g_ahead, leader);
+                const int r_wlo = __shfl((int)(unsigned)(g_words & 0xffffffffull), leader);
+                const int r_whi = __shfl((int)(unsigned)(g_words >> 32), leader);
+                if (got) {
+                    const unsigned long long w_new = (unsigned long long)(unsigned)r_wlo | ((unsigned long long)(unsigned)r_whi << 32);
+                    // the reset consumed (w_new - words) stream words, twisted ones first: their draw slots leave the tape
+                    const unsigned long long used = w_new - e.words;
+                    tape_shift<8>(tape, used < 2ull * 319ull ? (int)(used >> 1) : 319);
+                    e.mt_pos = r_pos;
+                    e.ahead = r_ahead;
+                    e.words = w_new;
+                    e.episodes += 1;
+                    e.found = 0;
+                    e.newly = 0;
+                    e.target_find = 0;
+                    e.time_step = 0;
+                    e.total_reward = 0;
+                    e.flags = 0;
+                    const double2 ta = sh.tgt[o][t], tb = sh.tgt[o][t + OG];
+                    e.tx[0] = ta.x;
+                    e.ty[0] = ta.y;
+                    e.tx[1] = tb.x;
+                    e.ty[1] = tb.y;
+                    start_pose<N>(cp, ag ? t : 0, e.x, e.y, e.yaw);
+                    trig_heading(T, e.yaw, e.sn, e.cs);
+                    sh.pos[o][t] = make_double2(e.x, e.y);
+                }
+            }
+            drain_vmem();
+            // reset-time detection pass (quirk Q3: its reward is discarded) of the envs just reset, from the tape -- topped up
+            // first where the attempts ran past the twisted words
+            if (__ballot(live && e.ahead < LOW)) oct_wave_advance<N>(cp, wave_b0, nvalid, lane, LOW, sh.rowbuf, e, tape, tape_ok);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            oct_detect<N>(p, sh, o, t, sh8, mine, e, tape);
+            put_found();
+            done = done && !mine;
+            if (__ballot(live && e.ahead < LOW)) oct_wave_advance<N>(cp, wave_b0, nvalid, lane, LOW, sh.rowbuf, e, tape, tape_ok);
+        }
+        const bool stepping = live && !(done && freeze);
+        OCT_STAMP(1);
+        // ---- kinematics -> positions, obs floats, out flags
+        const unsigned out = oct_kinematics<N>(p, T, sh, o, t, sh8, stepping, act, e);
+        OCT_STAMP(2);
+        if (stepping) e.flags = (e.flags & ~0xff00) | (int)(out << 8);
+        sh.pos[o][t] = make_double2(e.x, e.y);
+        put_agent();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- detection, reward, termination
+        OCT_STAMP(3);
+        const int reward = oct_detect<N>(p, sh, o, t, sh8, stepping, e, tape);
+        OCT_STAMP(4);
+        bool term = true;
+        if (stepping) {
+            e.total_reward += reward;
+            e.time_step += 1;
+            term = e.target_find >= p.n_targets || e.time_step >= p.time_limit;
+        }
+        if (__ballot(stepping && e.newly != 0u)) put_found();   // wave-uniform: some env found a target in this step
+        if (t == 0) {
+            sh.reward[o] = (float)reward;
+            sh.term[o] = term ? 1 : 0;
+            sh.win[o] = (e.flags & FLAG_WIN) ? 1 : 0;
+        }
+        OCT_STAMP(5);
+        // ---- a row that is about to run out of twisted words is topped up in place (about one wave-step in 10)
+        if (__builtin_expect(__ballot(live && e.ahead < LOW) != 0ull, 0))
+            oct_wave_advance<N>(cold_params(), wave_b0, nvalid, lane, LOW, sh.rowbuf, e, tape, tape_ok);
+        act = act_next;
+        act_next = act_after;
+        OCT_STAMP(6);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- this step's outputs: the wavefront's 8 envs are contiguous in every output tensor; every lane keeps running
+        //      pointers (one 64-bit add per tensor and step instead of rebuilding them from kernel arguments)
+        //      (all LDS reads first, then the stores: one LDS round trip instead of one per store)
+        const float o_rew = sh.reward[rtw];   // duplicates write the same value
+        const int o_term = sh.term[rtw], o_win = sh.win[rtw];
+        v4f o_obs = {0.f, 0.f, 0.f, 0.f}, o_st[Q];
+        if (EMIT || io.obs) {
+            const float *src = sh.tile + obs_lds;
+            o_obs = v4f{src[0], src[1], src[2], src[3]};
+        }
+        if (VEC && (EMIT || io.state)) {
+            const float4 *src4 = reinterpret_cast<const float4 *>(sh.tile);
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                const float4 v = src4[chunk[q]];
+                o_st[q] = v4f{v.x, v.y, v.z, v.w};
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        *p_rew = o_rew;
+        *p_term = (uint8_t)o_term;
+        *p_win = (uint8_t)o_win;
+        p_rew += p.B;
+        p_term += p.B;
+        p_win += p.B;
+        if (EMIT || io.obs) {   // one float4 per (env, agent)
+            __builtin_nontemporal_store(o_obs, p_obs);
+            p_obs += (size_t)p.B * N;
+        }
+        if (EMIT || io.state) {
+            if (VEC) {   // full wavefront, 16-byte aligned block of rows: float4 chunks; surplus lanes repeat the last chunk
+#pragma unroll
+                for (int q = 0; q < Q; q++) __builtin_nontemporal_store(o_st[q], p_st + chunk[q]);
+                p_st += (size_t)p.B * W / 4;
+            } else {
+                float *dst = io.state + ((size_t)s * p.B + wave_b0) * W;
+                for (int k = lane; k < rows_valid * W; k += 64) dst[k] = sh.tile[k];
+            }
+        }
+        OCT_STAMP(7);
+    }
+    if (live) {
+        const DevParams &cp = cold_params();
+        if (t == 0) {
+            int4 *h4 = reinterpret_cast<int4 *>(cp.hdr + (size_t)b * CS_H_WORDS);
+            h4[0] = make_int4((int)e.found, (int)e.newly, e.target_find, e.flags);
+            h4[1] = make_int4(e.time_step, e.total_reward, e.mt_pos, e.episodes);
+            h4[2] = make_int4((int)(unsigned)(e.words & 0xffffffffull), (int)(unsigned)(e.words >> 32), e.curr_reward,
+                              (int)e.newly_reset);
+            cp.ahead[b] = e.ahead;
+        }
+        if (ag) reinterpret_cast<double4 *>(cp.agent + (size_t)b * CS_MAX_AGENTS * 4)[t] = make_double4(e.x, e.y, e.yaw, 0.0);
+        if (tape_ok) {
+            U4 *tp = reinterpret_cast<U4 *>(cp.tape + (size_t)b * TAPE_STRIDE);
+            if (t == 0) tp[0] = U4{tape[0], tape[1], tape[2], tape[3]};
+            if (t == 1) tp[1] = U4{tape[4], tape[5], tape[6], tape[7]};
+            if (t == 2) tp[2] = U4{tape[8], tape[9], (unsigned)(e.words & 0xffffffffull), (unsigned)(e.words >> 32)};
+            if (t == 3) tp[3] = U4{(unsigned)(cp.detect_K & 0xffffffffull), (unsigned)(cp.detect_K >> 32), 0u, 0u};
+        }
+    }
+}
+
 template <int N>
 __global__ __launch_bounds__(BLOCK) void k_reset(DevParams p, const uint8_t *mask, int init, float *obs, float *state) {
     __shared__ double T[TRIG_ROWS * TRIG_COLS];
@@ -2931,12 +3568,42 @@ inline size_t lane_smem(const cs_config *c) {
     return ((TRIG_ROWS * TRIG_COLS * 8 + 15) / 16) * 16 + (BLOCK / 64) * 64 * W * sizeof(float) +
            (BLOCK / 64) * MT_N * sizeof(unsigned);   // + one MT19937 row per wavefront (in-loop refresh)
 }
+// Octet launch(es): a VEC launch over the full wavefronts (8 envs each) when every step's block of get_state rows is
+// 16-byte aligned, a plain launch for the remaining < 8 envs (or for everything otherwise).
+template <int N>
+void launch_oct(const cs_config *cfg, const DevParams &p, StepIO io, hipStream_t s) {
+    const size_t W = 4 * (size_t)cfg->n_agents + 3 * (size_t)cfg->n_targets;
+    const bool aligned = !io.state || ((reinterpret_cast<size_t>(io.state) & 15) == 0 && ((size_t)p.B * W) % 4 == 0);
+    const int full = aligned ? (p.B / OCT_ENVS) * OCT_ENVS : 0;
+    constexpr int EPB = (OCT_BLOCK / 64) * OCT_ENVS;   // envs per workgroup
+    io.min_ahead = 2 * cfg->n_agents * CS_MAX_TARGETS;  // rows are topped up in place whenever one runs low
+    if (full > 0) {
+        io.env0 = 0;
+        io.env_n = full;
+        const dim3 grid((unsigned)((full + EPB - 1) / EPB));
+        if (io.obs && io.state) hipLaunchKernelGGL((k_rollout_oct<N, true, true>), grid, dim3(OCT_BLOCK), 0, s, p, io);
+        else hipLaunchKernelGGL((k_rollout_oct<N, true, false>), grid, dim3(OCT_BLOCK), 0, s, p, io);
+    }
+    if (p.B - full > 0) {   // the tail (or an unaligned output tensor): plain stores, runtime checks
+        io.env0 = full;
+        io.env_n = p.B - full;
+        hipLaunchKernelGGL((k_rollout_oct<N, false, false>), dim3((unsigned)((p.B - full + EPB - 1) / EPB)), dim3(OCT_BLOCK), 0, s, p, io);
+    }
+}
 // Kernel choice for flight_easy: one env per 16-lane group (lowest latency, fills the chip from B = 4096) or one
 // env per lane (no replicated arithmetic; wins once the batch gives every SIMD a wavefront anyway).
-inline bool use_lane_kernel(const cs_config *c, int flags) {
+inline bool use_lane_kernel(const cs_config *c, int flags, bool rollout) {
     if (flags & CS_KERNEL_LANE) return true;
     if (flags & CS_KERNEL_GROUP) return false;
-    return c->batch >= 32768;
+    if (rollout && (flags & CS_KERNEL_OCT)) return false;
+    // single steps have no octet variant: the lane kernel takes over from the 16-lane step kernel at 32768 envs as before
+    return c->batch >= (rollout ? CS_LANE_FROM : 32768);
+}
+// cs_rollout: the octet kernel (one env per 8 lanes) between the pair kernel's range and the lane kernel's
+inline bool use_oct_kernel(const cs_config *c, int flags) {
+    if (flags & CS_KERNEL_OCT) return true;
+    if (flags & (CS_KERNEL_GROUP | CS_KERNEL_LANE | CS_KERNEL_SOLO | CS_KERNEL_DUO)) return false;
+    return c->batch > CS_OCT_FROM && c->batch < CS_LANE_FROM;
 }
 
 // 16-lanes-per-env rollout: the kinematics / detection wavefront pair pays while its two wavefronts per four envs still
@@ -3056,7 +3723,7 @@ int cs_step(const cs_config *cfg, void *state_dev, const void *actions_dev, int 
     if (!actions_dev || !reward_dev || !terminated_dev || !win_dev) return fail(CS_E_ARG, "null step buffer");
     hipStream_t s = (hipStream_t)stream;
     StepIO io{actions_dev, reward_dev, terminated_dev, win_dev, obs_dev, state_out_dev, flags, 1};
-    if (cfg->variant == 0 && use_lane_kernel(cfg, flags)) {
+    if (cfg->variant == 0 && use_lane_kernel(cfg, flags, false)) {
         CS_DISPATCH_N(cfg->n_agents, launch_lane<N>(cfg, p, io, lane_smem(cfg), s));
     } else if (cfg->variant == 0) {
         CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL((k_step<N, 0>), dim3(env_blocks(p)), dim3(BLOCK), 0, s, p, io));
@@ -3111,7 +3778,9 @@ int cs_rollout(const cs_config *cfg, void *state_dev, const void *actions_dev, i
         return launched("cs_rollout");
     }
     StepIO io{actions_dev, reward_dev, terminated_dev, win_dev, obs_dev, state_out_dev, flags, T};
-    if (use_lane_kernel(cfg, flags)) {
+    if (use_oct_kernel(cfg, flags)) {
+        CS_DISPATCH_N(cfg->n_agents, launch_oct<N>(cfg, p, io, (hipStream_t)stream));
+    } else if (use_lane_kernel(cfg, flags, true)) {
         // LANE_CHUNK steps per launch; before each chunk every env's MT19937 row is twisted fully ahead of its cursor by
         // a coalesced pre-pass, so the rollout loop itself (almost) never has to stop for a refill
         hipStream_t s = (hipStream_t)stream;

@@ -10,7 +10,7 @@
 // Registered as torch.ops.coopsearch.* (torch.ops.load_library on the in-tree coopsearch_torch.so).  The ctypes
 // binding (cooperative-search_amd/_lib.py) stays as the torch-free route to the same C ABI.
 #include <ATen/hip/HIPContext.h>
-#include <c10/hip/HIPGuard.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 #include <torch/types.h>
@@ -60,7 +60,7 @@ void check_state(const cs_config &c, const Tensor &state) {
 // duration of the call (the temporary lives to the end of the full expression `ok(cs_...(..., stream_of(t)))`) and hand
 // over torch's current stream ON THAT DEVICE -- an env on cuda:1 works while cuda:0 is current.
 struct StreamOn {
-    c10::hip::HIPGuard guard;
+    c10::hip::HIPGuardMasqueradingAsCUDA guard;   // ROCm tensors report DeviceType::CUDA: the plain HIPGuard refuses them
     void *stream;
     explicit StreamOn(const Tensor &t)
         : guard(t.device()), stream(c10::hip::getCurrentHIPStream(t.device().index()).stream()) {}

@@ -273,7 +273,63 @@ def test_flight_fused_auto_reset_matches_oracle(n, agent_mode):
         assert hdr(env)[:, _lib.H_EPISODES].min() >= 4
 
 
-@pytest.mark.parametrize("kernel", ["group", "solo", "duo", "lane"])
+@pytest.mark.parametrize("kernel", ["oct"])
+@pytest.mark.parametrize("variant,n,agent_mode,target_mode,B,T,kw", [
+    ("flight_easy", 3, 0, 0, 509, 230, {}),                    # 509 = 63 full octet wavefronts' worth + a tail of 5 envs
+    ("flight_easy", 5, 0, 0, 256, 230, {}),
+    ("flight_easy", 3, 3, 0, 128, 120, {}),                    # AM3: every reset draws (quirk Q3)
+    ("flight_easy", 3, 2, 1, 130, 120, {}),                    # AM2, uniform targets
+    ("flight_easy", 1, 1, 0, 64, 220, {}),
+    ("flight_easy", 8, 0, 0, 64, 100, {}),                     # 8 agents = every lane of the octet owns one
+    ("flight_easy", 2, 1, 0, 100, 100, {}),
+    ("flight_easy", 8, 0, 1, 72, 90, dict(target_num=16)),     # 8 x 16 pairs: the tape's worst case per step
+    ("flight_easy", 7, 0, 1, 72, 90, dict(target_num=16, view_range=30)),   # nearly every pair in range
+    ("flight_easy", 2, 0, 1, 40, 90, dict(target_num=1)),      # one target: lanes 1..7 own none
+    ("flight_easy", 3, 0, 0, 96, 90, dict(detect_prob=1.0)),
+    ("flight_easy", 4, 1, 0, 96, 90, dict(map_size=20, view_range=3)),      # agents crowd: the sequential loop every step
+    ("flight_easy", 5, 2, 0, 96, 90, dict(agent_velocity=2, force_dist=6, safe_dist=2)),
+    ("flight_easy", 3, 0, 0, 96, 90, dict(time_limit=7)),      # a reset every 7 steps
+    ("flight_easy", 6, 3, 0, 48, 120, {}),
+])
+@pytest.mark.parametrize("mode", ["frozen", "auto_reset", "unfrozen"])
+def test_octet_rollout_matches_oracle_bit_exact(variant, n, agent_mode, target_mode, B, T, kw, mode, kernel):
+    """The 8-lanes-per-env rollout kernel (k_rollout_oct: lane t owns agent t and targets t, t + 8) against the oracle:
+    every reward / terminated / win of every step, observations and get_state rows at three steps, the raw fp64 state and
+    the canonical MT19937 rows at the end -- in two rollout calls of uneven length, so the state also survives the
+    kernel's epilogue / prologue (tape hand-over included)."""
+    args = _custom_args(variant, n_agents=n, agent_mode=agent_mode, target_mode=target_mode, **kw)
+    m = args.target_num
+    seeds = (4242 + 17 * np.arange(B)).astype(np.uint32)
+    env = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, freeze_done=(mode == "frozen"), auto_reset=(mode == "auto_reset"),
+                              kernel=kernel)
+    env.seed(seeds)
+    env.reset(init=True)
+    cfg = orc.make_config(variant=variant, n_agents=n, n_targets=m, agent_mode=args.agent_mode, target_mode=args.target_mode,
+                          map_size=args.map_size, view_range=args.view_range, time_limit=args.time_limit,
+                          velocity=float(args.agent_velocity), safe_dist=float(args.safe_dist),
+                          detect_prob=float(args.detect_prob), force_dist=float(args.force_dist))
+    a = np.random.RandomState(n * 1000 + B).randint(0, 3, size=(T, B, n)).astype(np.int32)
+    cut = 37
+    with orc.hip_equivalent_arithmetic():
+        ob = orc.OracleBatch(cfg, B, seeds)
+        ob.reset(init=True, threads=8)
+        t0 = 0
+        for part in (a[:cut], a[cut:]):
+            out = env.rollout(torch.from_numpy(part))
+            want = ob.rollout(part, auto_reset=(mode == "auto_reset"), freeze_done=(mode == "frozen"), threads=8)
+            np.testing.assert_array_equal(out["reward"].cpu().numpy(), want["reward"], err_msg=f"reward from step {t0}")
+            np.testing.assert_array_equal(out["terminated"].cpu().numpy().astype(np.uint8), want["terminated"])
+            np.testing.assert_array_equal(out["win"].cpu().numpy().astype(np.uint8), want["win"])
+            for t in (0, len(part) // 2, len(part) - 1):
+                np.testing.assert_allclose(out["obs"][t].cpu().numpy(), want["obs"][t], rtol=0, atol=F32_TOL)
+                np.testing.assert_allclose(out["state"][t].cpu().numpy(), want["state"][t], rtol=0, atol=F32_TOL)
+            compare_with_oracle(env, ob, B, n, m, f"{mode} after step {t0 + len(part)}")
+            t0 += len(part)
+    if mode == "auto_reset" and args.time_limit <= 200 and T > args.time_limit:
+        assert hdr(env)[:, _lib.H_EPISODES].min() >= 2
+
+
+@pytest.mark.parametrize("kernel", ["group", "solo", "duo", "lane", "oct"])
 def test_rollout_kernel_equals_stepwise(kernel):
     B, n, T = 1000, 3, 200   # not a multiple of 64: exercises the partial last wavefront
     args = cs.make_env_args("flight_easy", n_agents=n)
@@ -330,7 +386,7 @@ def test_group_and_lane_kernels_can_be_interleaved(n):
 @pytest.mark.parametrize("n,B,T", [(3, 4096, 260), (5, 16384, 230)])
 def test_full_size_rollout_matches_oracle(n, B, T):
     """BASELINE configs 2 / 3 at full size through the kernels the bench runs (c2: the wavefront-pair kernel, c3: the
-    one-wavefront kernel), auto-reset through at least one episode boundary per env: every reward, terminated and win
+    octet kernel), auto-reset through at least one episode boundary per env: every reward, terminated and win
     flag of every step, the emitted observation / state of the last step, and the full raw state against the oracle."""
     m = 15
     seeds = np.arange(B, dtype=np.uint32) + 20240000          # SURVEY 8(d): env seeds base 20240000
@@ -625,7 +681,7 @@ def test_flight_rollout_call_equals_stepwise(B, n, T):
         assert torch.equal(r1[k], r2[k]), k
 
 
-@pytest.mark.parametrize("kernel", ["group", "solo", "duo", "lane"])
+@pytest.mark.parametrize("kernel", ["group", "solo", "duo", "lane", "oct"])
 def test_long_horizon_matches_oracle(kernel):
     """20 000 steps per env with auto-reset: ~100+ episodes, the circular MT19937 state wraps ~70 times (cursor,
     mirrored head, reset-time batches landing anywhere in the ring).  Rewards are compared every step (in rollout

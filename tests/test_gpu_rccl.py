@@ -52,7 +52,7 @@ def test_rccl_world_size_one_all_gather_of_device_metric_partials():
     assert line["reduced"] == line["local"]
     assert line["librccl_mapped"] and line["coopsearch_mapped"]
     m = line["metrics"]
-    assert m["episodes"] == 4096 and 0.0 <= m["targets_find"] <= 15.0 and m["episode_reward"] < 0.0
+    assert m["episodes"] == 4096 and 0.0 <= m["targets_find"] <= 15.0 and -45.0 <= m["episode_reward"] <= 260.0
     assert 0.0 <= line["curve_last"] <= 100.0
 
 

@@ -35,4 +35,5 @@ with tempfile.TemporaryDirectory() as d:
             g = lambda key: int(re.search(r"\." + key + r":\s+(\d+)", blk).group(1))
             agpr = int(re.match(r":\s+(\d+)", blk).group(1))
             print(f"{dem:34s} vgpr {g('vgpr_count'):4d} agpr {agpr:3d} sgpr {g('sgpr_count'):4d} "
+                  f"sgpr_spill {g('sgpr_spill_count'):4d} vgpr_spill {g('vgpr_spill_count'):4d} "
                   f"scratch {g('private_segment_fixed_size'):5d} lds {g('group_segment_fixed_size'):6d}")
