@@ -16,7 +16,8 @@ Workloads (BASELINE.json configs):
 Modes:
     step     one cs_step launch per step (the closed-loop path a policy drives), replayed from a hipGraph
     rollout  cs_rollout over an open-loop action table, 100 steps per call (default).  flight_easy: up to 100 steps per
-             launch with the env resident in registers; flight: one launch per step in which the map sweep of step t and
+             launch with the env resident in registers (kernel by batch: k_rollout_od up to 16384 envs, k_rollout_oct
+             below 65536, k_rollout_lane from there); flight: one launch per step in which the map sweep of step t and
              the kinematics / detection of step t + 1 run side by side (k_flight_pipe)
 
 Timing protocol (one clock): after W warm-up steps, the K-step region -- bracketed by a barrier and
@@ -71,9 +72,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads reported under 'also'")
-    ap.add_argument("--kernel", default="auto", choices=["auto", "group", "solo", "duo", "oct", "lane"],
+    ap.add_argument("--kernel", default="auto", choices=["auto", "group", "solo", "duo", "od", "oct", "lane"],
                     help="flight_easy kernel: 16 lanes per env (solo / duo wavefront roles, or chosen by batch), 8 lanes per env "
-                         "(oct), one lane per env, or everything by batch size")
+                         "(od: kinematics + detection wavefront pair, oct: one wavefront), one lane per env, or everything by "
+                         "batch size (auto: od up to 16384 envs, oct below 65536, lane from there)")
     ap.add_argument("--min-gpu-s", type=float, default=MIN_GPU_S)
     ap.add_argument("--pg", default="auto", choices=["auto", "on", "off"],
                     help="process group at N = 1: 'on' = init_process_group('nccl') even for one rank and fail if RCCL does "
@@ -151,9 +153,11 @@ def kernel_label(env_name, n, B, mode, kernel):
         return f"k_rollout_lane<{n}>"
     if mode == "step":
         return f"k_step<{n},0>"
-    if kernel == "oct" or (kernel == "auto" and B > 4096):
+    if kernel == "od" or (kernel == "auto" and B <= 16384):      # CS_OD_UPTO
+        return f"k_rollout_od<{n}>"
+    if kernel == "oct" or kernel == "auto":                         # CS_OCT_FROM < B < CS_LANE_FROM
         return f"k_rollout_oct<{n}>"
-    duo = kernel == "duo" or (kernel in ("auto", "group") and n <= 6 and B <= 4096)
+    duo = kernel == "duo" or (kernel == "group" and n <= 6 and B <= 4096)
     return f"k_rollout_duo<{n}>" if duo else f"k_rollout<{n}>"
 
 

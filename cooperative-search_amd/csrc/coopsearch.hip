@@ -1187,7 +1187,7 @@ __device__ __forceinline__ void step_once(const DevParams &p, const double *T, c
         e.flags &= ~(FLAG_DIRTY | FLAG_RESET_PASS);  // pending-map-update flags describe THIS launch only
         if (done && (io.flags & CS_AUTO_RESET)) {
             const unsigned long long words_before = e.words;
-            env_reset<N, false>(p, T, b, t, gshift, 0, e);
+            env_reset<N, false>(cold_params(), T, b, t, gshift, 0, e);   // cold path: parameters read where they are needed
             if (VARIANT == 1) {  // flight: the map kernel must replay the reset-time update before this step's
                 e.newly_reset = e.newly;
                 e.flags |= FLAG_RESET_PASS;
@@ -1323,8 +1323,12 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(DevParams p, StepIO io) {
         int act_next[N];
         const int sn = s + 1 < io.T ? s + 1 : s;
         load_actions<N>(io, (size_t)sn * p.B + (live ? b : 0), act_next);
+        // (lane predicates -- t == i, t < n_targets ... -- are recomputed every step: hoisted out of the loop each of them is
+        // an SGPR pair the scalar file has no room for, and they came back as v_readlane pairs at every use)
+        int lane_s = lane;
+        asm volatile("" : "+v"(lane_s));
         // n <= 4: the rows of step s are stored while step s+1 computes (costs ~12 VGPRs; larger teams have none spare)
-        step_once<N, 0>(p, T, io, tile, b, lane, (size_t)s * p.B + wave_b0, plan, live, act, win, s + 1 < io.T,
+        step_once<N, 0>(p, T, io, tile, b, lane_s, (size_t)s * p.B + wave_b0, plan, live, act, win, s + 1 < io.T,
                         PIPE && s > 0, (size_t)(s - 1) * p.B + wave_b0, PIPE, e, tape, USE_TAPE, tape_ok);
 #pragma unroll
         for (int i = 0; i < N; i++) act[i] = act_next[i];
@@ -1384,7 +1388,8 @@ __global__ __launch_bounds__(DUO_BLOCK, 2) void k_rollout_duo(DevParams p, StepI
     const bool is_k = wave < DUO_PAIRS;
     DUO_MARK(63, is_k ? 3 : 13);   // entry
     const int pw = wave % DUO_PAIRS;             // wave pair = 4 envs
-    const int t = lane & (G - 1), grp = lane >> 4, gshift = lane & ~(G - 1);
+    int t = lane & (G - 1);   // (made opaque once per step: its predicates are recomputed instead of living in SGPR pairs)
+    const int grp = lane >> 4, gshift = lane & ~(G - 1);
     const int el = 4 * pw + grp;                 // env within the block
     const int b = blockIdx.x * DUO_ENVS + el;
     const bool live = b < p.B;
@@ -1462,6 +1467,7 @@ __global__ __launch_bounds__(DUO_BLOCK, 2) void k_rollout_duo(DevParams p, StepI
         produce(0, act);
         __syncthreads();
         for (int s = 0; s < io.T; s++) {
+            asm volatile("" : "+v"(t));
             const bool more = s + 1 < io.T;
             int act_after[N];
             DUO_STAMP(0);
@@ -1530,6 +1536,7 @@ __global__ __launch_bounds__(DUO_BLOCK, 2) void k_rollout_duo(DevParams p, StepI
     }
     __syncthreads();   // the ring holds step 0
     for (int s = 0; s < io.T; s++) {
+        asm volatile("" : "+v"(t));
         const size_t slot0 = (size_t)s * p.B + wave_b0;
         int reward = 0;
         bool term = true, mispredicted = false;
@@ -1544,8 +1551,9 @@ __global__ __launch_bounds__(DUO_BLOCK, 2) void k_rollout_duo(DevParams p, StepI
             e.flags &= ~(FLAG_DIRTY | FLAG_RESET_PASS);
             if (done && auto_reset) {
                 const unsigned long long words_before = e.words;
-                env_reset<N, false>(p, T, b, t, gshift, 0, e);
-                reinterpret_cast<double2 *>(p.tgt + (size_t)b * G * 2)[t] = make_double2(e.tx, e.ty);
+                const DevParams &cp = cold_params();
+                env_reset<N, false>(cp, T, b, t, gshift, 0, e);
+                reinterpret_cast<double2 *>(cp.tgt + (size_t)b * G * 2)[t] = make_double2(e.tx, e.ty);
                 const unsigned long long used = e.words - words_before;   // its draw slots leave the tape
                 tape_shift<8>(tape, used < 2ull * 319ull ? (int)(used >> 1) : 319);
                 drain_vmem();
@@ -1858,8 +1866,11 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io
 #ifndef CS_LANE_FROM
 #define CS_LANE_FROM 65536      /* default kernel of cs_rollout / cs_step from this many envs: one env per lane */
 #endif
+#ifndef CS_OD_UPTO
+#define CS_OD_UPTO 16384        /* cs_rollout up to this many envs: the octet pair kernel */
+#endif
 #ifndef CS_OCT_FROM
-#define CS_OCT_FROM 4096        /* cs_rollout above this many envs (and below CS_LANE_FROM): one env per 8 lanes */
+#define CS_OCT_FROM 16384       /* cs_rollout above this many envs (and below CS_LANE_FROM): one env per 8 lanes, one wavefront */
 #endif
 constexpr int LANE_REFILL = 192;   // words twisted per refill (<= 227: independent of each other)
 constexpr int LANE_REFILL_MAX = 192;
@@ -2105,7 +2116,8 @@ __global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO i
     double *T = reinterpret_cast<double *>(smem);                                   // trig table (2072 B)
     const int W = 4 * N + 3 * p.n_targets;
     float *tiles = reinterpret_cast<float *>(smem + ((TRIG_ROWS * TRIG_COLS * 8 + 15) / 16) * 16);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int lane = threadIdx.x & 63;   // (made opaque once per step, see the loop)
+    const int wave = threadIdx.x >> 6;
     float *tile = tiles + (size_t)wave * 64 * W;
     float *row = tile + (size_t)lane * W;   // W is odd for m = 15: conflict-free column accesses
     const int b = io.env0 + blockIdx.x * BLOCK + threadIdx.x;
@@ -2165,6 +2177,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO i
     };
     bool flushed = true;   // VEC: the tile holds no step that still has to be written out
     for (int s = 0; s < io.T; s++) {
+        asm volatile("" : "+v"(lane));   // lane predicates are recomputed per step instead of being held (and spilled) as SGPR pairs
         const size_t slot = (size_t)s * p.B + arow;
         LANE_STAMP(0);
         bool done = live && (e.target_find >= p.n_targets || e.time_step >= p.time_limit);
@@ -2197,8 +2210,9 @@ __global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO i
                 g.tx = g.ty = 0.0;
                 if (src >= 0) {
                     const int br = b0 + src;
-                    env_reset<N, false>(p, T, br, t16, gshift, 0, g);
-                    reinterpret_cast<double2 *>(p.tgt + (size_t)br * G * 2)[t16] = make_double2(g.tx, g.ty);
+                    const DevParams &cp = cold_params();
+                    env_reset<N, false>(cp, T, br, t16, gshift, 0, g);
+                    reinterpret_cast<double2 *>(cp.tgt + (size_t)br * G * 2)[t16] = make_double2(g.tx, g.ty);
                     if (t16 < p.n_targets) {
                         float *rs = tile + (size_t)src * W + 4 * N + 3 * t16;
                         rs[0] = g.ntx;
@@ -2577,9 +2591,10 @@ struct OctKin {   // one lane's agent during the kinematics of a step
 // later stages.  The two fp64 divisions run only if SOME env of the wavefront has such a neighbour in this stage.
 template <int N, int I>
 struct OctStage {
-    static __device__ __forceinline__ void run(const DevParams &p, const OctShared &sh, int o, int t, bool act_lane, OctKin &k) {
+    static __device__ __forceinline__ void run(const DevParams &p, const double2 (*pos)[OCT_PAD], int o, int t, bool act_lane,
+                                               OctKin &k) {
         if constexpr (I < N) {
-            const double2 pi = sh.pos[o][I];   // agent I's position BEFORE its move (sh.pos is rewritten after the loop)
+            const double2 pi = pos[o][I];   // agent I's position BEFORE its move (the array is rewritten after the loop)
             const double xi = pi.x, yi = pi.y;
             const double dx = k.cx - xi, dy = k.cy - yi;
             const bool inr = act_lane & (t != I) & (dx * dx + dy * dy < p.force_d2) & ((k.cx != xi) | (k.cy != yi));
@@ -2603,7 +2618,7 @@ struct OctStage {
                 k.cy = k.yf;
                 k.hit = k.hitf;
             }
-            OctStage<N, I + 1>::run(p, sh, o, t, act_lane, k);
+            OctStage<N, I + 1>::run(p, pos, o, t, act_lane, k);
         }
     }
 };
@@ -2611,8 +2626,8 @@ struct OctStage {
 // Kinematics of one step for the octet's env (flight_env_easy.py:255-301); `act` = this lane's agent's action.
 // Returns the octet's out_flag bits.  Lanes t >= N hold no agent and take no part in any decision.
 template <int N>
-__device__ __forceinline__ unsigned oct_kinematics(const DevParams &p, const double *T, const OctShared &sh, int o, int t, int sh8,
-                                                   bool stepping, int act, EnvO<N> &e) {
+__device__ __forceinline__ unsigned oct_kinematics(const DevParams &p, const double *T, const double2 (*pos)[OCT_PAD], int o, int t,
+                                                   int sh8, bool stepping, int act, EnvO<N> &e) {
     const double PI = 3.141592653589793, TWO_PI = 2.0 * 3.141592653589793, THREE_PI = 3.0 * 3.141592653589793;
     const double DYAW = 3.141592653589793 / 18.0;
     const bool upd = (t < N) & stepping;
@@ -2627,7 +2642,32 @@ __device__ __forceinline__ unsigned oct_kinematics(const DevParams &p, const dou
     const double xt = (e.x + p.velocity * c1) + 0.0, yt = (e.y + p.velocity * s1) + 0.0;
     const bool hitf = (xt < 0.0) | (xt > p.L) | (yt < 0.0) | (yt > p.L);    // flight_env_easy.py:278
     OctKin k{e.x, e.y, c1, s1, hitf ? fmin(fmax(xt, 0.0), p.L) : xt, hitf ? fmin(fmax(yt, 0.0), p.L) : yt, hitf, false};
-    OctStage<N, 0>::run(p, sh, o, t, upd, k);
+    // Would the reference find ANY neighbour within force_dist in this step, in any env of the wavefront?  Every ordered
+    // pair (I, this lane's agent) is tested the way stage I would test it if no force had been applied before it: this
+    // agent's position is its zero-repulsion move if it precedes I (quirk Q7), else its old one.  If no pair is in range
+    // the reference's loop adds f = 0 everywhere and every agent's move IS the zero-repulsion one -- one ballot instead of
+    // one per stage (3 agents: ~3 wavefront-steps in 4); otherwise the stages run, exactly.
+    // (measured, pair kernel: 3 agents -2 % per step, 5 agents +5 %: with 40 agents per wavefront some pair is nearly always
+    // in range and the pre-test is pure overhead -- so only small teams take it)
+#ifndef CS_OCT_FASTPATH_MAX_N
+#define CS_OCT_FASTPATH_MAX_N 3
+#endif
+    constexpr bool FASTPATH = N <= CS_OCT_FASTPATH_MAX_N;
+    bool any_pair = !FASTPATH;
+#pragma unroll
+    for (int I = 0; I < (FASTPATH ? N : 0); I++) {
+        const double2 pi = pos[o][I];
+        const double qx = t < I ? k.xf : e.x, qy = t < I ? k.yf : e.y;
+        const double dx = qx - pi.x, dy = qy - pi.y;
+        any_pair = any_pair | ((t != I) & (dx * dx + dy * dy < p.force_d2) & ((qx != pi.x) | (qy != pi.y)));
+    }
+    if (__ballot(any_pair & upd)) {
+        OctStage<N, 0>::run(p, pos, o, t, upd, k);
+    } else {
+        k.cx = k.xf;
+        k.cy = k.yf;
+        k.hit = k.hitf;
+    }
     e.x = upd ? k.cx : e.x;
     e.y = upd ? k.cy : e.y;
     e.yaw = upd ? (k.hit ? yr : yw) : e.yaw;
@@ -2639,7 +2679,7 @@ __device__ __forceinline__ unsigned oct_kinematics(const DevParams &p, const dou
 // Detection pass + reward (flight_env_easy.py:223-253) for the octet's env on the positions in sh.pos; draws from the hit
 // tape, which the caller guarantees to cover a step's worst case.  Returns curr_reward.
 template <int N>
-__device__ __forceinline__ int oct_detect(const DevParams &p, const OctShared &sh, int o, int t, int sh8, bool stepping,
+__device__ __forceinline__ int oct_detect(const DevParams &p, const double2 (*pos)[OCT_PAD], int o, int t, int sh8, bool stepping,
                                           EnvO<N> &e, unsigned (&tape)[TAPE_DW]) {
     constexpr int MAXDW = (N * CS_MAX_TARGETS) / 32 < 1 ? 1 : (N * CS_MAX_TARGETS) / 32;   // draws of one pass, in dwords
     const bool has0 = stepping & (t < p.n_targets), has1 = stepping & (t + OG < p.n_targets);
@@ -2649,7 +2689,7 @@ __device__ __forceinline__ int oct_detect(const DevParams &p, const OctShared &s
     const unsigned below0 = (1u << t) - 1u, below1 = (1u << (t + OG)) - 1u;
 #pragma unroll
     for (int i = 0; i < N; i++) {
-        const double2 a = sh.pos[o][i];
+        const double2 a = pos[o][i];
         const double dx0 = e.tx[0] - a.x, dy0 = e.ty[0] - a.y, dx1 = e.tx[1] - a.x, dy1 = e.ty[1] - a.y;
         inr0[i] = has0 & (dx0 * dx0 + dy0 * dy0 <= p.view_r2);   // (t_x-x)**2 + (t_y-y)**2 <= view_range**2
         inr1[i] = has1 & (dx1 * dx1 + dy1 * dy1 <= p.view_r2);
@@ -2699,7 +2739,8 @@ __device__ __forceinline__ int oct_detect(const DevParams &p, const OctShared &s
 // The wavefront tops up the MT19937 rows of those of its 8 envs that have fewer than `min_ahead` twisted words left or no
 // matching tape -- whole wavefront on one row at a time, like group_wave_advance -- and hands the new tape to the env's
 // octet by ballot.
-template <int N>
+// DRAIN: end with nothing of its own in flight (callers whose steady-state loop waits for loads, see drain_vmem).
+template <int N, bool DRAIN = true>
 __device__ __forceinline__ void oct_wave_advance(const DevParams &p, int wave_b0, int nvalid, int lane, int min_ahead,
                                                  unsigned *rowbuf, EnvO<N> &e, unsigned (&tape)[TAPE_DW], bool &tape_ok) {
     const int o = lane >> 3;
@@ -2726,7 +2767,7 @@ __device__ __forceinline__ void oct_wave_advance(const DevParams &p, int wave_b0
             tape_ok = true;
         }
     }
-    drain_vmem();
+    if (DRAIN) drain_vmem();
 }
 
 // VEC: every wavefront of the launch is full and every step's block of get_state rows is 16-byte aligned (the host splits a
@@ -2734,6 +2775,31 @@ __device__ __forceinline__ void oct_wave_advance(const DevParams &p, int wave_b0
 // store of a step is unconditional, the number of stores between the action prefetch and its use is a compile-time constant
 // and the wait for the actions never waits for a store (with the stores behind `if (io.obs)` the compiler has to assume
 // the shortest path and waits for the first stores of the step to be acknowledged: +0.4 us per step).
+
+// Second half of an ASYNCHRONOUS row refresh (octet pair kernel, D): the row of env `g` of the wavefront was requested a
+// step ago (row_load into `rr`); it is twisted ahead of the env's cursor in LDS, the new words go back to the state blob,
+// and the env's octet receives its new hit tape.  Same work as oct_wave_advance for one env, minus the wait for the row.
+template <int N>
+__device__ __forceinline__ void oct_advance_finish(const DevParams &p, int wave_b0, int g, int lane, const RowRegs &rr,
+                                                   unsigned *rowbuf, EnvO<N> &e, unsigned (&tape)[TAPE_DW], bool &tape_ok) {
+    const int o = lane >> 3;
+    row_to_lds(rr, rowbuf, lane);
+    const int pos = __shfl(e.mt_pos, OG * g), a = __shfl(e.ahead, OG * g);
+    row_twist_ahead(rowbuf, p.mt + (size_t)(wave_b0 + g) * MT_STRIDE, pos, a < 0 ? 0 : a, lane);
+#pragma unroll
+    for (int it = 0; it < TAPE_DW / 2; it++) {
+        const unsigned long long bm = row_slot_hits(p, rowbuf, pos, it, lane);
+        if (o == g) {
+            tape[2 * it] = (unsigned)(bm & 0xffffffffull);
+            tape[2 * it + 1] = (unsigned)(bm >> 32);
+        }
+    }
+    if (o == g) {
+        e.ahead = MT_N;
+        tape_ok = true;
+    }
+}
+
 template <int N, bool VEC, bool EMIT>
 __global__ __launch_bounds__(OCT_BLOCK, CS_OCT_WAVES) void k_rollout_oct(DevParams p, StepIO io) {
     __shared__ double T[TRIG_ROWS * TRIG_COLS];
@@ -2929,7 +2995,7 @@ __global__ __launch_bounds__(OCT_BLOCK, CS_OCT_WAVES) void k_rollout_oct(DevPara
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            oct_detect<N>(p, sh, o, t, sh8, mine, e, tape);
+            oct_detect<N>(p, sh.pos, o, t, sh8, mine, e, tape);
             put_found();
             done = done && !mine;
             if (__ballot(live && e.ahead < LOW)) oct_wave_advance<N>(cp, wave_b0, nvalid, lane, LOW, sh.rowbuf, e, tape, tape_ok);
@@ -2937,7 +3003,7 @@ __global__ __launch_bounds__(OCT_BLOCK, CS_OCT_WAVES) void k_rollout_oct(DevPara
         const bool stepping = live && !(done && freeze);
         OCT_STAMP(1);
         // ---- kinematics -> positions, obs floats, out flags
-        const unsigned out = oct_kinematics<N>(p, T, sh, o, t, sh8, stepping, act, e);
+        const unsigned out = oct_kinematics<N>(p, T, sh.pos, o, t, sh8, stepping, act, e);
         OCT_STAMP(2);
         if (stepping) e.flags = (e.flags & ~0xff00) | (int)(out << 8);
         sh.pos[o][t] = make_double2(e.x, e.y);
@@ -2947,7 +3013,7 @@ __global__ __launch_bounds__(OCT_BLOCK, CS_OCT_WAVES) void k_rollout_oct(DevPara
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // ---- detection, reward, termination
         OCT_STAMP(3);
-        const int reward = oct_detect<N>(p, sh, o, t, sh8, stepping, e, tape);
+        const int reward = oct_detect<N>(p, sh.pos, o, t, sh8, stepping, e, tape);
         OCT_STAMP(4);
         bool term = true;
         if (stepping) {
@@ -3023,6 +3089,440 @@ __global__ __launch_bounds__(OCT_BLOCK, CS_OCT_WAVES) void k_rollout_oct(DevPara
             cp.ahead[b] = e.ahead;
         }
         if (ag) reinterpret_cast<double4 *>(cp.agent + (size_t)b * CS_MAX_AGENTS * 4)[t] = make_double4(e.x, e.y, e.yaw, 0.0);
+        if (tape_ok) {
+            U4 *tp = reinterpret_cast<U4 *>(cp.tape + (size_t)b * TAPE_STRIDE);
+            if (t == 0) tp[0] = U4{tape[0], tape[1], tape[2], tape[3]};
+            if (t == 1) tp[1] = U4{tape[4], tape[5], tape[6], tape[7]};
+            if (t == 2) tp[2] = U4{tape[8], tape[9], (unsigned)(e.words & 0xffffffffull), (unsigned)(e.words >> 32)};
+            if (t == 3) tp[3] = U4{(unsigned)(cp.detect_K & 0xffffffffull), (unsigned)(cp.detect_K >> 32), 0u, 0u};
+        }
+    }
+}
+
+// =========================================================================================================
+// Octet pair (flight_easy): the octet layout with the TWO ROLES of the pair kernel -- per 8 envs a kinematics
+// wavefront K and a detection wavefront D, one pair per workgroup, one workgroup barrier per step.
+//
+// In the octet kernel one wavefront walks the whole dependent chain of a step -- kinematics (~1800 cycles for 3 agents),
+// then detection + reward + rows (~1500) -- and at the batch sizes where every SIMD holds at most one or two wavefronts
+// nothing fills its stalls.  As in k_rollout_duo, the kinematics of step s + 1 need nothing from the detection pass of
+// step s (the actions are an open-loop table; the only coupling is a termination K cannot predict from the step counter:
+// an env finding its last target), so K runs one step ahead and leaves each step's positions in a two-slot LDS ring; D
+// consumes them.  The step time drops to max(K, D), and a batch gets twice the wavefronts: 4096 envs fill all 1024 SIMDs
+// (the octet kernel: half of them).  Roles:
+//   K  lane t owns agent t: trig, the repulsion stages (OctStage), wall rule; keeps the team's current positions in its
+//      own LDS array (kpos), publishes (x, y, yaw, cos, sin, out flags) per step; predicts resets / freezes from the step
+//      counter; after the barrier it redoes step s + 1 for the envs D flagged (restored from the ring).
+//   D  lane t owns targets t, t + 8, the env's header and its hit tape: sensor tests on the ring's positions, draws,
+//      reward, termination, the persistent get_state rows and every output store; resets (target placement on the 16-lane
+//      code, reset-time pass) and row top-ups.
+// Arithmetic per env is the octet kernel's (same functions), so results are bit-identical.
+// =========================================================================================================
+#ifndef CS_OD_WAVES
+#define CS_OD_WAVES 4
+#endif
+constexpr int OD_BLOCK = 128;
+
+struct __attribute__((aligned(16))) OdRing {   // what K hands to D for one step
+    double2 pos[OCT_ENVS][OCT_PAD];
+    double yaw[OCT_ENVS][CS_MAX_AGENTS];
+    float2 cssn[OCT_ENVS][CS_MAX_AGENTS];
+    unsigned out[OCT_ENVS];
+    unsigned pad[OCT_ENVS];
+};
+struct __attribute__((aligned(16))) OdShared {
+    OdRing ring[2];
+    double2 kpos[OCT_ENVS][OCT_PAD];        // K: the team's current positions (the "old" ones of its next step)
+    double2 dpos[OCT_ENVS][OCT_PAD];        // D: start poses for the reset-time detection pass
+    double2 tgt[OCT_ENVS][CS_MAX_TARGETS];  // D: reset hand-over (16-lane group -> octet)
+    float tile[OCT_ENVS * TILE_W];
+    float reward[OCT_ENVS];
+    int term[OCT_ENVS], win[OCT_ENVS];
+    unsigned fix[2];                         // [step parity]: envs (bit o) whose termination K mispredicted
+    unsigned rowbuf[MT_N];
+};
+
+template <int N, bool VEC, bool EMIT>
+__global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams p, StepIO io) {
+    __shared__ double T[TRIG_ROWS * TRIG_COLS];
+    __shared__ OdShared sh;
+    const int lane = threadIdx.x & 63;
+    const bool is_k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0;
+    const int o = lane >> 3, sh8 = lane & ~(OG - 1);
+    int t = lane & (OG - 1);   // (made opaque once per step: lane predicates are recomputed, not held in SGPR pairs)
+    const int wave_b0 = io.env0 + blockIdx.x * OCT_ENVS;
+    const int b_end = io.env0 + io.env_n;
+    const int b = wave_b0 + o;
+    const bool live = VEC || b < b_end;
+    const int nvalid = b_end - wave_b0 < OCT_ENVS ? b_end - wave_b0 : OCT_ENVS;   // >= 1: the grid covers env_n exactly
+    const int W = 4 * N + 3 * p.n_targets;
+    bool ag = t < N;
+    const bool auto_reset = io.flags & CS_AUTO_RESET, freeze = io.flags & CS_FREEZE_DONE;
+    const size_t bl = live ? (size_t)b : (size_t)io.env0;
+    EnvO<N> e;
+    {
+        const int4 *h4 = reinterpret_cast<const int4 *>(p.hdr + bl * CS_H_WORDS);
+        const int4 h0 = h4[0], h1 = h4[1], h2 = h4[2];
+        e.found = (unsigned)h0.x;
+        e.newly = (unsigned)h0.y;
+        e.target_find = h0.z;
+        e.flags = h0.w;
+        e.time_step = h1.x;
+        e.total_reward = h1.y;
+        e.mt_pos = h1.z;
+        e.episodes = h1.w;
+        e.words = (unsigned long long)(unsigned)h2.x | ((unsigned long long)(unsigned)h2.y << 32);
+        e.curr_reward = h2.z;
+        e.newly_reset = (unsigned)h2.w;
+    }
+    if (!live) {   // a lane without an env never steps, resets or asks for a top-up
+        e.target_find = 0;
+        e.time_step = 0;
+    }
+
+    if (is_k) {
+        // ------------------------------------------------------------------------------------------ K: kinematics
+        {
+            const double4 a = reinterpret_cast<const double4 *>(p.agent + bl * CS_MAX_AGENTS * 4)[t];
+            e.x = a.x;
+            e.y = a.y;
+            e.yaw = a.z;
+        }
+        const int aidx = ag ? t : N - 1;   // lanes without an agent repeat the last agent's (valid) address
+        const int astride = (io.flags & CS_ACTIONS_I64) ? 2 : 1;
+        const int *ap = reinterpret_cast<const int *>(io.actions) + (bl * N + aidx) * astride;   // this lane's action of step 0
+        const size_t astep = (size_t)p.B * N * astride;
+        int act = ap[0];
+        if (io.T > 1) ap += astep;
+        int act_next = ap[0];   // one step ahead of its use
+        if (io.T > 2) ap += astep;
+        load_trig_to_lds(T);
+        trig_heading(T, e.yaw, e.sn, e.cs);   // what a frozen env keeps emitting
+        sh.kpos[o][t] = make_double2(e.x, e.y);
+        bool k_done = live && (e.target_find >= p.n_targets || e.time_step >= p.time_limit);   // exact at launch
+        int k_time = e.time_step;
+        unsigned k_out = ((unsigned)e.flags >> 8) & 0xffu;
+        // the state after step `sp` from the state after step sp - 1, for the octets in `sel`, into ring slot sp & 1
+        auto produce = [&](int sp, int a, bool sel) __attribute__((always_inline)) {
+            const bool rs = sel && live && k_done && auto_reset;   // predicted reset (flight_env_easy.py:139-180: start poses)
+            if (__ballot(rs)) {
+                if (rs) {
+                    start_pose<N>(cold_params(), ag ? t : 0, e.x, e.y, e.yaw);
+                    sh.kpos[o][t] = make_double2(e.x, e.y);
+                    k_out = 0u;
+                    k_time = 0;
+                    k_done = false;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            const bool stepping = sel && live && !(k_done && freeze);
+            const unsigned out = oct_kinematics<N>(p, T, sh.kpos, o, t, sh8, stepping, a, e);
+            if (stepping) {
+                k_out = out;
+                k_time += 1;
+                k_done = k_time >= p.time_limit;   // a win is D's knowledge: see the fix-up below
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();   // every lane has read the old positions
+            OdRing &r = sh.ring[sp & 1];
+            if (sel) {
+                const double2 xy = make_double2(e.x, e.y);
+                sh.kpos[o][t] = xy;
+                r.pos[o][t] = xy;
+                r.yaw[o][t] = e.yaw;
+                r.cssn[o][t] = make_float2((float)e.cs, (float)e.sn);
+                if (t == 0) r.out[o] = k_out;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+        produce(0, act, true);
+        __syncthreads();   // the ring holds step 0
+        for (int s = 0; s < io.T; s++) {
+            asm volatile("" : "+v"(t));
+            ag = t < N;
+            const bool more = s + 1 < io.T;
+            DUO_STAMP(0);
+            const int act_after = ap[0];
+            if (s + 3 < io.T) ap += astep;
+            if (more) produce(s + 1, act_next, true);
+            DUO_STAMP(1);
+            __syncthreads();   // D has consumed step s (and left its flags), step s + 1 is in the ring
+            DUO_STAMP(2);
+            const unsigned f = sh.fix[s & 1];
+            if (f) {   // block-uniform, rare: an env terminated by finding its last target
+                if (more) {
+                    const bool mine = live && ((f >> o) & 1u);
+                    if (mine) {   // the env as it was after step s
+                        const OdRing &r = sh.ring[s & 1];
+                        const double2 xy = r.pos[o][t];
+                        e.x = xy.x;
+                        e.y = xy.y;
+                        e.yaw = r.yaw[o][t];
+                        trig_heading(T, e.yaw, e.sn, e.cs);
+                        sh.kpos[o][t] = xy;
+                        k_out = r.out[o];
+                        k_done = true;
+                        k_time -= 1;   // the speculative step s + 1 is undone (a frozen env never gets here)
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    produce(s + 1, act_next, mine);
+                }
+                __syncthreads();
+            }
+            act_next = act_after;
+        }
+        if (live && ag)   // agents are K's part of the state
+            reinterpret_cast<double4 *>(cold_params().agent + (size_t)b * CS_MAX_AGENTS * 4)[t] = make_double4(e.x, e.y, e.yaw, 0.0);
+        return;
+    }
+
+    // ---------------------------------------------------------------------------------------------- D: detection
+    e.ahead = live ? p.ahead[bl] : (1 << 20);
+    {
+        const double2 *t2 = reinterpret_cast<const double2 *>(p.tgt + bl * G * 2);
+        const double2 ta = t2[t], tb = t2[t + OG];
+        e.tx[0] = ta.x;
+        e.ty[0] = ta.y;
+        e.tx[1] = tb.x;
+        e.ty[1] = tb.y;
+    }
+    const TapeRaw traw = tape_fetch(p, (int)bl);
+    load_trig_to_lds(T);   // (K's table; D only joins its barrier)
+    unsigned tape[TAPE_DW];
+    bool tape_ok = tape_finish(p, traw, e, tape) || !live;
+    float *row = sh.tile + o * W;
+    auto put_found = [&]() __attribute__((always_inline)) {
+        if (t < p.n_targets) row[4 * N + 3 * t + 2] = ((e.found >> t) & 1u) ? 1.0f : 0.0f;
+        if (t + OG < p.n_targets) row[4 * N + 3 * (t + OG) + 2] = ((e.found >> (t + OG)) & 1u) ? 1.0f : 0.0f;
+    };
+    if (t < p.n_targets) {
+        row[4 * N + 3 * t + 0] = (float)((e.tx[0] - p.mid) * p.inv_half);   // norm_target
+        row[4 * N + 3 * t + 1] = (float)((e.ty[0] - p.mid) * p.inv_half);
+    }
+    if (t + OG < p.n_targets) {
+        row[4 * N + 3 * (t + OG) + 0] = (float)((e.tx[1] - p.mid) * p.inv_half);
+        row[4 * N + 3 * (t + OG) + 1] = (float)((e.ty[1] - p.mid) * p.inv_half);
+    }
+    put_found();
+    if (lane == 0) sh.fix[0] = sh.fix[1] = 0u;
+    constexpr int LOW = 2 * N * CS_MAX_TARGETS;   // words one step can consume
+    // A row that is about to run out of twisted words is topped up in place.  (CS_OD_ASYNC: requested at the end of a step
+    // for ONE env that is running low, twisted and re-taped at the top of the next step, when the row has long arrived.)
+    // D's steady-state loop waits for no load, so none of these paths needs to end drained (-4 % per step at 4096 envs).
+#ifndef CS_OD_ASYNC
+#define CS_OD_ASYNC 0   /* measured SLOWER (3 agents, 4096 envs: 2.06 against 1.92 us per step; 5 agents, 8192: 3.49 against 3.07):
+                           the ten row registers held across the step push the 128-VGPR kernel into hot-path spills, and the
+                           request's ballot runs every step; the code stays for the next register budget */
+#endif
+#ifndef CS_OD_DRAIN
+#define CS_OD_DRAIN 0
+#endif
+    constexpr int REQ = CS_OD_ASYNC ? LOW + (LOW > 96 ? LOW : 96) : 0;
+    RowRegs rr;
+    int cand = -1;   // env (octet) of the wavefront whose row is in flight in `rr`
+    oct_wave_advance<N, CS_OD_DRAIN != 0>(p, wave_b0, nvalid, lane, io.min_ahead > LOW ? io.min_ahead : LOW, sh.rowbuf, e, tape, tape_ok);   // while K produces step 0
+    // ---- write-out plan (loop invariant)
+    const int rows_valid = nvalid;
+    constexpr int W_MAX = 4 * N + 3 * CS_MAX_TARGETS;
+    constexpr int Q = (OCT_ENVS * W_MAX / 4 + 63) / 64;   // float4 chunks per lane of the largest tile
+    const int ol = lane < rows_valid * N ? lane : rows_valid * N - 1;
+    const int orow = ol / N, oag = ol - orow * N;
+    const int obs_lds = orow * W + 4 * oag;
+    const int rtw = (lane & 7) < rows_valid ? (lane & 7) : rows_valid - 1;
+    const int t16 = lane & (G - 1), gshift16 = lane & ~(G - 1), grp = lane >> 4;
+    float *p_rew = io.reward + wave_b0 + rtw;
+    uint8_t *p_term = io.terminated + wave_b0 + rtw, *p_win = io.win + wave_b0 + rtw;
+    v4f *p_obs = reinterpret_cast<v4f *>(io.obs + (size_t)wave_b0 * N * 4) + ol;
+    v4f *p_st = reinterpret_cast<v4f *>(io.state + (size_t)wave_b0 * W);
+    int chunk[Q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) chunk[q] = lane + 64 * q < OCT_ENVS * W / 4 - 1 ? lane + 64 * q : OCT_ENVS * W / 4 - 1;
+    __syncthreads();   // the ring holds step 0
+    for (int s = 0; s < io.T; s++) {
+        asm volatile("" : "+v"(t));
+        ag = t < N;
+        DUO_STAMP(8);
+        if (__builtin_expect(cand >= 0, 0)) {   // wave-uniform: the row requested a step ago
+            oct_advance_finish<N>(cold_params(), wave_b0, cand, lane, rr, sh.rowbuf, e, tape, tape_ok);
+            cand = -1;
+        }
+        if (__builtin_expect(__ballot(live && e.ahead < LOW) != 0ull, 0))   // could not wait for its turn
+            oct_wave_advance<N, CS_OD_DRAIN != 0>(cold_params(), wave_b0, nvalid, lane, LOW, sh.rowbuf, e, tape, tape_ok);
+        bool done = e.target_find >= p.n_targets || e.time_step >= p.time_limit;
+        e.flags &= ~(FLAG_DIRTY | FLAG_RESET_PASS);
+        // ---- auto-reset: target placement on the 16-lane code (one resetting env per 16-lane group and round), then the
+        //      reset-time detection pass (quirk Q3) on the start poses
+        const unsigned long long need = __ballot(live && done && auto_reset && t == 0);   // bit 8 o'
+        if (__builtin_expect(need != 0ull, 0)) {
+            const DevParams &cp = cold_params();
+            const bool mine = (need >> sh8) & 1ull;
+            const int my_rank = __popcll(need & ((1ull << sh8) - 1ull));
+            unsigned long long pend = need;
+            for (int round = 0; pend; round++) {
+                unsigned long long m = pend;
+                for (int q = 0; q < grp; q++) m &= m ? m - 1 : 0ull;   // this group's env: the grp-th pending one
+                const int src = m ? __ffsll((long long)m) - 1 : -1;
+                for (int q = 0; q < 4; q++) pend &= pend ? pend - 1 : 0ull;
+                const int sl = src >= 0 ? src : lane;
+                int g_pos = __shfl(e.mt_pos, sl), g_ahead = __shfl(e.ahead, sl);
+                unsigned long long g_words = (unsigned long long)(unsigned)__shfl((int)(unsigned)(e.words & 0xffffffffull), sl) |
+                                             ((unsigned long long)(unsigned)__shfl((int)(unsigned)(e.words >> 32), sl) << 32);
+                if (src >= 0) {
+                    const int so = src >> 3, br = wave_b0 + so;
+                    double gx, gy;
+                    reset_targets(cp, cp.mt + (size_t)br * MT_STRIDE, t16, gshift16, g_pos, g_words, g_ahead, gx, gy);
+                    reinterpret_cast<double2 *>(cp.tgt + (size_t)br * G * 2)[t16] = make_double2(gx, gy);
+                    sh.tgt[so][t16] = make_double2(gx, gy);
+                    if (t16 < cp.n_targets) {
+                        float *rs = sh.tile + so * W + 4 * N + 3 * t16;
+                        rs[0] = (float)((gx - cp.mid) * cp.inv_half);   // norm_target
+                        rs[1] = (float)((gy - cp.mid) * cp.inv_half);
+                        rs[2] = 0.0f;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int q = my_rank - 4 * round;
+                const bool got = mine && q >= 0 && q < 4;
+                const int leader = got ? 16 * q : lane;
+                const int r_pos = __shfl(g_pos, leader), r_ahead = __shfl(g_ahead, leader);
+                const int r_wlo = __shfl((int)(unsigned)(g_words & 0xffffffffull), leader);
+                const int r_whi = __shfl((int)(unsigned)(g_words >> 32), leader);
+                if (got) {
+                    const unsigned long long w_new = (unsigned long long)(unsigned)r_wlo | ((unsigned long long)(unsigned)r_whi << 32);
+                    const unsigned long long used = w_new - e.words;   // its draw slots leave the tape
+                    tape_shift<8>(tape, used < 2ull * 319ull ? (int)(used >> 1) : 319);
+                    e.mt_pos = r_pos;
+                    e.ahead = r_ahead;
+                    e.words = w_new;
+                    e.episodes += 1;
+                    e.found = 0;
+                    e.newly = 0;
+                    e.target_find = 0;
+                    e.time_step = 0;
+                    e.total_reward = 0;
+                    e.flags = 0;
+                    const double2 ta = sh.tgt[o][t], tb = sh.tgt[o][t + OG];
+                    e.tx[0] = ta.x;
+                    e.ty[0] = ta.y;
+                    e.tx[1] = tb.x;
+                    e.ty[1] = tb.y;
+                    double sx, sy, syaw;
+                    start_pose<N>(cp, ag ? t : 0, sx, sy, syaw);
+                    sh.dpos[o][t] = make_double2(sx, sy);
+                }
+            }
+            if (__ballot(live && e.ahead < LOW)) oct_wave_advance<N, CS_OD_DRAIN != 0>(cp, wave_b0, nvalid, lane, LOW, sh.rowbuf, e, tape, tape_ok);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            oct_detect<N>(p, sh.dpos, o, t, sh8, mine, e, tape);
+            put_found();
+            done = done && !mine;
+            if (__ballot(live && e.ahead < LOW)) oct_wave_advance<N, CS_OD_DRAIN != 0>(cp, wave_b0, nvalid, lane, LOW, sh.rowbuf, e, tape, tape_ok);
+        }
+        const bool stepping = live && !(done && freeze);
+        DUO_STAMP(9);
+        // ---- K's step s: out flags, the agents' four floats (get_obs / get_state), positions for the sensor tests
+        const OdRing &r = sh.ring[s & 1];
+        if (live) e.flags = (e.flags & ~0xff00) | (int)(r.out[o] << 8);
+        if (ag) {
+            const double2 xy = r.pos[o][t];
+            const float2 cs = r.cssn[o][t];
+            row[4 * t + 0] = (float)((xy.x - p.mid) * p.inv_half);
+            row[4 * t + 1] = (float)((xy.y - p.mid) * p.inv_half);
+            row[4 * t + 2] = cs.x;
+            row[4 * t + 3] = cs.y;
+        }
+        const int reward = oct_detect<N>(p, r.pos, o, t, sh8, stepping, e, tape);
+        DUO_STAMP(10);
+        bool term = true, mispredicted = false;
+        if (stepping) {
+            e.total_reward += reward;
+            e.time_step += 1;
+            term = e.target_find >= p.n_targets || e.time_step >= p.time_limit;
+            mispredicted = (auto_reset || freeze) && term && e.time_step < p.time_limit;   // K steps on unless the counter says otherwise
+        }
+        {
+            const unsigned long long mb = __ballot(mispredicted && t == 0);
+            unsigned m8 = 0;
+#pragma unroll
+            for (int q = 0; q < OCT_ENVS; q++) m8 |= (unsigned)((mb >> (OG * q)) & 1ull) << q;
+            if (lane == 0) sh.fix[s & 1] = m8;
+        }
+        if (__ballot(stepping && e.newly != 0u)) put_found();   // wave-uniform: some env found a target in this step
+        if (t == 0) {
+            sh.reward[o] = (float)reward;
+            sh.term[o] = term ? 1 : 0;
+            sh.win[o] = (e.flags & FLAG_WIN) ? 1 : 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- this step's outputs (all LDS reads first, then the stores)
+        const float o_rew = sh.reward[rtw];   // duplicates write the same value
+        const int o_term = sh.term[rtw], o_win = sh.win[rtw];
+        v4f o_obs = {0.f, 0.f, 0.f, 0.f}, o_st[Q];
+        if (EMIT || io.obs) {
+            const float *src = sh.tile + obs_lds;
+            o_obs = v4f{src[0], src[1], src[2], src[3]};
+        }
+        if (VEC && (EMIT || io.state)) {
+            const float4 *src4 = reinterpret_cast<const float4 *>(sh.tile);
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                const float4 v = src4[chunk[q]];
+                o_st[q] = v4f{v.x, v.y, v.z, v.w};
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (CS_OD_ASYNC) {   // request next step's refresh (before this step's stores): the env running lowest, if any is below REQ
+            const unsigned long long lowb = __ballot(live && e.ahead < REQ && t == 0);
+            cand = lowb ? __builtin_amdgcn_readfirstlane((__ffsll((long long)lowb) - 1) >> 3) : -1;
+            if (__builtin_expect(cand >= 0, 0)) row_load(cold_params().mt + (size_t)(wave_b0 + cand) * MT_STRIDE, lane, rr);
+        }
+        *p_rew = o_rew;
+        *p_term = (uint8_t)o_term;
+        *p_win = (uint8_t)o_win;
+        p_rew += p.B;
+        p_term += p.B;
+        p_win += p.B;
+        if (EMIT || io.obs) {   // one float4 per (env, agent)
+            __builtin_nontemporal_store(o_obs, p_obs);
+            p_obs += (size_t)p.B * N;
+        }
+        if (EMIT || io.state) {
+            if (VEC) {
+#pragma unroll
+                for (int q = 0; q < Q; q++) __builtin_nontemporal_store(o_st[q], p_st + chunk[q]);
+                p_st += (size_t)p.B * W / 4;
+            } else {
+                float *dst = io.state + ((size_t)s * p.B + wave_b0) * W;
+                for (int k = lane; k < rows_valid * W; k += 64) dst[k] = sh.tile[k];
+            }
+        }
+        DUO_STAMP(11);
+        __syncthreads();
+        DUO_STAMP(12);
+        if (sh.fix[s & 1]) __syncthreads();   // K redoes step s + 1 of the flagged envs
+    }
+    if (live) {   // header, cursor and tape are D's part of the state; targets were stored at each reset
+        const DevParams &cp = cold_params();
+        if (t == 0) {
+            int4 *h4 = reinterpret_cast<int4 *>(cp.hdr + (size_t)b * CS_H_WORDS);
+            h4[0] = make_int4((int)e.found, (int)e.newly, e.target_find, e.flags);
+            h4[1] = make_int4(e.time_step, e.total_reward, e.mt_pos, e.episodes);
+            h4[2] = make_int4((int)(unsigned)(e.words & 0xffffffffull), (int)(unsigned)(e.words >> 32), e.curr_reward,
+                              (int)e.newly_reset);
+            cp.ahead[b] = e.ahead;
+        }
         if (tape_ok) {
             U4 *tp = reinterpret_cast<U4 *>(cp.tape + (size_t)b * TAPE_STRIDE);
             if (t == 0) tp[0] = U4{tape[0], tape[1], tape[2], tape[3]};
@@ -3590,20 +4090,46 @@ void launch_oct(const cs_config *cfg, const DevParams &p, StepIO io, hipStream_t
         hipLaunchKernelGGL((k_rollout_oct<N, false, false>), dim3((unsigned)((p.B - full + EPB - 1) / EPB)), dim3(OCT_BLOCK), 0, s, p, io);
     }
 }
+// Octet-pair launch(es): like launch_oct, one workgroup (K + D wavefront) per 8 envs.
+template <int N>
+void launch_od(const cs_config *cfg, const DevParams &p, StepIO io, hipStream_t s) {
+    const size_t W = 4 * (size_t)cfg->n_agents + 3 * (size_t)cfg->n_targets;
+    const bool aligned = !io.state || ((reinterpret_cast<size_t>(io.state) & 15) == 0 && ((size_t)p.B * W) % 4 == 0);
+    const int full = aligned ? (p.B / OCT_ENVS) * OCT_ENVS : 0;
+    io.min_ahead = 2 * cfg->n_agents * CS_MAX_TARGETS;  // rows are topped up in place whenever one runs low
+    if (full > 0) {
+        io.env0 = 0;
+        io.env_n = full;
+        const dim3 grid((unsigned)(full / OCT_ENVS));
+        if (io.obs && io.state) hipLaunchKernelGGL((k_rollout_od<N, true, true>), grid, dim3(OD_BLOCK), 0, s, p, io);
+        else hipLaunchKernelGGL((k_rollout_od<N, true, false>), grid, dim3(OD_BLOCK), 0, s, p, io);
+    }
+    if (p.B - full > 0) {   // the tail (or an unaligned output tensor): plain stores, runtime checks
+        io.env0 = full;
+        io.env_n = p.B - full;
+        hipLaunchKernelGGL((k_rollout_od<N, false, false>), dim3((unsigned)((p.B - full + OCT_ENVS - 1) / OCT_ENVS)), dim3(OD_BLOCK), 0, s, p, io);
+    }
+}
 // Kernel choice for flight_easy: one env per 16-lane group (lowest latency, fills the chip from B = 4096) or one
 // env per lane (no replicated arithmetic; wins once the batch gives every SIMD a wavefront anyway).
 inline bool use_lane_kernel(const cs_config *c, int flags, bool rollout) {
     if (flags & CS_KERNEL_LANE) return true;
     if (flags & CS_KERNEL_GROUP) return false;
-    if (rollout && (flags & CS_KERNEL_OCT)) return false;
+    if (rollout && (flags & (CS_KERNEL_OCT | CS_KERNEL_OD))) return false;
     // single steps have no octet variant: the lane kernel takes over from the 16-lane step kernel at 32768 envs as before
     return c->batch >= (rollout ? CS_LANE_FROM : 32768);
 }
 // cs_rollout: the octet kernel (one env per 8 lanes) between the pair kernel's range and the lane kernel's
 inline bool use_oct_kernel(const cs_config *c, int flags) {
     if (flags & CS_KERNEL_OCT) return true;
-    if (flags & (CS_KERNEL_GROUP | CS_KERNEL_LANE | CS_KERNEL_SOLO | CS_KERNEL_DUO)) return false;
+    if (flags & (CS_KERNEL_GROUP | CS_KERNEL_LANE | CS_KERNEL_SOLO | CS_KERNEL_DUO | CS_KERNEL_OD)) return false;
     return c->batch > CS_OCT_FROM && c->batch < CS_LANE_FROM;
+}
+// cs_rollout: the octet PAIR kernel (kinematics wavefront + detection wavefront per 8 envs)
+inline bool use_od_kernel(const cs_config *c, int flags) {
+    if (flags & CS_KERNEL_OD) return true;
+    if (flags & (CS_KERNEL_GROUP | CS_KERNEL_LANE | CS_KERNEL_SOLO | CS_KERNEL_DUO | CS_KERNEL_OCT)) return false;
+    return c->batch <= CS_OD_UPTO;
 }
 
 // 16-lanes-per-env rollout: the kinematics / detection wavefront pair pays while its two wavefronts per four envs still
@@ -3778,7 +4304,9 @@ int cs_rollout(const cs_config *cfg, void *state_dev, const void *actions_dev, i
         return launched("cs_rollout");
     }
     StepIO io{actions_dev, reward_dev, terminated_dev, win_dev, obs_dev, state_out_dev, flags, T};
-    if (use_oct_kernel(cfg, flags)) {
+    if (use_od_kernel(cfg, flags)) {
+        CS_DISPATCH_N(cfg->n_agents, launch_od<N>(cfg, p, io, (hipStream_t)stream));
+    } else if (use_oct_kernel(cfg, flags)) {
         CS_DISPATCH_N(cfg->n_agents, launch_oct<N>(cfg, p, io, (hipStream_t)stream));
     } else if (use_lane_kernel(cfg, flags, true)) {
         // LANE_CHUNK steps per launch; before each chunk every env's MT19937 row is twisted fully ahead of its cursor by

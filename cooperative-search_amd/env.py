@@ -69,10 +69,11 @@ class BatchedFlightEnv:
     kernel      flight_easy only: "group" (16 lanes per env: lowest step latency, fills the chip from B = 4096; its
                 rollout picks between "solo" -- one wavefront per four envs does the whole step -- and "duo" -- a
                 kinematics wavefront and a detection wavefront per four envs, for batches that leave a wave slot per
-                SIMD empty), "oct" (rollout only: 8 lanes per env, lane t owns agent t and targets t, t + 8 -- the
-                mid-batch kernel), "lane" (one env per lane: no replicated arithmetic, for large batches) or "auto"
-                (rollout: pair kernel up to 4096 envs, octet kernel above, lane kernel from 32768).  All produce
-                bit-identical results.
+                SIMD empty), "oct" (rollout only: 8 lanes per env, lane t owns agent t and targets t, t + 8), "od"
+                (rollout only: the octet layout with a kinematics wavefront running one step ahead of a detection
+                wavefront), "lane" (one env per lane: no replicated arithmetic, for large batches) or "auto" (rollout:
+                "od" up to 16384 envs, "oct" below 65536, "lane" from there; single steps: the 16-lane step kernel,
+                "lane" from 32768).  All produce bit-identical results.
     step_advance  step(): refresh the hit tapes every STEP_ADVANCE_EVERY single steps (default).  False leaves every
                 MT19937 word to be twisted on demand by the step kernel itself -- same results, one more dependent load per
                 launch.
@@ -133,8 +134,8 @@ class BatchedFlightEnv:
             self._state = torch.zeros(B, self.state_shape, dtype=torch.float32, device=self.device)
             self._avail = torch.ones(B, self.n_actions, dtype=torch.float32, device=self.device)
             self._metrics = torch.zeros(4, dtype=torch.float64, device=self.device)
-        if kernel not in ("auto", "group", "lane", "solo", "duo", "oct"):
-            raise ValueError("kernel must be 'auto', 'group', 'lane', 'solo', 'duo' or 'oct'")
+        if kernel not in ("auto", "group", "lane", "solo", "duo", "oct", "od"):
+            raise ValueError("kernel must be 'auto', 'group', 'lane', 'solo', 'duo', 'oct' or 'od'")
         self.kernel = kernel
         self.freeze_done = bool(freeze_done)
         self.auto_reset = bool(auto_reset)
@@ -264,6 +265,8 @@ class BatchedFlightEnv:
             f |= _lib.KERNEL_LANE
         elif self.kernel == "oct":   # rollout(): 8 lanes per env; step() has no octet variant and uses the 16-lane kernel
             f |= _lib.KERNEL_OCT
+        elif self.kernel == "od":    # rollout(): the octet layout, kinematics and detection wavefronts pipelined
+            f |= _lib.KERNEL_OD
         return f
 
     def step(self, actions, out=None):

@@ -65,9 +65,11 @@ enum {
     CS_KERNEL_SOLO = 32, /* cs_rollout, 16-lanes-per-env path: one wavefront per four envs does the whole step */
     CS_KERNEL_DUO = 64,  /* ... a kinematics wavefront and a detection wavefront per four envs (default up to 4096 envs
                             of at most 6 agents, where the batch leaves a wave slot per SIMD empty); same results */
-    CS_KERNEL_OCT = 128  /* cs_rollout, flight_easy: force the 8-lanes-per-env kernel (lane t owns agent t and targets t, t + 8;
+    CS_KERNEL_OCT = 128, /* cs_rollout, flight_easy: force the 8-lanes-per-env kernel (lane t owns agent t and targets t, t + 8;
                             nothing replicated but the header: four and more wavefronts per SIMD -- the default between
                             the pair kernel's range and the lane kernel's); same results */
+    CS_KERNEL_OD = 256   /* cs_rollout, flight_easy: force the octet PAIR kernel (the 8-lane layout with a kinematics wavefront
+                            running one step ahead of a detection wavefront, per 8 envs); same results */
 };
 
 /* Environment constants: common/arguments.py:27-34 (map_size, target_num, target_mode, agent_mode, n_agents,

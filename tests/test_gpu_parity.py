@@ -273,7 +273,7 @@ def test_flight_fused_auto_reset_matches_oracle(n, agent_mode):
         assert hdr(env)[:, _lib.H_EPISODES].min() >= 4
 
 
-@pytest.mark.parametrize("kernel", ["oct"])
+@pytest.mark.parametrize("kernel", ["oct", "od"])
 @pytest.mark.parametrize("variant,n,agent_mode,target_mode,B,T,kw", [
     ("flight_easy", 3, 0, 0, 509, 230, {}),                    # 509 = 63 full octet wavefronts' worth + a tail of 5 envs
     ("flight_easy", 5, 0, 0, 256, 230, {}),
@@ -293,7 +293,8 @@ def test_flight_fused_auto_reset_matches_oracle(n, agent_mode):
 ])
 @pytest.mark.parametrize("mode", ["frozen", "auto_reset", "unfrozen"])
 def test_octet_rollout_matches_oracle_bit_exact(variant, n, agent_mode, target_mode, B, T, kw, mode, kernel):
-    """The 8-lanes-per-env rollout kernel (k_rollout_oct: lane t owns agent t and targets t, t + 8) against the oracle:
+    """The 8-lanes-per-env rollout kernels (k_rollout_oct: lane t owns agent t and targets t, t + 8; k_rollout_od: the same
+    layout with a kinematics wavefront running one step ahead of a detection wavefront) against the oracle:
     every reward / terminated / win of every step, observations and get_state rows at three steps, the raw fp64 state and
     the canonical MT19937 rows at the end -- in two rollout calls of uneven length, so the state also survives the
     kernel's epilogue / prologue (tape hand-over included)."""
@@ -329,7 +330,7 @@ def test_octet_rollout_matches_oracle_bit_exact(variant, n, agent_mode, target_m
         assert hdr(env)[:, _lib.H_EPISODES].min() >= 2
 
 
-@pytest.mark.parametrize("kernel", ["group", "solo", "duo", "lane", "oct"])
+@pytest.mark.parametrize("kernel", ["group", "solo", "duo", "lane", "oct", "od"])
 def test_rollout_kernel_equals_stepwise(kernel):
     B, n, T = 1000, 3, 200   # not a multiple of 64: exercises the partial last wavefront
     args = cs.make_env_args("flight_easy", n_agents=n)
@@ -681,7 +682,7 @@ def test_flight_rollout_call_equals_stepwise(B, n, T):
         assert torch.equal(r1[k], r2[k]), k
 
 
-@pytest.mark.parametrize("kernel", ["group", "solo", "duo", "lane", "oct"])
+@pytest.mark.parametrize("kernel", ["group", "solo", "duo", "lane", "oct", "od"])
 def test_long_horizon_matches_oracle(kernel):
     """20 000 steps per env with auto-reset: ~100+ episodes, the circular MT19937 state wraps ~70 times (cursor,
     mirrored head, reset-time batches landing anywhere in the ring).  Rewards are compared every step (in rollout

@@ -1,0 +1,20 @@
+"""Debug: per-stage cycle counts of workgroup 0 of k_rollout_od (library built with -DCS_TIMELINE).  env: N, B."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import cooperative_search_amd as cs
+n, B, T = int(os.environ.get("N", 3)), int(os.environ.get("B", 4096)), 64
+env = cs.BatchedFlightEnv(cs.make_env_args("flight_easy", n_agents=n), batch=B, freeze_done=False, auto_reset=True, kernel="od")
+acts = torch.randint(0, 3, (T, B, n), dtype=torch.int32, device="cuda")
+out = env.rollout(acts); out = env.rollout(acts, out=out, update_views=False)
+torch.cuda.synchronize()
+L = cs.lib.load()
+buf = (C.c_ulonglong * (64 * 16))()
+L.cs_debug_read_stamps.argtypes = [C.c_void_p]
+assert L.cs_debug_read_stamps(buf) == 0
+st = np.frombuffer(buf, dtype=np.uint64).reshape(64, 16).astype(np.int64)
+med = lambda a: int(np.median(a[5:60]))
+print(f"k_rollout_od<{n}> B={B}, workgroup 0, median cycles over steps 5..60")
+print("  K: produce(s+1)", med(st[:, 1] - st[:, 0]), " wait at barrier", med(st[:, 2] - st[:, 1]), " step-to-step", med(st[1:, 0] - st[:-1, 0]))
+print("  D: top-up/reset", med(st[:, 9] - st[:, 8]), " ring+detect", med(st[:, 10] - st[:, 9]), " flags+rows+stores", med(st[:, 11] - st[:, 10]),
+      " wait at barrier", med(st[:, 12] - st[:, 11]), " step-to-step", med(st[1:, 8] - st[:-1, 8]))

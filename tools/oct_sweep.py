@@ -25,7 +25,7 @@ dev = torch.device("cuda", 0)
 for n in [int(v) for v in a.n.split(",")]:
     for B in [int(v) for v in a.batches.split(",")]:
         for kernel in a.kernels.split(","):
-            if kernel in ("duo", "solo") and B > 65536:
+            if kernel in ("duo", "solo", "od") and B > 65536:
                 continue
             env = cs.BatchedFlightEnv(cs.make_env_args("flight_easy", n_agents=n), batch=B, device=dev, freeze_done=False,
                                       auto_reset=True, kernel=kernel)
