@@ -17,7 +17,7 @@ Modes:
     step     one cs_step launch per step (the closed-loop path a policy drives), replayed from a hipGraph
     rollout  cs_rollout over an open-loop action table, 100 steps per call (default).  flight_easy: up to 100 steps per
              launch with the env resident in registers (kernel by batch: k_rollout_od up to 16384 envs, k_rollout_oct
-             below 65536, k_rollout_lane from there); flight: one launch per step in which the map sweep of step t and
+             below 131072, k_rollout_lane from there); flight: one launch per step in which the map sweep of step t and
              the kinematics / detection of step t + 1 run side by side (k_flight_pipe)
 
 Timing protocol (one clock): after W warm-up steps, the K-step region -- bracketed by a barrier and
@@ -75,7 +75,7 @@ def parse_args(argv=None):
     ap.add_argument("--kernel", default="auto", choices=["auto", "group", "solo", "duo", "od", "oct", "lane"],
                     help="flight_easy kernel: 16 lanes per env (solo / duo wavefront roles, or chosen by batch), 8 lanes per env "
                          "(od: kinematics + detection wavefront pair, oct: one wavefront), one lane per env, or everything by "
-                         "batch size (auto: od up to 16384 envs, oct below 65536, lane from there)")
+                         "batch size (auto: od up to 16384 envs, oct below 131072, lane from there)")
     ap.add_argument("--min-gpu-s", type=float, default=MIN_GPU_S)
     ap.add_argument("--pg", default="auto", choices=["auto", "on", "off"],
                     help="process group at N = 1: 'on' = init_process_group('nccl') even for one rank and fail if RCCL does "
@@ -145,7 +145,7 @@ def largest_divisor_leq(k, cap):
 
 def kernel_label(env_name, n, B, mode, kernel):
     """The kernel cs_step / cs_rollout dispatches to (csrc/coopsearch.hip: use_lane_kernel, duo_pays)."""
-    lane_from = 65536 if mode == "rollout" else 32768   # CS_LANE_FROM (rollout); single steps: 32768
+    lane_from = 131072 if mode == "rollout" else 32768   # CS_LANE_FROM (rollout); single steps: 32768
     lane = env_name == "flight_easy" and (kernel == "lane" or (kernel == "auto" and B >= lane_from))
     if env_name == "flight":   # rollout call: step t + 1 rides inside the map sweep of step t, one launch per step
         return f"k_flight_pipe<{n}>" if mode == "rollout" else f"k_step<{n},1> + k_map<{n}>"
@@ -325,27 +325,30 @@ def run_workload(cs, dev, comm, env_name, n, B, mode, K, W, kernel, rank=0, no_g
             obs=torch.empty(S, B, n, env.obs_width, dtype=torch.float32, device=dev),
             state=torch.empty(S, B, env.state_shape, dtype=torch.float32, device=dev))
 
-        def chunk():
+        def chunk_eager():
             env.rollout(acts, out=out, update_views=False)
     else:
         def chunk_eager():
             for s in range(S):
                 env.step(acts[s])
-        if no_graph:
-            chunk = chunk_eager
-        else:
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
-                chunk_eager()
-            torch.cuda.current_stream(dev).wait_stream(side)
-            torch.cuda.synchronize(dev)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                chunk_eager()
+    if no_graph or mode == "rollout":
+        # rollout mode: one cs_rollout call per chunk, launched directly.  (Replaying it from a hipGraph was measured: the
+        # graph launch costs MORE than the plain launch it replaces -- 58.7 against 52.2 us per 20-step region at c2.)
+        chunk = chunk_eager
+    else:
+        # step mode: the S cs_step (+ cs_mt_advance) launches of a chunk captured once and replayed
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            chunk_eager()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            chunk_eager()
 
-            def chunk():
-                graph.replay()
+        def chunk():
+            graph.replay()
     for _ in range(max(1, math.ceil(W / S))):
         chunk()
 
@@ -473,6 +476,7 @@ def main():
     import numpy as np  # noqa: F401  (oracle / env import it; fail early if missing)
     import torch
 
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -480,6 +484,21 @@ def main():
         raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
     if a.dry_run:
         return dry_run(a, rank, world)
+    # Exactly ONE line goes to stdout: native libraries write there too (RCCL prints its version banner through C stdio
+    # when the first communicator comes up, and the buffer is flushed at exit -- AFTER the JSON line).  From here on file
+    # descriptor 1 is stderr; the JSON line is written to the saved descriptor at the very end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit_line(obj):
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:   # noqa: BLE001
+            pass
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
     # BENCH_SHARE_GPU=1 (tests only): all ranks use cuda:0 and the gloo backend, to exercise the N > 1 control flow on
@@ -579,6 +598,12 @@ def main():
                                  "flight_easy", 3, 4096, "step", 2000, 200, "auto"),
                 side_measurement(cs, dev, comm, "c3 flight_easy 5a15t B=16384", "flight_easy", 5, 16384, "rollout",
                                  1000, 100, "auto"),
+                side_measurement(cs, dev, comm, "flight_easy 3a15t B=16384 (the 8192..65536 valley of round 2)", "flight_easy", 3,
+                                 16384, "rollout", 1000, 100, "auto"),
+                side_measurement(cs, dev, comm, "flight_easy 3a15t B=32768 (one-wavefront octet kernel)", "flight_easy", 3,
+                                 32768, "rollout", 400, 100, "auto"),
+                side_measurement(cs, dev, comm, "flight_easy 5a15t B=32768 (one-wavefront octet kernel)", "flight_easy", 5,
+                                 32768, "rollout", 400, 100, "auto"),
                 side_measurement(cs, dev, comm, "c4 flight 3a15t B=8192, cs_step per step (hipGraph): k_step then k_map",
                                  "flight", 3, 8192, "step", 400, 100, "auto"),
                 side_measurement(cs, dev, comm, "c4 flight 3a15t B=8192 (cs_rollout: sweep of step t beside step t + 1)",
@@ -596,7 +621,7 @@ def main():
             line["also"] = also
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(env_name, n, B)
-        print(json.dumps(line), flush=True)
+        emit_line(line)
     if pg:
         dist.barrier()
         dist.destroy_process_group()

@@ -117,13 +117,15 @@ struct AttemptBatch {
     double u1, u2;  // np.random.rand() #2l and #2l+1 of the batch
 
     // `ahead` = words at `pos` that are already twisted (their stored value IS the new word)
-    __device__ __forceinline__ void generate(const unsigned *mt, int pos, int l, int ahead) {
+    // use_pre (group-uniform; only with ahead >= 4 * G): the batch's words were fetched ahead of time into pre[0..3]
+    __device__ __forceinline__ void generate(const unsigned *mt, int pos, int l, int ahead, bool use_pre = false,
+                                             const unsigned *pre = nullptr) {
         const int i0 = wrap624(pos + 4 * l);
         unsigned tw[4];
         if (ahead >= 4 * G) {   // group-uniform, the usual case: the whole batch was twisted ahead of time
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                nw[q] = mt[wrap624(i0 + q)];
+                nw[q] = use_pre ? pre[q] : mt[wrap624(i0 + q)];
                 tw[q] = mt_temper(nw[q]);
             }
         } else {
@@ -865,8 +867,10 @@ __device__ __forceinline__ void start_pose(const DevParams &p, int i, double &x,
 // Target placement of a reset (flight_env_easy.py:95-134) for the env whose 16-lane group this is: lane t gets target t's
 // position in (mx, my); the env's MT19937 cursor / word count / pre-twisted count advance by what the reference's
 // sequential algorithm consumes.  No agent state involved: the octet kernel calls this alone.
+// use_pre: the first batch's four stream words (per lane) were prefetched into pre[] (octet pair kernel).
 __device__ __forceinline__ void reset_targets(const DevParams &p, unsigned *mt, int t, int gshift, int &mt_pos,
-                                              unsigned long long &words_total, int &ahead, double &mx, double &my) {
+                                              unsigned long long &words_total, int &ahead, double &mx, double &my,
+                                              bool use_pre = false, const unsigned *pre = nullptr) {
     const unsigned tmask = p.n_targets >= 32 ? ~0u : ((1u << p.n_targets) - 1u);
     mx = 0.0;
     my = 0.0;
@@ -889,7 +893,7 @@ __device__ __forceinline__ void reset_targets(const DevParams &p, unsigned *mt, 
         int taken = 0;
         while (taken < need_total) {  // group-uniform; one batch suffices ~99 % of the time for 9 jittered targets
             AttemptBatch ab;
-            ab.generate(mt, mt_pos, t, ahead);
+            ab.generate(mt, mt_pos, t, ahead, use_pre && taken == 0, pre);
             const double x1 = 2.0 * ab.u1 - 1.0, x2 = 2.0 * ab.u2 - 1.0;
             const double r2 = x1 * x1 + x2 * x2;
             const bool accept = !(r2 >= 1.0 || r2 == 0.0);
@@ -917,7 +921,7 @@ __device__ __forceinline__ void reset_targets(const DevParams &p, unsigned *mt, 
     } else {
         // x, y = map_size*np.random.rand() per target, flight_env_easy.py:122-127
         AttemptBatch ab;
-        ab.generate(mt, mt_pos, t, ahead);
+        ab.generate(mt, mt_pos, t, ahead, use_pre, pre);
         mx = p.L * ab.u1;
         my = p.L * ab.u2;
         const int words = 4 * p.n_targets;
@@ -1005,7 +1009,11 @@ __device__ int g_tl_step_dummy;
 #define DUO_STAMP(k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && s < 64) g_stamps[s][k] = __builtin_readcyclecounter(); } while (0)
 #define DUO_MARK(row, k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_stamps[row][k] = __builtin_readcyclecounter(); } while (0)
 #define OCT_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && s < 64) g_stamps[s][k] = __builtin_readcyclecounter(); } while (0)
+#define KIN_STAMP(k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && tl_step >= 0 && tl_step < 64) g_stamps[tl_step][k] = __builtin_readcyclecounter(); } while (0)
+#define KIN_STAMP_SP(k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && sp >= 1 && sp <= 64) g_stamps[sp - 1][k] = __builtin_readcyclecounter(); } while (0)
 #else
+#define KIN_STAMP(k) do {} while (0)
+#define KIN_STAMP_SP(k) do {} while (0)
 #define OCT_STAMP(k) do {} while (0)
 #define DUO_STAMP(k) do {} while (0)
 #define DUO_MARK(row, k) do {} while (0)
@@ -1864,7 +1872,8 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io
 #define CS_LANE_REFRESH_MAX_N 5   /* measured at B = 262144: 4 agents 29.9 -> 34-38 %, 5 agents 23.5 -> 28 % */
 #endif
 #ifndef CS_LANE_FROM
-#define CS_LANE_FROM 65536      /* default kernel of cs_rollout / cs_step from this many envs: one env per lane */
+#define CS_LANE_FROM 131072     /* default kernel of cs_rollout from this many envs: one env per lane (65536: octet 7.6e9
+                                   against lane 7.1e9 env-steps/s at 3 agents, 5.0e9 against 4.8e9 at 5; 262144: 8.0 / 10.4) */
 #endif
 #ifndef CS_OD_UPTO
 #define CS_OD_UPTO 16384        /* cs_rollout up to this many envs: the octet pair kernel */
@@ -1964,8 +1973,10 @@ __device__ __forceinline__ void kinematics_lane(const DevParams &p, const double
         yaw = act[i] == 1 ? yaw + DYAW : (act[i] == 2 ? yaw + -DYAW : yaw);  // dyaw = [0, pi/18, -pi/18][act]
         yaw = yaw > TWO_PI ? yaw - TWO_PI : (yaw < 0.0 ? yaw + TWO_PI : yaw);
         yw[i] = yaw;
-        trig_heading(T, yaw, s1[i], c1[i]);
         yr[i] = (yaw <= PI) ? PI - yaw : THREE_PI - yaw;
+        // (evaluating the 2n headings branch-free in one basic block so that their chains interleave was
+        // measured: 39.1 -> 39.1 % at 2^18 envs, 41.7 -> 42.2 % at 2^20, for 32 more VGPRs: not kept here)
+        trig_heading(T, yaw, s1[i], c1[i]);
         trig_heading(T, yr[i], s2[i], c2[i]);
     }
     unsigned out = 0;
@@ -2470,7 +2481,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO i
 //     row, when an env is about to run out of twisted words.
 // ~45 persistent VGPRs per lane instead of ~130: four and more wavefronts per SIMD, i.e. 32768+ envs in one resident
 // round, and per-env arithmetic that is exactly the 16-lane kernels' (same functions / same expression order), so
-// the results are bit-identical (tests/test_gpu_parity.py runs all kernels against the oracle and each other).
+// the results are bit-identical (tests/test_gpu_parity.py compares every kernel with the CPU restatement of the reference and with every other kernel).
 // =========================================================================================================
 #ifndef CS_OCT_WAVES
 #define CS_OCT_WAVES 3                     /* wavefronts per SIMD the register budget must allow (168 VGPRs): measured 2 / 3 / 4,
@@ -2627,7 +2638,7 @@ struct OctStage {
 // Returns the octet's out_flag bits.  Lanes t >= N hold no agent and take no part in any decision.
 template <int N>
 __device__ __forceinline__ unsigned oct_kinematics(const DevParams &p, const double *T, const double2 (*pos)[OCT_PAD], int o, int t,
-                                                   int sh8, bool stepping, int act, EnvO<N> &e) {
+                                                   int sh8, bool stepping, int act, EnvO<N> &e, int tl_step = -1) {
     const double PI = 3.141592653589793, TWO_PI = 2.0 * 3.141592653589793, THREE_PI = 3.0 * 3.141592653589793;
     const double DYAW = 3.141592653589793 / 18.0;
     const bool upd = (t < N) & stepping;
@@ -2636,7 +2647,9 @@ __device__ __forceinline__ unsigned oct_kinematics(const DevParams &p, const dou
     yaw = yaw > TWO_PI ? yaw - TWO_PI : (yaw < 0.0 ? yaw + TWO_PI : yaw);
     const double yw = yaw, yr = (yaw <= PI) ? PI - yaw : THREE_PI - yaw;
     double s1, c1, s2, c2;
+    KIN_STAMP(3);
     trig_heading_pair(T, yw, yr, s1, c1, s2, c2);
+    KIN_STAMP(4);
     // the move every agent makes unless a neighbour is within force_dist: (x + v*cos) + 0.0 -- the "+ 0.0" so that even
     // signed zeros agree with the reference's `x += force[0]`
     const double xt = (e.x + p.velocity * c1) + 0.0, yt = (e.y + p.velocity * s1) + 0.0;
@@ -2668,6 +2681,7 @@ __device__ __forceinline__ unsigned oct_kinematics(const DevParams &p, const dou
         k.cy = k.yf;
         k.hit = k.hitf;
     }
+    KIN_STAMP(5);
     e.x = upd ? k.cx : e.x;
     e.y = upd ? k.cy : e.y;
     e.yaw = upd ? (k.hit ? yr : yw) : e.yaw;
@@ -2777,13 +2791,13 @@ __device__ __forceinline__ void oct_wave_advance(const DevParams &p, int wave_b0
 // the shortest path and waits for the first stores of the step to be acknowledged: +0.4 us per step).
 
 // Second half of an ASYNCHRONOUS row refresh (octet pair kernel, D): the row of env `g` of the wavefront was requested a
-// step ago (row_load into `rr`); it is twisted ahead of the env's cursor in LDS, the new words go back to the state blob,
-// and the env's octet receives its new hit tape.  Same work as oct_wave_advance for one env, minus the wait for the row.
+// step ago straight into `rowbuf` (global_load_lds) and has arrived (the caller waited for it); it is twisted ahead of the
+// env's cursor in LDS, the new words go back to the state blob, and the env's octet receives its new hit tape.  Same work
+// as oct_wave_advance for one env, minus the wait for the row.
 template <int N>
-__device__ __forceinline__ void oct_advance_finish(const DevParams &p, int wave_b0, int g, int lane, const RowRegs &rr,
-                                                   unsigned *rowbuf, EnvO<N> &e, unsigned (&tape)[TAPE_DW], bool &tape_ok) {
+__device__ __forceinline__ void oct_advance_finish(const DevParams &p, int wave_b0, int g, int lane, unsigned *rowbuf,
+                                                   EnvO<N> &e, unsigned (&tape)[TAPE_DW], bool &tape_ok) {
     const int o = lane >> 3;
-    row_to_lds(rr, rowbuf, lane);
     const int pos = __shfl(e.mt_pos, OG * g), a = __shfl(e.ahead, OG * g);
     row_twist_ahead(rowbuf, p.mt + (size_t)(wave_b0 + g) * MT_STRIDE, pos, a < 0 ? 0 : a, lane);
 #pragma unroll
@@ -3139,7 +3153,8 @@ struct __attribute__((aligned(16))) OdShared {
     float reward[OCT_ENVS];
     int term[OCT_ENVS], win[OCT_ENVS];
     unsigned fix[2];                         // [step parity]: envs (bit o) whose termination K mispredicted
-    unsigned rowbuf[MT_N];
+    unsigned rowbuf[MT_N + 16];              // one MT19937 row (+ the 16 words lanes 48..63 of the tenth dword column land on)
+    unsigned prebuf[4 * 64];                 // [q][lane]: the first attempt batch of the resets due at the next step
 };
 
 template <int N, bool VEC, bool EMIT>
@@ -3218,7 +3233,8 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
             const bool stepping = sel && live && !(k_done && freeze);
-            const unsigned out = oct_kinematics<N>(p, T, sh.kpos, o, t, sh8, stepping, a, e);
+            const unsigned out = oct_kinematics<N>(p, T, sh.kpos, o, t, sh8, stepping, a, e, sp - 1);
+            KIN_STAMP_SP(6);
             if (stepping) {
                 k_out = out;
                 k_time += 1;
@@ -3312,20 +3328,23 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
     put_found();
     if (lane == 0) sh.fix[0] = sh.fix[1] = 0u;
     constexpr int LOW = 2 * N * CS_MAX_TARGETS;   // words one step can consume
-    // A row that is about to run out of twisted words is topped up in place.  (CS_OD_ASYNC: requested at the end of a step
-    // for ONE env that is running low, twisted and re-taped at the top of the next step, when the row has long arrived.)
+    // Rare events stall the whole pair (K waits at the barrier), and what they cost is mostly ONE dependent round trip to
+    // memory: the MT19937 row of a top-up, the stream words of a reset's attempt batch.  Both are known a step ahead -- an
+    // env running low on twisted words; an env whose step just terminated -- so D requests them at the end of that step
+    // straight into LDS (global_load_lds: asynchronous, no registers) and uses them at the top of the next one.  An env
+    // that cannot wait (several running low at once, a reset that consumed its words) is topped up on the spot.
     // D's steady-state loop waits for no load, so none of these paths needs to end drained (-4 % per step at 4096 envs).
 #ifndef CS_OD_ASYNC
-#define CS_OD_ASYNC 0   /* measured SLOWER (3 agents, 4096 envs: 2.06 against 1.92 us per step; 5 agents, 8192: 3.49 against 3.07):
-                           the ten row registers held across the step push the 128-VGPR kernel into hot-path spills, and the
-                           request's ballot runs every step; the code stays for the next register budget */
+#define CS_OD_ASYNC 1   /* rows and reset words are fetched a step ahead, straight into LDS (global_load_lds: no registers; the
+                           first version held the row in ten VGPRs across the step and was slower: spills in the hot path) */
 #endif
 #ifndef CS_OD_DRAIN
 #define CS_OD_DRAIN 0
 #endif
     constexpr int REQ = CS_OD_ASYNC ? LOW + (LOW > 96 ? LOW : 96) : 0;
-    RowRegs rr;
-    int cand = -1;   // env (octet) of the wavefront whose row is in flight in `rr`
+    int cand = -1;                       // env (octet) of the wavefront whose row is on its way into sh.rowbuf
+    unsigned long long pre_need = 0ull;  // the reset mask sh.prebuf was filled for
+    unsigned pre_valid = 0u;             // bit g: 16-lane group g's attempt batch is (on its way) in sh.prebuf
     oct_wave_advance<N, CS_OD_DRAIN != 0>(p, wave_b0, nvalid, lane, io.min_ahead > LOW ? io.min_ahead : LOW, sh.rowbuf, e, tape, tape_ok);   // while K produces step 0
     // ---- write-out plan (loop invariant)
     const int rows_valid = nvalid;
@@ -3348,8 +3367,10 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
         asm volatile("" : "+v"(t));
         ag = t < N;
         DUO_STAMP(8);
-        if (__builtin_expect(cand >= 0, 0)) {   // wave-uniform: the row requested a step ago
-            oct_advance_finish<N>(cold_params(), wave_b0, cand, lane, rr, sh.rowbuf, e, tape, tape_ok);
+        if (__builtin_expect(cand >= 0, 0)) {   // wave-uniform: the row requested a step ago is in sh.rowbuf
+            drain_vmem();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            oct_advance_finish<N>(cold_params(), wave_b0, cand, lane, sh.rowbuf, e, tape, tape_ok);
             cand = -1;
         }
         if (__builtin_expect(__ballot(live && e.ahead < LOW) != 0ull, 0))   // could not wait for its turn
@@ -3376,7 +3397,16 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
                 if (src >= 0) {
                     const int so = src >> 3, br = wave_b0 + so;
                     double gx, gy;
-                    reset_targets(cp, cp.mt + (size_t)br * MT_STRIDE, t16, gshift16, g_pos, g_words, g_ahead, gx, gy);
+                    // round 0: the attempt batch was requested when the env's step terminated (same mask -> same group)
+                    const bool use_pre = CS_OD_ASYNC && round == 0 && need == pre_need && ((pre_valid >> grp) & 1u);
+                    unsigned pre[4] = {0u, 0u, 0u, 0u};
+                    if (use_pre) {
+                        drain_vmem();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                        for (int q = 0; q < 4; q++) pre[q] = sh.prebuf[64 * q + lane];
+                    }
+                    reset_targets(cp, cp.mt + (size_t)br * MT_STRIDE, t16, gshift16, g_pos, g_words, g_ahead, gx, gy, use_pre, pre);
                     reinterpret_cast<double2 *>(cp.tgt + (size_t)br * G * 2)[t16] = make_double2(gx, gy);
                     sh.tgt[so][t16] = make_double2(gx, gy);
                     if (t16 < cp.n_targets) {
@@ -3483,10 +3513,40 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (CS_OD_ASYNC) {   // request next step's refresh (before this step's stores): the env running lowest, if any is below REQ
+        if (CS_OD_ASYNC && s + 1 < io.T) {   // requests for the next step, before this step's stores
+            // (a) the row of the env running lowest on twisted words, if any is below REQ: ten dword columns -> sh.rowbuf
             const unsigned long long lowb = __ballot(live && e.ahead < REQ && t == 0);
             cand = lowb ? __builtin_amdgcn_readfirstlane((__ffsll((long long)lowb) - 1) >> 3) : -1;
-            if (__builtin_expect(cand >= 0, 0)) row_load(cold_params().mt + (size_t)(wave_b0 + cand) * MT_STRIDE, lane, rr);
+            if (__builtin_expect(cand >= 0, 0)) {
+                const unsigned *m = cold_params().mt + (size_t)(wave_b0 + cand) * MT_STRIDE;
+#pragma unroll
+                for (int i = 0; i < 10; i++)   // (the tenth column reaches words 576..639: inside the row's 672, mirror included)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(m + lane + 64 * i),
+                                                     (__attribute__((address_space(3))) void *)(sh.rowbuf + 64 * i), 4, 0, 0);
+            }
+            // (b) the first attempt batch of every env whose step just terminated: it resets at the top of the next step
+            const unsigned long long nn = __ballot(live && stepping && term && auto_reset && t == 0);
+            pre_need = nn;
+            pre_valid = 0u;
+            if (__builtin_expect(nn != 0ull, 0)) {
+                unsigned long long mm = nn;
+                for (int q = 0; q < grp; q++) mm &= mm ? mm - 1 : 0ull;   // this 16-lane group's env in round 0 (as in the reset)
+                const int src = mm ? __ffsll((long long)mm) - 1 : -1;
+                const int sl = src >= 0 ? src : lane;
+                const int ppos = __shfl(e.mt_pos, sl), pah = __shfl(e.ahead, sl);
+                const bool okg = src >= 0 && pah >= 4 * G;   // its words are twisted already: their stored values are final
+                if (okg) {
+                    const unsigned *m = cold_params().mt + (size_t)(wave_b0 + (src >> 3)) * MT_STRIDE;
+                    const int i0 = wrap624(ppos + 4 * t16);
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(m + wrap624(i0 + q)),
+                                                         (__attribute__((address_space(3))) void *)(sh.prebuf + 64 * q), 4, 0, 0);
+                }
+                const unsigned long long vb = __ballot(okg);
+                pre_valid = (unsigned)((vb >> 0) & 1ull) | ((unsigned)((vb >> 16) & 1ull) << 1) | ((unsigned)((vb >> 32) & 1ull) << 2) |
+                            ((unsigned)((vb >> 48) & 1ull) << 3);
+            }
         }
         *p_rew = o_rew;
         *p_term = (uint8_t)o_term;

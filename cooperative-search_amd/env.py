@@ -72,7 +72,7 @@ class BatchedFlightEnv:
                 SIMD empty), "oct" (rollout only: 8 lanes per env, lane t owns agent t and targets t, t + 8), "od"
                 (rollout only: the octet layout with a kinematics wavefront running one step ahead of a detection
                 wavefront), "lane" (one env per lane: no replicated arithmetic, for large batches) or "auto" (rollout:
-                "od" up to 16384 envs, "oct" below 65536, "lane" from there; single steps: the 16-lane step kernel,
+                "od" up to 16384 envs, "oct" below 131072, "lane" from there; single steps: the 16-lane step kernel,
                 "lane" from 32768).  All produce bit-identical results.
     step_advance  step(): refresh the hit tapes every STEP_ADVANCE_EVERY single steps (default).  False leaves every
                 MT19937 word to be twisted on demand by the step kernel itself -- same results, one more dependent load per

@@ -1,14 +1,17 @@
 """Batch sweep of the flight_easy rollout kernels (SURVEY.md section 8d asks for 2^12..2^22): env-steps/s and the
-algorithmic-bytes roofline fraction per batch size, solo / duo (16 lanes per env) vs lane kernel.  Writes a markdown table."""
+algorithmic-bytes roofline fraction per batch size: the 16-lane kernels of rounds 1-2 (solo / duo), the octet kernels (od: pair
+of wavefronts per 8 envs, oct: one wavefront per 8 envs) and the lane kernel.  Writes a markdown table."""
 import json, subprocess, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rows = []
 for n in (3, 5):
-    for B in (1024, 2048, 4096, 8192, 16384, 65536, 262144, 1048576, 4194304):
-        for kernel in ("solo", "duo", "lane"):
+    for B in (1024, 2048, 4096, 8192, 16384, 32768, 65536, 262144, 1048576, 4194304):
+        for kernel in ("solo", "duo", "od", "oct", "lane"):
             if kernel == "lane" and B in (2048, 8192):
                 continue
-            if kernel != "lane" and B > (1 << 18):
+            if kernel in ("solo", "duo") and B > (1 << 16):
+                continue
+            if kernel in ("od", "oct") and B > (1 << 20):
                 continue
             if kernel == "duo" and B > (1 << 14):
                 continue
@@ -16,8 +19,8 @@ for n in (3, 5):
             out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-also",
                                   "--workload", "c2" if n == 3 else "c3", "--mode", "rollout", "--kernel", kernel,
                                   "--batch", str(B), "--steps", str(steps), "--warmup", str(min(100, steps))],
-                                 capture_output=True, text=True).stdout.strip().splitlines()[-1]
-            d = json.loads(out)
+                                 capture_output=True, text=True).stdout.strip().splitlines()
+            d = json.loads([ln for ln in out if ln.startswith("{")][-1])
             rows.append((n, B, kernel, d["value"], d["ms_per_step"] * 1e3, d["roofline"]["frac"]))
             print(rows[-1], flush=True)
 print("\n| agents | batch | kernel | env-steps/s | us per step | algorithmic GB/s / 8000 |")

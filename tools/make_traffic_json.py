@@ -7,7 +7,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-raw_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r02_traffic_raw.json")
+raw_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03_traffic_raw.json")
 out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "traffic.json")
 raw = json.load(open(raw_path))
 
@@ -17,13 +17,12 @@ raw = json.load(open(raw_path))
 # (bench label @ steps per launch, workload tag, kernels, steps per launch of that pass): bench.py only uses an entry for
 # a run with the SAME number of steps per launch (prologue traffic per env-step depends on the launch length)
 LABELS = [
-    ("k_rollout_duo<3>@100", "c2_rollout", ["k_rollout_duo<3>"], 100),
-    ("k_rollout_duo<3>@20", "c2_rollout20", ["k_rollout_duo<3>"], 20),
+    ("k_rollout_od<3>@100", "c2_rollout", ["k_rollout_od<3, true, true>"], 100),
+    ("k_rollout_od<3>@20", "c2_rollout20", ["k_rollout_od<3, true, true>"], 20),
     ("k_step<3,0>@1", "c2_step", ["k_step<3, 0>"], 1),
-    ("k_rollout<5>@100", "c3_rollout", ["k_rollout<5>"], 100),
-    ("k_rollout_oct<5>@100", "c3_oct", ["k_rollout_oct<5>"], 100),
-    ("k_rollout_oct<5>@100", "c5_oct", ["k_rollout_oct<5>"], 100),
-    ("k_rollout_oct<3>@100", "oct3_rollout", ["k_rollout_oct<3>"], 100),
+    ("k_rollout_od<5>@100", "c3_rollout", ["k_rollout_od<5, true, true>"], 100),
+    ("k_rollout_oct<3>@100", "oct3_32768", ["k_rollout_oct<3, true, true>"], 100),
+    ("k_rollout_oct<5>@100", "oct5_32768", ["k_rollout_oct<5, true, true>"], 100),
     ("k_rollout_lane<5>@100", "c5s_rollout", ["k_rollout_lane<5, true>", "k_rollout_lane<5, false>"], 100),
     ("k_rollout_lane<3>@100", "lane3_rollout", ["k_rollout_lane<3, true>", "k_rollout_lane<3, false>"], 100),
     ("k_step<3,1> + k_map<3>@1", "c4_step", ["k_map<3>", "k_step<3, 1>"], 1),
@@ -64,7 +63,7 @@ for label, tag, names, spl in LABELS:
     kernels[label] = ent
 doc = ("HBM traffic per env-step from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_traffic.sh over "
        "tools/exp_workload.py, which runs a known number of env-steps; KB units x 1024, summed over every launch of the "
-       "kernel; raw sums in r02_traffic_raw.json; this file = tools/make_traffic_json.py). FETCH_SIZE is doubled for k_map / "
+       "kernel; raw sums in r03_traffic_raw.json; this file = tools/make_traffic_json.py). FETCH_SIZE is doubled for k_map / "
        "k_flight_pipe (16 B/lane coalesced stream: gfx950 reports exactly half, MI355X_MICROARCH.md section HBM) and left raw "
        "for the other kernels (uncalibrated width). bench.py reports roofline.traffic = hbm_bytes_per_env_step x batch x "
        "steps per launch of ITS run. The rollout kernels refresh their MT19937 rows themselves (prologue / in-loop), so "

@@ -15,12 +15,15 @@ run() {  # tag, args...
     rc=$?; echo "$tag $c rc=$rc"; [ $rc -ne 0 ] && { fail=1; tail -3 "$OUT/${tag}_$c.log"; }
   done
 }
-run c2_rollout flight_easy 3 group 4096 rollout 4 100
-run c2_rollout20 flight_easy 3 group 4096 rollout 8 20
+run c2_rollout flight_easy 3 auto 4096 rollout 4 100
+run c2_rollout20 flight_easy 3 auto 4096 rollout 8 20
 run c2_step flight_easy 3 group 4096 step 2 100
-run c3_rollout flight_easy 5 group 16384 rollout 4 100
-run c5_rollout flight_easy 5 group 8192 rollout 4 100
-run c5s_rollout flight_easy 5 lane 65536 rollout 3 100
+run c3_rollout flight_easy 5 auto 16384 rollout 4 100
+run c5_rollout flight_easy 5 auto 8192 rollout 4 100
+run od3_16384 flight_easy 3 auto 16384 rollout 4 100
+run oct3_32768 flight_easy 3 auto 32768 rollout 4 100
+run oct5_32768 flight_easy 5 auto 32768 rollout 4 100
+run c5s_rollout flight_easy 5 auto 65536 rollout 3 100
 run lane3_rollout flight_easy 3 lane 262144 rollout 3 100
 run c4_step flight 3 group 8192 step 1 100
 run c4_rollout flight 3 group 8192 rollout 1 100
