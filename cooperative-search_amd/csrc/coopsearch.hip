@@ -1010,7 +1010,7 @@ __device__ int g_tl_step_dummy;
 #define DUO_MARK(row, k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_stamps[row][k] = __builtin_readcyclecounter(); } while (0)
 #define OCT_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && s < 64) g_stamps[s][k] = __builtin_readcyclecounter(); } while (0)
 #define KIN_STAMP(k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && tl_step >= 0 && tl_step < 64) g_stamps[tl_step][k] = __builtin_readcyclecounter(); } while (0)
-#define KIN_STAMP_SP(k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && sp >= 1 && sp <= 64) g_stamps[sp - 1][k] = __builtin_readcyclecounter(); } while (0)
+#define KIN_STAMP_SP(k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && sp >= 0 && sp < 64) g_stamps[sp][k] = __builtin_readcyclecounter(); } while (0)
 #else
 #define KIN_STAMP(k) do {} while (0)
 #define KIN_STAMP_SP(k) do {} while (0)
@@ -3121,12 +3121,18 @@ __global__ __launch_bounds__(OCT_BLOCK, CS_OCT_WAVES) void k_rollout_oct(DevPara
 // then detection + reward + rows (~1500) -- and at the batch sizes where every SIMD holds at most one or two wavefronts
 // nothing fills its stalls.  As in k_rollout_duo, the kinematics of step s + 1 need nothing from the detection pass of
 // step s (the actions are an open-loop table; the only coupling is a termination K cannot predict from the step counter:
-// an env finding its last target), so K runs one step ahead and leaves each step's positions in a two-slot LDS ring; D
-// consumes them.  The step time drops to max(K, D), and a batch gets twice the wavefronts: 4096 envs fill all 1024 SIMDs
-// (the octet kernel: half of them).  Roles:
+// an env finding its last target), so K runs AHEAD and leaves each step's positions in a ring of OD_RING LDS slots; D
+// consumes them.  A batch gets twice the wavefronts -- 4096 envs fill all 1024 SIMDs (the octet kernel: half of them) -- and
+// the two halves of a step overlap.  The pair synchronises through two LDS counters, not through workgroup barriers: K
+// may produce step j once D has finished step j - OD_RING, D may consume step s once K has produced it.  With a barrier per
+// step (round 2's pair kernel, and the first version of this one) every rare event on either side -- a reset, an MT19937
+// row top-up: 1.5-3 us each -- stops BOTH wavefronts, and each step pays the barrier's own latency on top of max(K, D);
+// with counters K simply runs up to OD_RING - 1 steps ahead, D (the longer half) never waits, and its events cost only D's
+// own time.  Roles:
 //   K  lane t owns agent t: trig, the repulsion stages (OctStage), wall rule; keeps the team's current positions in its
 //      own LDS array (kpos), publishes (x, y, yaw, cos, sin, out flags) per step; predicts resets / freezes from the step
-//      counter; after the barrier it redoes step s + 1 for the envs D flagged (restored from the ring).
+//      counter.  When D reports a termination K could not predict (a win at step s), K restores that env from ring slot s
+//      and REDOES every step it has already produced past s, for that env only (D holds slot s and waits meanwhile).
 //   D  lane t owns targets t, t + 8, the env's header and its hit tape: sensor tests on the ring's positions, draws,
 //      reward, termination, the persistent get_state rows and every output store; resets (target placement on the 16-lane
 //      code, reset-time pass) and row top-ups.
@@ -3135,7 +3141,12 @@ __global__ __launch_bounds__(OCT_BLOCK, CS_OCT_WAVES) void k_rollout_oct(DevPara
 #ifndef CS_OD_WAVES
 #define CS_OD_WAVES 4
 #endif
+#ifndef CS_OD_RING
+#define CS_OD_RING 4
+#endif
 constexpr int OD_BLOCK = 128;
+constexpr int OD_RING = CS_OD_RING;   // steps K may be ahead of D (power of two)
+static_assert((OD_RING & (OD_RING - 1)) == 0 && OD_RING >= 2, "ring depth");
 
 struct __attribute__((aligned(16))) OdRing {   // what K hands to D for one step
     double2 pos[OCT_ENVS][OCT_PAD];
@@ -3145,15 +3156,22 @@ struct __attribute__((aligned(16))) OdRing {   // what K hands to D for one step
     unsigned pad[OCT_ENVS];
 };
 struct __attribute__((aligned(16))) OdShared {
-    OdRing ring[2];
+    OdRing ring[OD_RING];
     double2 kpos[OCT_ENVS][OCT_PAD];        // K: the team's current positions (the "old" ones of its next step)
     double2 dpos[OCT_ENVS][OCT_PAD];        // D: start poses for the reset-time detection pass
-    double2 tgt[OCT_ENVS][CS_MAX_TARGETS];  // D: reset hand-over (16-lane group -> octet)
     float tile[OCT_ENVS * TILE_W];
     float reward[OCT_ENVS];
     int term[OCT_ENVS], win[OCT_ENVS];
-    unsigned fix[2];                         // [step parity]: envs (bit o) whose termination K mispredicted
-    unsigned rowbuf[MT_N + 16];              // one MT19937 row (+ the 16 words lanes 48..63 of the tenth dword column land on)
+    // pair synchronisation (LDS words, written by one side, polled by the other; the LDS serves a workgroup's accesses in
+    // order, so data written before a counter is visible to whoever has seen the counter)
+    int k_steps;                             // K: steps produced so far (slot s is valid once k_steps > s)
+    int d_steps;                             // D: steps finished so far (slot s may be overwritten once d_steps > s)
+    int fix_req, fix_ack;                    // D -> K: "step fix_req - 1 ended an episode you could not predict" / K -> D: redone
+    unsigned fix_mask;                       // ... for the envs in this mask (bit o)
+    union {   // never live together: a requested row is consumed at the top of a step, before any reset of that step
+        unsigned rowbuf[MT_N + 16];          // one MT19937 row (+ the 16 words lanes 48..63 of the tenth dword column land on)
+        double2 tgt[OCT_ENVS][CS_MAX_TARGETS];   // D: reset hand-over (16-lane group -> octet)
+    };
     unsigned prebuf[4 * 64];                 // [q][lane]: the first attempt batch of the resets due at the next step
 };
 
@@ -3217,7 +3235,18 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
         bool k_done = live && (e.target_find >= p.n_targets || e.time_step >= p.time_limit);   // exact at launch
         int k_time = e.time_step;
         unsigned k_out = ((unsigned)e.flags >> 8) & 0xffu;
-        // the state after step `sp` from the state after step sp - 1, for the octets in `sel`, into ring slot sp & 1
+        // The counters are relaxed workgroup-scope atomics on LDS words, ordered against the slot data by wavefront-scope fences
+        // only: the LDS serves one wavefront's accesses in order, and a workgroup-scope release / acquire would also wait for
+        // every GLOBAL operation in flight (K's action prefetch, D's output stores) -- measured: +400 cycles per step.
+        auto peek = [](const int *w) __attribute__((always_inline)) {
+            return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        auto post = [&](int *w, int v) __attribute__((always_inline)) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            if (lane == 0) __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        int fix_seen = 0;
+        // the state after step `sp` from the state after step sp - 1, for the octets in `sel`, into ring slot sp % OD_RING
         auto produce = [&](int sp, int a, bool sel) __attribute__((always_inline)) {
             const bool rs = sel && live && k_done && auto_reset;   // predicted reset (flight_env_easy.py:139-180: start poses)
             if (__ballot(rs)) {
@@ -3233,7 +3262,7 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
             const bool stepping = sel && live && !(k_done && freeze);
-            const unsigned out = oct_kinematics<N>(p, T, sh.kpos, o, t, sh8, stepping, a, e, sp - 1);
+            const unsigned out = oct_kinematics<N>(p, T, sh.kpos, o, t, sh8, stepping, a, e, sp);
             KIN_STAMP_SP(6);
             if (stepping) {
                 k_out = out;
@@ -3242,7 +3271,7 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();   // every lane has read the old positions
-            OdRing &r = sh.ring[sp & 1];
+            OdRing &r = sh.ring[sp & (OD_RING - 1)];
             if (sel) {
                 const double2 xy = make_double2(e.x, e.y);
                 sh.kpos[o][t] = xy;
@@ -3255,44 +3284,61 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         };
-        produce(0, act, true);
-        __syncthreads();   // the ring holds step 0
-        for (int s = 0; s < io.T; s++) {
+        const int *const abase = reinterpret_cast<const int *>(io.actions) + (bl * N + aidx) * astride;
+        // D reported a termination K could not predict (an env found its last target at step fs before the time limit):
+        // restore the env as it was after step fs from the ring (D holds that slot), mark it done -- the next produce then
+        // resets or freezes it like a predicted termination -- and redo the steps already produced past fs, for it alone
+        auto handle_fix = [&](int produced) __attribute__((always_inline)) {
+            const int req = peek(&sh.fix_req);
+            if (__builtin_expect(req != fix_seen, 0)) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int fs = req - 1;
+                const bool mine = live && ((sh.fix_mask >> o) & 1u);
+                if (mine) {
+                    const OdRing &r = sh.ring[fs & (OD_RING - 1)];
+                    const double2 xy = r.pos[o][t];
+                    e.x = xy.x;
+                    e.y = xy.y;
+                    e.yaw = r.yaw[o][t];
+                    trig_heading(T, e.yaw, e.sn, e.cs);
+                    sh.kpos[o][t] = xy;
+                    k_out = r.out[o];
+                    k_done = true;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (int j = fs + 1; j < produced; j++) produce(j, abase[(size_t)j * astep], mine);
+                fix_seen = req;
+                post(&sh.fix_ack, req);
+            }
+        };
+        for (int s = 0; s < io.T; s++) {   // (D zeroed the counters before the barrier that published the trig table)
             asm volatile("" : "+v"(t));
             ag = t < N;
-            const bool more = s + 1 < io.T;
             DUO_STAMP(0);
             const int act_after = ap[0];
             if (s + 3 < io.T) ap += astep;
-            if (more) produce(s + 1, act_next, true);
-            DUO_STAMP(1);
-            __syncthreads();   // D has consumed step s (and left its flags), step s + 1 is in the ring
-            DUO_STAMP(2);
-            const unsigned f = sh.fix[s & 1];
-            if (f) {   // block-uniform, rare: an env terminated by finding its last target
-                if (more) {
-                    const bool mine = live && ((f >> o) & 1u);
-                    if (mine) {   // the env as it was after step s
-                        const OdRing &r = sh.ring[s & 1];
-                        const double2 xy = r.pos[o][t];
-                        e.x = xy.x;
-                        e.y = xy.y;
-                        e.yaw = r.yaw[o][t];
-                        trig_heading(T, e.yaw, e.sn, e.cs);
-                        sh.kpos[o][t] = xy;
-                        k_out = r.out[o];
-                        k_done = true;
-                        k_time -= 1;   // the speculative step s + 1 is undone (a frozen env never gets here)
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    produce(s + 1, act_next, mine);
-                }
-                __syncthreads();
+            // flow control: slot s % OD_RING is free once D has finished step s - OD_RING
+            while (peek(&sh.d_steps) <= s - OD_RING) {
+                handle_fix(s);
+                __builtin_amdgcn_s_sleep(2);
             }
+            handle_fix(s);
+            DUO_STAMP(2);
+            produce(s, act, true);
+            DUO_STAMP(1);
+            post(&sh.k_steps, s + 1);
+            act = act_next;
             act_next = act_after;
         }
+        // D may still report an unpredicted termination of a step K has long left behind: stay until it has judged step T - 2
+        // (the last one whose successor exists)
+        while (peek(&sh.d_steps) < io.T - 1) {
+            handle_fix(io.T);
+            __builtin_amdgcn_s_sleep(4);
+        }
+        handle_fix(io.T);
         if (live && ag)   // agents are K's part of the state
             reinterpret_cast<double4 *>(cold_params().agent + (size_t)b * CS_MAX_AGENTS * 4)[t] = make_double4(e.x, e.y, e.yaw, 0.0);
         return;
@@ -3309,7 +3355,14 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
         e.ty[1] = tb.y;
     }
     const TapeRaw traw = tape_fetch(p, (int)bl);
-    load_trig_to_lds(T);   // (K's table; D only joins its barrier)
+    if (lane == 0) {   // the pair's counters: zero before the barrier below lets K start
+        sh.k_steps = 0;
+        sh.d_steps = 0;
+        sh.fix_req = 0;
+        sh.fix_ack = 0;
+        sh.fix_mask = 0u;
+    }
+    load_trig_to_lds(T);   // (K's table; D only joins its barrier -- after which K produces ahead, up to OD_RING steps)
     unsigned tape[TAPE_DW];
     bool tape_ok = tape_finish(p, traw, e, tape) || !live;
     float *row = sh.tile + o * W;
@@ -3326,7 +3379,13 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
         row[4 * N + 3 * (t + OG) + 1] = (float)((e.ty[1] - p.mid) * p.inv_half);
     }
     put_found();
-    if (lane == 0) sh.fix[0] = sh.fix[1] = 0u;
+    auto peek = [](const int *w) __attribute__((always_inline)) {
+        return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto post = [&](int *w, int v) __attribute__((always_inline)) {   // (see K: LDS-only ordering)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (lane == 0) __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
     constexpr int LOW = 2 * N * CS_MAX_TARGETS;   // words one step can consume
     // Rare events stall the whole pair (K waits at the barrier), and what they cost is mostly ONE dependent round trip to
     // memory: the MT19937 row of a top-up, the stream words of a reset's attempt batch.  Both are known a step ahead -- an
@@ -3362,7 +3421,6 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
     int chunk[Q];
 #pragma unroll
     for (int q = 0; q < Q; q++) chunk[q] = lane + 64 * q < OCT_ENVS * W / 4 - 1 ? lane + 64 * q : OCT_ENVS * W / 4 - 1;
-    __syncthreads();   // the ring holds step 0
     for (int s = 0; s < io.T; s++) {
         asm volatile("" : "+v"(t));
         ag = t < N;
@@ -3460,8 +3518,10 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
         }
         const bool stepping = live && !(done && freeze);
         DUO_STAMP(9);
-        // ---- K's step s: out flags, the agents' four floats (get_obs / get_state), positions for the sensor tests
-        const OdRing &r = sh.ring[s & 1];
+        // ---- K's step s (normally produced long ago): out flags, the agents' four floats (get_obs / get_state), positions
+        while (peek(&sh.k_steps) <= s) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const OdRing &r = sh.ring[s & (OD_RING - 1)];
         if (live) e.flags = (e.flags & ~0xff00) | (int)(r.out[o] << 8);
         if (ag) {
             const double2 xy = r.pos[o][t];
@@ -3480,12 +3540,13 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
             term = e.target_find >= p.n_targets || e.time_step >= p.time_limit;
             mispredicted = (auto_reset || freeze) && term && e.time_step < p.time_limit;   // K steps on unless the counter says otherwise
         }
-        {
-            const unsigned long long mb = __ballot(mispredicted && t == 0);
+        const unsigned long long mb = s + 1 < io.T ? __ballot(mispredicted && t == 0) : 0ull;
+        if (__builtin_expect(mb != 0ull, 0)) {   // K has stepped these envs on as if nothing had happened: have it redo them
             unsigned m8 = 0;
 #pragma unroll
             for (int q = 0; q < OCT_ENVS; q++) m8 |= (unsigned)((mb >> (OG * q)) & 1ull) << q;
-            if (lane == 0) sh.fix[s & 1] = m8;
+            if (lane == 0) sh.fix_mask = m8;
+            post(&sh.fix_req, s + 1);
         }
         if (__ballot(stepping && e.newly != 0u)) put_found();   // wave-uniform: some env found a target in this step
         if (t == 0) {
@@ -3569,9 +3630,11 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
             }
         }
         DUO_STAMP(11);
-        __syncthreads();
+        if (__builtin_expect(mb != 0ull, 0)) {   // slot s stays ours until K has restored the flagged envs from it
+            while (peek(&sh.fix_ack) != s + 1) __builtin_amdgcn_s_sleep(1);
+        }
+        post(&sh.d_steps, s + 1);
         DUO_STAMP(12);
-        if (sh.fix[s & 1]) __syncthreads();   // K redoes step s + 1 of the flagged envs
     }
     if (live) {   // header, cursor and tape are D's part of the state; targets were stored at each reset
         const DevParams &cp = cold_params();

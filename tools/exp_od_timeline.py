@@ -15,8 +15,8 @@ assert L.cs_debug_read_stamps(buf) == 0
 st = np.frombuffer(buf, dtype=np.uint64).reshape(64, 16).astype(np.int64)
 med = lambda a: int(np.median(a[5:60]))
 print(f"k_rollout_od<{n}> B={B}, workgroup 0, median cycles over steps 5..60")
-print("  K: produce(s+1)", med(st[:, 1] - st[:, 0]), " wait at barrier", med(st[:, 2] - st[:, 1]), " step-to-step", med(st[1:, 0] - st[:-1, 0]))
-print("  K inside produce: entry->trig", med(st[:, 3] - st[:, 0]), " trig pair", med(st[:, 4] - st[:, 3]), " fast path / stages", med(st[:, 5] - st[:, 4]),
+print("  K: wait for a free slot", med(st[:, 2] - st[:, 0]), " produce(s)", med(st[:, 1] - st[:, 2]), " step-to-step", med(st[1:, 0] - st[:-1, 0]))
+print("  K inside produce: entry->trig", med(st[:, 3] - st[:, 2]), " trig pair", med(st[:, 4] - st[:, 3]), " fast path / stages", med(st[:, 5] - st[:, 4]),
       " selects+ballot", med(st[:, 6] - st[:, 5]), " publish (LDS)", med(st[:, 1] - st[:, 6]))
 print("  D: top-up/reset", med(st[:, 9] - st[:, 8]), " ring+detect", med(st[:, 10] - st[:, 9]), " flags+rows+stores", med(st[:, 11] - st[:, 10]),
-      " wait at barrier", med(st[:, 12] - st[:, 11]), " step-to-step", med(st[1:, 8] - st[:-1, 8]))
+      " publish", med(st[:, 12] - st[:, 11]), " step-to-step", med(st[1:, 8] - st[:-1, 8]))
