@@ -61,6 +61,7 @@ struct DevParams {
     int obs_row_w;   // floats per (env, agent) row of the obs output: 4, flight: cells + 4 (map first, flight_env.py:223-230)
     int obs_feat_off;  // where the agent's own 4 floats sit in its row: 0, flight: cells
     float thr32, eps32;  // lane kernel's fp32 pre-filter of the sensor test, in normalised coordinates
+    double start_x[CS_MAX_AGENTS], start_y[CS_MAX_AGENTS], start_yaw;  // start_pose() of every agent, evaluated once on the host
 };
 
 // The kernel's own DevParams as it sits in the kernarg segment (every kernel here takes it as its FIRST argument), behind
@@ -153,16 +154,31 @@ struct AttemptBatch {
     }
 };
 
-// index of the k-th (0-based) set bit of a 16-bit mask, 16 if there is none
+// index of the k-th (0-based) set bit of a 16-bit mask, 16 if there is none: binary search on popcounts (24 instructions;
+// the 16-step scan it replaces was 64, twice per attempt batch of every reset)
 __device__ __forceinline__ int kth_set_bit16(unsigned mask, int k) {
-    int sel = 16, c = 0;
-#pragma unroll
-    for (int l = 0; l < 16; l++) {
-        const bool bit = (mask >> l) & 1u;
-        sel = (bit && c == k) ? l : sel;
-        c += bit ? 1 : 0;
-    }
-    return sel;
+    const bool none = k < 0 || __popc(mask & 0xffffu) <= k;
+    unsigned m = mask & 0xffffu;
+    int sel = 0;
+    int c = __popc(m & 0xffu);
+    bool hi = k >= c;
+    sel += hi ? 8 : 0;
+    k -= hi ? c : 0;
+    m = hi ? m >> 8 : m;
+    c = __popc(m & 0xfu);
+    hi = k >= c;
+    sel += hi ? 4 : 0;
+    k -= hi ? c : 0;
+    m = hi ? m >> 4 : m;
+    c = __popc(m & 0x3u);
+    hi = k >= c;
+    sel += hi ? 2 : 0;
+    k -= hi ? c : 0;
+    m = hi ? m >> 2 : m;
+    c = (int)(m & 1u);
+    hi = k >= c;
+    sel += hi ? 1 : 0;
+    return none ? 16 : sel;
 }
 
 struct __attribute__((packed, aligned(4))) U4 { unsigned x, y, z, w; };  // 4-byte-aligned 16-byte access
@@ -864,6 +880,15 @@ __device__ __forceinline__ void start_pose(const DevParams &p, int i, double &x,
 // reset: flight_env_easy.py:79-182 / flight_env.py:83-191.  Group-cooperative; ends with the reset-time
 // detection pass (quirk Q3) whose reward is discarded.
 // ---------------------------------------------------------------------------------------------------------
+#ifdef CS_TIMELINE
+__device__ unsigned long long g_blk[1024][8];   // per workgroup: K entry / loop / loop end / exit, D the same
+#define BLK_STAMP(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) g_blk[blockIdx.x][k] = __builtin_readcyclecounter(); } while (0)
+extern __device__ unsigned long long g_stamps[64][16];
+#define RT_STAMP(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_stamps[63][3 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define RT_STAMP(k) do {} while (0)
+#define BLK_STAMP(k) do {} while (0)
+#endif
 // Target placement of a reset (flight_env_easy.py:95-134) for the env whose 16-lane group this is: lane t gets target t's
 // position in (mx, my); the env's MT19937 cursor / word count / pre-twisted count advance by what the reference's
 // sequential algorithm consumes.  No agent state involved: the octet kernel calls this alone.
@@ -882,10 +907,13 @@ __device__ __forceinline__ void reset_targets(const DevParams &p, unsigned *mt, 
         // this lane's entries of the kernel-argument tables, read where they are (the kernarg segment, indexed by lane):
         // as 64 selects the tables sat in SGPRs across the rollout loops and spilled in every kernel that can reset
         // (k_rollout<5>: 1244 -> 441 v_readlane / v_writelane, 253 -> 250 VGPRs)
+        RT_STAMP(0);
         mx = p.tx0[t];
         my = p.ty0[t];
         jx = p.jx2[t];
         jy = p.jy2[t];
+        asm volatile("" : "+v"(mx), "+v"(my), "+v"(jx), "+v"(jy));
+        RT_STAMP(1);
         const unsigned fmask = ~p.deter_mask & tmask;        // jittered targets
         const int need_total = __popc(fmask);
         const bool mine = (fmask >> t) & 1u;
@@ -894,11 +922,15 @@ __device__ __forceinline__ void reset_targets(const DevParams &p, unsigned *mt, 
         while (taken < need_total) {  // group-uniform; one batch suffices ~99 % of the time for 9 jittered targets
             AttemptBatch ab;
             ab.generate(mt, mt_pos, t, ahead, use_pre && taken == 0, pre);
+            asm volatile("" : "+v"(ab.u1), "+v"(ab.u2));
+            RT_STAMP(2);
             const double x1 = 2.0 * ab.u1 - 1.0, x2 = 2.0 * ab.u2 - 1.0;
             const double r2 = x1 * x1 + x2 * x2;
             const bool accept = !(r2 >= 1.0 || r2 == 0.0);
             const double f = sqrt(-2.0 * log(accept ? r2 : 0.5) / (accept ? r2 : 0.5));
-            const double g1 = f * x2, g2 = f * x1;
+            double g1 = f * x2, g2 = f * x1;
+            asm volatile("" : "+v"(g1), "+v"(g2));
+            RT_STAMP(3);
             const unsigned amask = (unsigned)((__ballot(accept) >> gshift) & 0xffffull);
             const int have = __popc(amask);
             const int want = need_total - taken;
@@ -917,6 +949,7 @@ __device__ __forceinline__ void reset_targets(const DevParams &p, unsigned *mt, 
             words_total += (unsigned long long)words;
             ahead = ahead > words ? ahead - words : 0;
             taken += have < want ? have : want;
+            RT_STAMP(4);
         }
     } else {
         // x, y = map_size*np.random.rand() per target, flight_env_easy.py:122-127
@@ -2814,10 +2847,206 @@ __device__ __forceinline__ void oct_advance_finish(const DevParams &p, int wave_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Auto-reset of the octet kernels (flight_env_easy.py:79-182).  With random or trained policies an episode of the shipped
+// configuration ends after ~50 steps, so a wavefront of 8 envs resets one of them every ~6 steps: not a rare path.  The
+// first version ran the 16-lane reset_targets() on kernel parameters read through cold_params(): a generic pointer, so
+// every field was a flat load followed by a full wait -- some 25 dependent memory round trips per reset, ~8000 cycles, three
+// steps' worth.  Here
+//  * the scalars come from the kernarg segment through a CONSTANT-address-space pointer: scalar loads, one wait for all;
+//  * the target tables (a*cx, a*cy, 2*a*dx, 2*a*dy per target) sit in LDS since the prologue (`rtab`, 4 x 16 doubles);
+//  * every attempt batch reads twisted words only: an env with fewer than 64 left is topped up BEFORE its batch (whole
+//    wavefront on the row, as everywhere), so there is no twist-on-the-fly path, no write-back of stream words and no
+//    spilled predicates of one; an env whose first 16 attempts did not yield enough accepted pairs (~1 %) simply stays
+//    pending for another round, its partial placement in LDS;
+//  * start poses are a table the host filled (DevParams::start_x / start_y), not N divisions.
+// ---------------------------------------------------------------------------------------------------------
+#define CS_AS1 __attribute__((address_space(1)))
+#define CS_AS4 __attribute__((address_space(4)))
+__device__ __forceinline__ const CS_AS4 DevParams *cold_params4() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    auto q = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(q));
+    return (const CS_AS4 DevParams *)q;
+#else
+    return nullptr;   // host pass: never executed
+#endif
+}
+
+// the reset's target tables into LDS: rtab[0..15] = a*cx, [16..31] = a*cy, [32..47] = 2*a*dx, [48..63] = 2*a*dy
+// (DevParams::tx0, ty0, jx2, jy2: adjacent in the kernarg segment); one lane per entry
+__device__ __forceinline__ void load_reset_tab(double *rtab, int lane) {
+    const CS_AS4 DevParams *q = cold_params4();
+    static_assert(CS_MAX_TARGETS == G, "one table row per 16 lanes");
+    static_assert(offsetof(DevParams, jy2) - offsetof(DevParams, tx0) == 3 * G * sizeof(double), "tables are adjacent");
+    rtab[lane] = q->tx0[lane];   // lane 0..63 runs through tx0, ty0, jx2, jy2
+}
+
+template <int N>
+struct StartTab {
+    double x[N], y[N], yaw;
+};
+template <int N>
+__device__ __forceinline__ StartTab<N> start_tab() {
+    const CS_AS4 DevParams *q = cold_params4();
+    StartTab<N> st;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        st.x[i] = q->start_x[i];
+        st.y[i] = q->start_y[i];
+    }
+    st.yaw = q->start_yaw;
+    return st;
+}
+template <int N>
+__device__ __forceinline__ void start_pick(const StartTab<N> &st, int i, double &x, double &y) {
+    x = st.x[0];
+    y = st.y[0];
+#pragma unroll
+    for (int k = 1; k < N; k++) {
+        x = i == k ? st.x[k] : x;
+        y = i == k ? st.y[k] : y;
+    }
+}
+
+// Target placement for the envs in `need` (bit 8 o = env o of the wavefront resets): new targets into the octet's e.tx /
+// e.ty, the state blob and (normalised, found = 0) the env's get_state row in `tile`; each env's stream cursor, word count,
+// twisted-ahead count and hit tape advance by what the reference's sequential algorithm consumes.  One env per 16-lane
+// group and round (lane = polar attempt; `slots`: four rows of 16 positions, the hand-over from group to octet, free between
+// rounds); pre(w) may hand a group the four stream words of its FIRST batch (fetched ahead of time).
+template <int N, bool DRAIN, class Pre>
+__device__ __forceinline__ void oct_place_targets(const DevParams &cp, int wave_b0, int nvalid, int lane, bool live,
+                                                  unsigned long long need, const double *rtab, double2 (*slots)[G], float *tile,
+                                                  int W, unsigned *rowbuf, EnvO<N> &e, unsigned (&tape)[TAPE_DW], bool &tape_ok,
+                                                  Pre pre) {
+    const CS_AS4 DevParams *q = cold_params4();
+    const int t16 = lane & (G - 1), gshift16 = lane & ~(G - 1), grp = lane >> 4, sh8 = lane & ~(OG - 1), t = lane & (OG - 1);
+    const int n_targets = q->n_targets, target_mode = q->target_mode;
+    const unsigned deter_mask = q->deter_mask;
+    const double mid = q->mid, inv_half = q->inv_half, L = q->L;
+    const CS_AS1 unsigned *mt = (const CS_AS1 unsigned *)q->mt;
+    CS_AS1 double *tgt = (CS_AS1 double *)q->tgt;
+    const unsigned tmask = n_targets >= 32 ? ~0u : ((1u << n_targets) - 1u);
+    const unsigned fmask = target_mode == 0 ? ~deter_mask & tmask : 0u;   // jittered targets (flight_env_easy.py:95-113)
+    const int need_total = __popc(fmask);
+    const bool jit = (fmask >> t16) & 1u;
+    const int my_rank = __popc(fmask & ((1u << t16) - 1u));   // which accepted attempt is this target's
+    unsigned long long pend = need;
+    int taken_env = 0;   // octet-uniform: accepted attempts of this env so far
+    bool first = true;
+    while (pend) {   // wave-uniform
+        const bool pending = (pend >> sh8) & 1ull;
+        if (__ballot(live && pending && e.ahead < 4 * G))
+            oct_wave_advance<N, DRAIN>(cp, wave_b0, nvalid, lane, 4 * G, rowbuf, e, tape, tape_ok);
+        unsigned long long m = pend;
+        for (int k = 0; k < grp; k++) m &= m ? m - 1 : 0ull;   // this group's env: the grp-th pending one
+        const int src = m ? __ffsll((long long)m) - 1 : -1;
+        const int sl = src >= 0 ? src : lane;
+        const int g_pos = __shfl(e.mt_pos, sl), g_taken = __shfl(taken_env, sl);
+        // an env back for another batch (~1 %) brings its partial placement along: target j sits in lane j % 8 of its octet
+        double px = 0.0, py = 0.0;
+        if (__ballot(src >= 0 && g_taken > 0)) {   // wave-uniform
+            const int from = src >= 0 ? OG * (src >> 3) + (t16 & (OG - 1)) : lane;
+            const double x0 = __shfl(e.tx[0], from), x1 = __shfl(e.tx[1], from), y0 = __shfl(e.ty[0], from), y1 = __shfl(e.ty[1], from);
+            px = t16 < OG ? x0 : x1;
+            py = t16 < OG ? y0 : y1;
+        }
+        int words = 0, taken_new = 0;
+        bool fin = false;
+        if (src >= 0) {
+            const int br = wave_b0 + (src >> 3);
+            double mx = rtab[t16], my = rtab[G + t16];   // a*cx, a*cy of target t16 (flight_env_easy.py:95-113)
+            fin = true;
+            if (target_mode != 0 || need_total > 0) {
+                unsigned w[4];
+                if (!(first && pre(w))) {
+                    const CS_AS1 unsigned *row = mt + (size_t)br * MT_STRIDE + wrap624(g_pos + 4 * t16);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) w[k] = row[k];   // (words 0..31 are mirrored behind the row: no wrap inside a lane's four)
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) w[k] = mt_temper(w[k]);
+                // numpy random_sample: 53-bit double from two words
+                const double u1 = ((double)(w[0] >> 5) * 67108864.0 + (double)(w[1] >> 6)) / 9007199254740992.0;
+                const double u2 = ((double)(w[2] >> 5) * 67108864.0 + (double)(w[3] >> 6)) / 9007199254740992.0;
+                if (target_mode == 0) {
+                    // np.random.randn is the legacy polar method: attempts (x1, x2) until 0 < r2 < 1; the pair's SECOND value
+                    // f*x2 is returned first, f*x1 is cached for the next call -- the j-th accepted attempt serves the j-th
+                    // jittered target (see reset_targets)
+                    if (g_taken > 0) {
+                        mx = px;
+                        my = py;
+                    }
+                    const double x1 = 2.0 * u1 - 1.0, x2 = 2.0 * u2 - 1.0;
+                    const double r2 = x1 * x1 + x2 * x2;
+                    const bool accept = !(r2 >= 1.0 || r2 == 0.0);
+                    const double f = sqrt(-2.0 * log(accept ? r2 : 0.5) / (accept ? r2 : 0.5));
+                    const double g1 = f * x2, g2 = f * x1;
+                    const unsigned amask = (unsigned)((__ballot(accept) >> gshift16) & 0xffffull);
+                    const int have = __popc(amask);
+                    const int want = need_total - g_taken;
+                    const int k = my_rank - g_taken;   // my index within this batch's accepts
+                    const int sel = kth_set_bit16(amask, (k >= 0 && k < 16) ? k : 0);
+                    const double s1 = __shfl(g1, sel & 15, G), s2 = __shfl(g2, sel & 15, G);
+                    if (jit && k >= 0 && k < have && k < want) {
+                        mx += rtab[2 * G + t16] * (s1 - 0.5);  // dx*2*(randn-0.5)
+                        my += rtab[3 * G + t16] * (s2 - 0.5);
+                    }
+                    // words consumed: up to and including the attempt that supplied the last needed pair, else the batch
+                    const int last = have >= want ? kth_set_bit16(amask, want - 1) : 15;
+                    words = 4 * (last + 1);
+                    taken_new = g_taken + (have < want ? have : want);
+                    fin = taken_new >= need_total;
+                } else {   // x, y = map_size*np.random.rand() per target, flight_env_easy.py:122-127
+                    mx = L * u1;
+                    my = L * u2;
+                    words = 4 * n_targets;
+                }
+            }
+            slots[grp][t16] = make_double2(mx, my);
+            if (fin) {
+                typedef double v2d __attribute__((ext_vector_type(2)));
+                reinterpret_cast<CS_AS1 v2d *>(tgt + (size_t)br * G * 2)[t16] = v2d{mx, my};
+                if (t16 < n_targets) {
+                    float *rs = tile + (src >> 3) * W + 4 * N + 3 * t16;
+                    rs[0] = (float)((mx - mid) * inv_half);   // norm_target
+                    rs[1] = (float)((my - mid) * inv_half);
+                    rs[2] = 0.0f;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // the k-th pending env was served by group k: its octet takes the placement (final or partial) and the stream position
+        const int rank = __popcll(pend & ((1ull << sh8) - 1ull));
+        const bool got = pending && rank < 4;
+        const int leader = got ? G * rank : lane;
+        const int r_words = __shfl(words, leader), r_taken = __shfl(taken_new, leader), r_fin = __shfl(fin ? 1 : 0, leader);
+        if (got) {
+            const double2 ta = slots[rank][t], tb = slots[rank][t + OG];
+            e.tx[0] = ta.x;
+            e.ty[0] = ta.y;
+            e.tx[1] = tb.x;
+            e.ty[1] = tb.y;
+            tape_shift<1>(tape, r_words >> 1);   // (<= 32 draw slots leave the tape)
+            e.mt_pos = wrap624(e.mt_pos + r_words);
+            e.words += (unsigned long long)r_words;
+            e.ahead -= r_words;
+            taken_env = r_taken;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // the slots are free again (next round; a top-up may reuse their memory)
+        pend &= ~__ballot(got && r_fin != 0 && t == 0);
+        first = false;
+    }
+}
+
 template <int N, bool VEC, bool EMIT>
 __global__ __launch_bounds__(OCT_BLOCK, CS_OCT_WAVES) void k_rollout_oct(DevParams p, StepIO io) {
     __shared__ double T[TRIG_ROWS * TRIG_COLS];
     __shared__ OctShared shared[OCT_BLOCK / 64];
+    __shared__ double rtab[4 * G];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int o = lane >> 3, sh8 = lane & ~(OG - 1);
     int t = lane & (OG - 1);   // (not const: made opaque once per step, see the loop)
@@ -2868,6 +3097,7 @@ __global__ __launch_bounds__(OCT_BLOCK, CS_OCT_WAVES) void k_rollout_oct(DevPara
     if (io.T > 1) ap += astep;
     int act_next = ap[0];   // one step ahead of its use
     if (io.T > 2) ap += astep;   // -> step 2 (or the last step: short launches re-read it, the value is never used)
+    if (wave == 0) load_reset_tab(rtab, lane);
     load_trig_to_lds(T);
     if (nvalid <= 0) return;   // wave-uniform
     if (!live) {   // a lane without an env never steps, resets or asks for a top-up
@@ -2940,67 +3170,24 @@ __global__ __launch_bounds__(OCT_BLOCK, CS_OCT_WAVES) void k_rollout_oct(DevPara
         //      targets come back through LDS, the stream position by shuffle; the agents' start poses and the reset-time
         //      detection pass (quirk Q3) are the octet's own.
         const unsigned long long need = __ballot(live && done && auto_reset && t == 0);   // bit 8 o'
-        if (__builtin_expect(need != 0ull, 0)) {   // cold: about one wave-step in 24
+        if (__builtin_expect(need != 0ull, 0)) {   // one wave-step in ~6 with the shipped configuration (see oct_place_targets)
             const DevParams &cp = cold_params();
             const bool mine = (need >> sh8) & 1ull;
-            const int my_rank = __popcll(need & ((1ull << sh8) - 1ull));
-            unsigned long long pend = need;
-            for (int round = 0; pend; round++) {
-                unsigned long long m = pend;
-                for (int q = 0; q < grp; q++) m &= m ? m - 1 : 0ull;   // this group's env: the grp-th pending one
-                const int src = m ? __ffsll((long long)m) - 1 : -1;
-                for (int q = 0; q < 4; q++) pend &= pend ? pend - 1 : 0ull;
-                const int sl = src >= 0 ? src : lane;
-                int g_pos = __shfl(e.mt_pos, sl), g_ahead = __shfl(e.ahead, sl);
-                unsigned long long g_words = (unsigned long long)(unsigned)__shfl((int)(unsigned)(e.words & 0xffffffffull), sl) |
-                                             ((unsigned long long)(unsigned)__shfl((int)(unsigned)(e.words >> 32), sl) << 32);
-                if (src >= 0) {
-                    const int so = src >> 3, br = wave_b0 + so;
-                    double gx, gy;
-                    reset_targets(cp, cp.mt + (size_t)br * MT_STRIDE, t16, gshift16, g_pos, g_words, g_ahead, gx, gy);
-                    reinterpret_cast<double2 *>(cp.tgt + (size_t)br * G * 2)[t16] = make_double2(gx, gy);
-                    sh.tgt[so][t16] = make_double2(gx, gy);
-                    if (t16 < cp.n_targets) {
-                        float *rs = sh.tile + so * W + 4 * N + 3 * t16;
-                        rs[0] = (float)((gx - cp.mid) * cp.inv_half);   // norm_target
-                        rs[1] = (float)((gy - cp.mid) * cp.inv_half);
-                        rs[2] = 0.0f;
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                // the q-th pending env of this round was reset by group q: its (group-uniform) stream position comes back
-                const int q = my_rank - 4 * round;
-                const bool got = mine && q >= 0 && q < 4;
-                const int leader = got ? 16 * q : lane;
-                const int r_pos = __shfl(g_pos, leader), r_ahead = __shfl(g_ahead, leader);
-                const int r_wlo = __shfl((int)(unsigned)(g_words & 0xffffffffull), leader);
-                const int r_whi = __shfl((int)(unsigned)(g_words >> 32), leader);
-                if (got) {
-                    const unsigned long long w_new = (unsigned long long)(unsigned)r_wlo | ((unsigned long long)(unsigned)r_whi << 32);
-                    // the reset consumed (w_new - words) stream words, twisted ones first: their draw slots leave the tape
-                    const unsigned long long used = w_new - e.words;
-                    tape_shift<8>(tape, used < 2ull * 319ull ? (int)(used >> 1) : 319);
-                    e.mt_pos = r_pos;
-                    e.ahead = r_ahead;
-                    e.words = w_new;
-                    e.episodes += 1;
-                    e.found = 0;
-                    e.newly = 0;
-                    e.target_find = 0;
-                    e.time_step = 0;
-                    e.total_reward = 0;
-                    e.flags = 0;
-                    const double2 ta = sh.tgt[o][t], tb = sh.tgt[o][t + OG];
-                    e.tx[0] = ta.x;
-                    e.ty[0] = ta.y;
-                    e.tx[1] = tb.x;
-                    e.ty[1] = tb.y;
-                    start_pose<N>(cp, ag ? t : 0, e.x, e.y, e.yaw);
-                    trig_heading(T, e.yaw, e.sn, e.cs);
-                    sh.pos[o][t] = make_double2(e.x, e.y);
-                }
+            const StartTab<N> st = start_tab<N>();
+            oct_place_targets<N, true>(cp, wave_b0, nvalid, lane, live, need, rtab, sh.tgt, sh.tile, W, sh.rowbuf, e, tape, tape_ok,
+                                       [](unsigned (&)[4]) { return false; });
+            if (mine) {
+                e.episodes += 1;
+                e.found = 0;
+                e.newly = 0;
+                e.target_find = 0;
+                e.time_step = 0;
+                e.total_reward = 0;
+                e.flags = 0;
+                start_pick<N>(st, ag ? t : 0, e.x, e.y);
+                e.yaw = st.yaw;
+                trig_heading(T, e.yaw, e.sn, e.cs);
+                sh.pos[o][t] = make_double2(e.x, e.y);
             }
             drain_vmem();
             // reset-time detection pass (quirk Q3: its reward is discarded) of the envs just reset, from the tape -- topped up
@@ -3009,8 +3196,24 @@ __global__ __launch_bounds__(OCT_BLOCK, CS_OCT_WAVES) void k_rollout_oct(DevPara
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            oct_detect<N>(p, sh.pos, o, t, sh8, mine, e, tape);
-            put_found();
+            // (agent_mode 0 with the shipped target file never has a target within view of a start pose: the pass -- whose
+            // reward is discarded anyway -- is then three assignments; the test costs a third of the pass it usually saves)
+            bool near = false;
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                const double sx = st.x[i], sy = st.y[i];
+                const double ax0 = e.tx[0] - sx, ay0 = e.ty[0] - sy, ax1 = e.tx[1] - sx, ay1 = e.ty[1] - sy;
+                near = near | ((t < cp.n_targets) & (ax0 * ax0 + ay0 * ay0 <= cp.view_r2)) |
+                       ((t + OG < cp.n_targets) & (ax1 * ax1 + ay1 * ay1 <= cp.view_r2));
+            }
+            if (__ballot(mine && near)) {
+                oct_detect<N>(p, sh.pos, o, t, sh8, mine, e, tape);
+                put_found();
+            } else if (mine) {   // what the pass does when no pair is in range: no draw, reward -1
+                e.newly = 0u;
+                e.curr_reward = -1;
+                e.flags |= FLAG_DIRTY;
+            }
             done = done && !mine;
             if (__ballot(live && e.ahead < LOW)) oct_wave_advance<N>(cp, wave_b0, nvalid, lane, LOW, sh.rowbuf, e, tape, tape_ok);
         }
@@ -3170,11 +3373,37 @@ struct __attribute__((aligned(16))) OdShared {
     unsigned fix_mask;                       // ... for the envs in this mask (bit o)
     union {   // never live together: a requested row is consumed at the top of a step, before any reset of that step
         unsigned rowbuf[MT_N + 16];          // one MT19937 row (+ the 16 words lanes 48..63 of the tenth dword column land on)
-        double2 tgt[OCT_ENVS][CS_MAX_TARGETS];   // D: reset hand-over (16-lane group -> octet)
+        double2 tgt[4][CS_MAX_TARGETS];      // D: reset hand-over (16-lane group -> octet), free between rounds
     };
     unsigned prebuf[4 * 64];                 // [q][lane]: the first attempt batch of the resets due at the next step
+    double rtab[4 * G];                      // the reset's target tables (load_reset_tab)
 };
 
+// The pair's counters are plain LDS words written and polled with hand-placed ds instructions.  The LDS serves one
+// wavefront's accesses in order, so slot data written before a counter is visible to whoever has seen the counter; nothing
+// else is needed -- and anything else costs: a workgroup-scope release fence, and even a relaxed workgroup-scope atomic store,
+// make the compiler wait for every GLOBAL operation in flight first (`s_waitcnt vmcnt(0)` before the ds_write: D's six output
+// stores of the step, K's action prefetch), i.e. one memory round trip per step on both sides.
+__device__ __forceinline__ unsigned lds_offset_of(const void *w) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void *)w;
+}
+__device__ __forceinline__ void lds_post(int *w, int v) {
+    asm volatile("ds_write_b32 %0, %1" : : "v"(lds_offset_of(w)), "v"(v) : "memory");
+}
+__device__ __forceinline__ int lds_peek(const int *w) {
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_offset_of(w)) : "memory");
+    return v;
+}
+
+#ifndef CS_OD_COLD_PARAMS
+#define CS_OD_COLD_PARAMS 1
+#endif
+#if CS_OD_COLD_PARAMS
+#define OD_COLD() cold_params()
+#else
+#define OD_COLD() p
+#endif
 template <int N, bool VEC, bool EMIT>
 __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams p, StepIO io) {
     __shared__ double T[TRIG_ROWS * TRIG_COLS];
@@ -3187,6 +3416,7 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
     const int b_end = io.env0 + io.env_n;
     const int b = wave_b0 + o;
     const bool live = VEC || b < b_end;
+    BLK_STAMP(is_k ? 0 : 4);
     const int nvalid = b_end - wave_b0 < OCT_ENVS ? b_end - wave_b0 : OCT_ENVS;   // >= 1: the grid covers env_n exactly
     const int W = 4 * N + 3 * p.n_targets;
     bool ag = t < N;
@@ -3235,15 +3465,10 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
         bool k_done = live && (e.target_find >= p.n_targets || e.time_step >= p.time_limit);   // exact at launch
         int k_time = e.time_step;
         unsigned k_out = ((unsigned)e.flags >> 8) & 0xffu;
-        // The counters are relaxed workgroup-scope atomics on LDS words, ordered against the slot data by wavefront-scope fences
-        // only: the LDS serves one wavefront's accesses in order, and a workgroup-scope release / acquire would also wait for
-        // every GLOBAL operation in flight (K's action prefetch, D's output stores) -- measured: +400 cycles per step.
-        auto peek = [](const int *w) __attribute__((always_inline)) {
-            return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        };
-        auto post = [&](int *w, int v) __attribute__((always_inline)) {
+        auto peek = [](const int *w) __attribute__((always_inline)) { return lds_peek(w); };
+        auto post = [&](int *w, int v) __attribute__((always_inline)) {   // (lds_post above: LDS-only ordering)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            if (lane == 0) __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane == 0) lds_post(w, v);
         };
         int fix_seen = 0;
         // the state after step `sp` from the state after step sp - 1, for the octets in `sel`, into ring slot sp % OD_RING
@@ -3251,7 +3476,9 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
             const bool rs = sel && live && k_done && auto_reset;   // predicted reset (flight_env_easy.py:139-180: start poses)
             if (__ballot(rs)) {
                 if (rs) {
-                    start_pose<N>(cold_params(), ag ? t : 0, e.x, e.y, e.yaw);
+                    const StartTab<N> st = start_tab<N>();
+                    start_pick<N>(st, ag ? t : 0, e.x, e.y);
+                    e.yaw = st.yaw;
                     sh.kpos[o][t] = make_double2(e.x, e.y);
                     k_out = 0u;
                     k_time = 0;
@@ -3262,7 +3489,11 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
             const bool stepping = sel && live && !(k_done && freeze);
+#ifdef CS_OD_ABL_NOKIN   /* experiment: what D alone sustains */
+            const unsigned out = 0u;
+#else
             const unsigned out = oct_kinematics<N>(p, T, sh.kpos, o, t, sh8, stepping, a, e, sp);
+#endif
             KIN_STAMP_SP(6);
             if (stepping) {
                 k_out = out;
@@ -3284,6 +3515,7 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         };
+        BLK_STAMP(1);
         const int *const abase = reinterpret_cast<const int *>(io.actions) + (bl * N + aidx) * astride;
         // D reported a termination K could not predict (an env found its last target at step fs before the time limit):
         // restore the env as it was after step fs from the ring (D holds that slot), mark it done -- the next produce then
@@ -3332,6 +3564,7 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
             act = act_next;
             act_next = act_after;
         }
+        BLK_STAMP(2);
         // D may still report an unpredicted termination of a step K has long left behind: stay until it has judged step T - 2
         // (the last one whose successor exists)
         while (peek(&sh.d_steps) < io.T - 1) {
@@ -3340,7 +3573,8 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
         }
         handle_fix(io.T);
         if (live && ag)   // agents are K's part of the state
-            reinterpret_cast<double4 *>(cold_params().agent + (size_t)b * CS_MAX_AGENTS * 4)[t] = make_double4(e.x, e.y, e.yaw, 0.0);
+            reinterpret_cast<double4 *>(OD_COLD().agent + (size_t)b * CS_MAX_AGENTS * 4)[t] = make_double4(e.x, e.y, e.yaw, 0.0);
+        BLK_STAMP(3);
         return;
     }
 
@@ -3362,6 +3596,7 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
         sh.fix_ack = 0;
         sh.fix_mask = 0u;
     }
+    load_reset_tab(sh.rtab, lane);
     load_trig_to_lds(T);   // (K's table; D only joins its barrier -- after which K produces ahead, up to OD_RING steps)
     unsigned tape[TAPE_DW];
     bool tape_ok = tape_finish(p, traw, e, tape) || !live;
@@ -3379,12 +3614,10 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
         row[4 * N + 3 * (t + OG) + 1] = (float)((e.ty[1] - p.mid) * p.inv_half);
     }
     put_found();
-    auto peek = [](const int *w) __attribute__((always_inline)) {
-        return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    auto post = [&](int *w, int v) __attribute__((always_inline)) {   // (see K: LDS-only ordering)
+    auto peek = [](const int *w) __attribute__((always_inline)) { return lds_peek(w); };
+    auto post = [&](int *w, int v) __attribute__((always_inline)) {   // (lds_post above: LDS-only ordering)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        if (lane == 0) __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) lds_post(w, v);
     };
     constexpr int LOW = 2 * N * CS_MAX_TARGETS;   // words one step can consume
     // Rare events stall the whole pair (K waits at the barrier), and what they cost is mostly ONE dependent round trip to
@@ -3401,6 +3634,15 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
 #define CS_OD_DRAIN 0
 #endif
     constexpr int REQ = CS_OD_ASYNC ? LOW + (LOW > 96 ? LOW : 96) : 0;
+    // The requests of a step are issued BEFORE its output stores, and loads / stores retire in order: waiting until no more
+    // than the step's own stores are in flight is waiting for the requests -- without also sitting out the stores, which were
+    // issued a few hundred cycles ago and take a memory round trip (measured: a plain vmcnt(0) here cost ~1000 cycles per event).
+    constexpr int STEP_STORES = 3 + 1 + (OCT_ENVS * (4 * N + 3 * CS_MAX_TARGETS) / 4 + 63) / 64;   // reward, terminated, win, obs, Q state chunks (EMIT && VEC: exactly these)
+    auto wait_for_requests = [&]() __attribute__((always_inline)) {
+        if (EMIT && VEC && STEP_STORES <= 15) __builtin_amdgcn_s_waitcnt(0x0F70 | STEP_STORES);   // vmcnt(STEP_STORES)
+        else drain_vmem();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
     int cand = -1;                       // env (octet) of the wavefront whose row is on its way into sh.rowbuf
     unsigned long long pre_need = 0ull;  // the reset mask sh.prebuf was filled for
     unsigned pre_valid = 0u;             // bit g: 16-lane group g's attempt batch is (on its way) in sh.prebuf
@@ -3421,98 +3663,75 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
     int chunk[Q];
 #pragma unroll
     for (int q = 0; q < Q; q++) chunk[q] = lane + 64 * q < OCT_ENVS * W / 4 - 1 ? lane + 64 * q : OCT_ENVS * W / 4 - 1;
+    BLK_STAMP(5);
     for (int s = 0; s < io.T; s++) {
         asm volatile("" : "+v"(t));
         ag = t < N;
         DUO_STAMP(8);
         if (__builtin_expect(cand >= 0, 0)) {   // wave-uniform: the row requested a step ago is in sh.rowbuf
-            drain_vmem();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            oct_advance_finish<N>(cold_params(), wave_b0, cand, lane, sh.rowbuf, e, tape, tape_ok);
+            wait_for_requests();
+            oct_advance_finish<N>(OD_COLD(), wave_b0, cand, lane, sh.rowbuf, e, tape, tape_ok);
             cand = -1;
         }
         if (__builtin_expect(__ballot(live && e.ahead < LOW) != 0ull, 0))   // could not wait for its turn
-            oct_wave_advance<N, CS_OD_DRAIN != 0>(cold_params(), wave_b0, nvalid, lane, LOW, sh.rowbuf, e, tape, tape_ok);
+            oct_wave_advance<N, CS_OD_DRAIN != 0>(OD_COLD(), wave_b0, nvalid, lane, LOW, sh.rowbuf, e, tape, tape_ok);
         bool done = e.target_find >= p.n_targets || e.time_step >= p.time_limit;
         e.flags &= ~(FLAG_DIRTY | FLAG_RESET_PASS);
         // ---- auto-reset: target placement on the 16-lane code (one resetting env per 16-lane group and round), then the
         //      reset-time detection pass (quirk Q3) on the start poses
         const unsigned long long need = __ballot(live && done && auto_reset && t == 0);   // bit 8 o'
         if (__builtin_expect(need != 0ull, 0)) {
-            const DevParams &cp = cold_params();
+            DUO_STAMP(13);
+            const DevParams &cp = OD_COLD();
             const bool mine = (need >> sh8) & 1ull;
-            const int my_rank = __popcll(need & ((1ull << sh8) - 1ull));
-            unsigned long long pend = need;
-            for (int round = 0; pend; round++) {
-                unsigned long long m = pend;
-                for (int q = 0; q < grp; q++) m &= m ? m - 1 : 0ull;   // this group's env: the grp-th pending one
-                const int src = m ? __ffsll((long long)m) - 1 : -1;
-                for (int q = 0; q < 4; q++) pend &= pend ? pend - 1 : 0ull;
-                const int sl = src >= 0 ? src : lane;
-                int g_pos = __shfl(e.mt_pos, sl), g_ahead = __shfl(e.ahead, sl);
-                unsigned long long g_words = (unsigned long long)(unsigned)__shfl((int)(unsigned)(e.words & 0xffffffffull), sl) |
-                                             ((unsigned long long)(unsigned)__shfl((int)(unsigned)(e.words >> 32), sl) << 32);
-                if (src >= 0) {
-                    const int so = src >> 3, br = wave_b0 + so;
-                    double gx, gy;
-                    // round 0: the attempt batch was requested when the env's step terminated (same mask -> same group)
-                    const bool use_pre = CS_OD_ASYNC && round == 0 && need == pre_need && ((pre_valid >> grp) & 1u);
-                    unsigned pre[4] = {0u, 0u, 0u, 0u};
-                    if (use_pre) {
-                        drain_vmem();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const StartTab<N> st = start_tab<N>();
+            // round 0's attempt batches were requested when the envs' steps terminated (same mask -> same groups)
+            oct_place_targets<N, CS_OD_DRAIN != 0>(cp, wave_b0, nvalid, lane, live, need, sh.rtab, sh.tgt, sh.tile, W, sh.rowbuf, e, tape, tape_ok,
+                                                   [&](unsigned (&w)[4]) __attribute__((always_inline)) {
+                                                       const bool ok = CS_OD_ASYNC && need == pre_need && ((pre_valid >> grp) & 1u);
+                                                       if (ok) {
+                                                           wait_for_requests();
 #pragma unroll
-                        for (int q = 0; q < 4; q++) pre[q] = sh.prebuf[64 * q + lane];
-                    }
-                    reset_targets(cp, cp.mt + (size_t)br * MT_STRIDE, t16, gshift16, g_pos, g_words, g_ahead, gx, gy, use_pre, pre);
-                    reinterpret_cast<double2 *>(cp.tgt + (size_t)br * G * 2)[t16] = make_double2(gx, gy);
-                    sh.tgt[so][t16] = make_double2(gx, gy);
-                    if (t16 < cp.n_targets) {
-                        float *rs = sh.tile + so * W + 4 * N + 3 * t16;
-                        rs[0] = (float)((gx - cp.mid) * cp.inv_half);   // norm_target
-                        rs[1] = (float)((gy - cp.mid) * cp.inv_half);
-                        rs[2] = 0.0f;
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int q = my_rank - 4 * round;
-                const bool got = mine && q >= 0 && q < 4;
-                const int leader = got ? 16 * q : lane;
-                const int r_pos = __shfl(g_pos, leader), r_ahead = __shfl(g_ahead, leader);
-                const int r_wlo = __shfl((int)(unsigned)(g_words & 0xffffffffull), leader);
-                const int r_whi = __shfl((int)(unsigned)(g_words >> 32), leader);
-                if (got) {
-                    const unsigned long long w_new = (unsigned long long)(unsigned)r_wlo | ((unsigned long long)(unsigned)r_whi << 32);
-                    const unsigned long long used = w_new - e.words;   // its draw slots leave the tape
-                    tape_shift<8>(tape, used < 2ull * 319ull ? (int)(used >> 1) : 319);
-                    e.mt_pos = r_pos;
-                    e.ahead = r_ahead;
-                    e.words = w_new;
-                    e.episodes += 1;
-                    e.found = 0;
-                    e.newly = 0;
-                    e.target_find = 0;
-                    e.time_step = 0;
-                    e.total_reward = 0;
-                    e.flags = 0;
-                    const double2 ta = sh.tgt[o][t], tb = sh.tgt[o][t + OG];
-                    e.tx[0] = ta.x;
-                    e.ty[0] = ta.y;
-                    e.tx[1] = tb.x;
-                    e.ty[1] = tb.y;
-                    double sx, sy, syaw;
-                    start_pose<N>(cp, ag ? t : 0, sx, sy, syaw);
-                    sh.dpos[o][t] = make_double2(sx, sy);
-                }
+                                                           for (int k = 0; k < 4; k++) w[k] = sh.prebuf[64 * k + lane];
+                                                       }
+                                                       return ok;
+                                                   });
+            if (mine) {
+                e.episodes += 1;
+                e.found = 0;
+                e.newly = 0;
+                e.target_find = 0;
+                e.time_step = 0;
+                e.total_reward = 0;
+                e.flags = 0;
+                double sx, sy;
+                start_pick<N>(st, ag ? t : 0, sx, sy);
+                sh.dpos[o][t] = make_double2(sx, sy);
             }
+            DUO_STAMP(14);
             if (__ballot(live && e.ahead < LOW)) oct_wave_advance<N, CS_OD_DRAIN != 0>(cp, wave_b0, nvalid, lane, LOW, sh.rowbuf, e, tape, tape_ok);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            oct_detect<N>(p, sh.dpos, o, t, sh8, mine, e, tape);
-            put_found();
+            DUO_STAMP(15);
+            // (agent_mode 0 with the shipped target file never has a target within view of a start pose: the pass -- whose
+            // reward is discarded anyway -- is then three assignments; the test costs a third of the pass it usually saves)
+            bool near = false;
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                const double sx = st.x[i], sy = st.y[i];
+                const double ax0 = e.tx[0] - sx, ay0 = e.ty[0] - sy, ax1 = e.tx[1] - sx, ay1 = e.ty[1] - sy;
+                near = near | ((t < cp.n_targets) & (ax0 * ax0 + ay0 * ay0 <= cp.view_r2)) |
+                       ((t + OG < cp.n_targets) & (ax1 * ax1 + ay1 * ay1 <= cp.view_r2));
+            }
+            if (__ballot(mine && near)) {
+                oct_detect<N>(p, sh.dpos, o, t, sh8, mine, e, tape);
+                put_found();
+            } else if (mine) {   // what the pass does when no pair is in range: no draw, reward -1
+                e.newly = 0u;
+                e.curr_reward = -1;
+                e.flags |= FLAG_DIRTY;
+            }
             done = done && !mine;
             if (__ballot(live && e.ahead < LOW)) oct_wave_advance<N, CS_OD_DRAIN != 0>(cp, wave_b0, nvalid, lane, LOW, sh.rowbuf, e, tape, tape_ok);
         }
@@ -3521,6 +3740,10 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
         // ---- K's step s (normally produced long ago): out flags, the agents' four floats (get_obs / get_state), positions
         while (peek(&sh.k_steps) <= s) __builtin_amdgcn_s_sleep(1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef CS_OD_ABL_NODET   /* experiment: what K alone sustains */
+        post(&sh.d_steps, s + 1);
+        continue;
+#endif
         const OdRing &r = sh.ring[s & (OD_RING - 1)];
         if (live) e.flags = (e.flags & ~0xff00) | (int)(r.out[o] << 8);
         if (ag) {
@@ -3579,7 +3802,7 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
             const unsigned long long lowb = __ballot(live && e.ahead < REQ && t == 0);
             cand = lowb ? __builtin_amdgcn_readfirstlane((__ffsll((long long)lowb) - 1) >> 3) : -1;
             if (__builtin_expect(cand >= 0, 0)) {
-                const unsigned *m = cold_params().mt + (size_t)(wave_b0 + cand) * MT_STRIDE;
+                const unsigned *m = OD_COLD().mt + (size_t)(wave_b0 + cand) * MT_STRIDE;
 #pragma unroll
                 for (int i = 0; i < 10; i++)   // (the tenth column reaches words 576..639: inside the row's 672, mirror included)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(m + lane + 64 * i),
@@ -3597,7 +3820,7 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
                 const int ppos = __shfl(e.mt_pos, sl), pah = __shfl(e.ahead, sl);
                 const bool okg = src >= 0 && pah >= 4 * G;   // its words are twisted already: their stored values are final
                 if (okg) {
-                    const unsigned *m = cold_params().mt + (size_t)(wave_b0 + (src >> 3)) * MT_STRIDE;
+                    const unsigned *m = OD_COLD().mt + (size_t)(wave_b0 + (src >> 3)) * MT_STRIDE;
                     const int i0 = wrap624(ppos + 4 * t16);
 #pragma unroll
                     for (int q = 0; q < 4; q++)
@@ -3636,8 +3859,9 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
         post(&sh.d_steps, s + 1);
         DUO_STAMP(12);
     }
+    BLK_STAMP(6);
     if (live) {   // header, cursor and tape are D's part of the state; targets were stored at each reset
-        const DevParams &cp = cold_params();
+        const DevParams &cp = OD_COLD();
         if (t == 0) {
             int4 *h4 = reinterpret_cast<int4 *>(cp.hdr + (size_t)b * CS_H_WORDS);
             h4[0] = make_int4((int)e.found, (int)e.newly, e.target_find, e.flags);
@@ -3654,8 +3878,8 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
             if (t == 3) tp[3] = U4{(unsigned)(cp.detect_K & 0xffffffffull), (unsigned)(cp.detect_K >> 32), 0u, 0u};
         }
     }
+    BLK_STAMP(7);
 }
-
 template <int N>
 __global__ __launch_bounds__(BLOCK) void k_reset(DevParams p, const uint8_t *mask, int init, float *obs, float *state) {
     __shared__ double T[TRIG_ROWS * TRIG_COLS];
@@ -4148,6 +4372,15 @@ int make_params(const cs_config *c, void *state, DevParams *p) {
         p->thr32 = (float)thr;
         p->eps32 = (float)(1e-6 + 4e-6 * thr);
     }
+    for (int i = 0; i < c->n_agents; i++) {   // flight_env_easy.py:139-180, the arithmetic of start_pose() (IEEE: same bits)
+        const double sp = c->n_agents != 1 ? (double)(i * c->map_size) / (double)(c->n_agents - 1) : p->L / 2.0;
+        switch (c->agent_mode) {
+        case 0: p->start_x[i] = sp; p->start_y[i] = 0.0; p->start_yaw = 3.141592653589793 / 2.0; break;
+        case 1: p->start_x[i] = sp; p->start_y[i] = p->L / 2.0; p->start_yaw = 3.141592653589793 / 2.0; break;
+        case 2: p->start_x[i] = 0.0; p->start_y[i] = sp; p->start_yaw = 0.0; break;
+        default: p->start_x[i] = p->L; p->start_y[i] = sp; p->start_yaw = 3.141592653589793; break;
+        }
+    }
     p->prob = (float *)(base + lay.prob_off);
     p->job = base + lay.job_off;
     p->obs_row_w = c->variant == 1 ? p->cells + 4 : 4;
@@ -4585,6 +4818,10 @@ int cs_metrics(const cs_config *cfg, void *state_dev, double *out4_dev, void *st
 }
 
 #ifdef CS_TIMELINE
+int cs_debug_read_blk(unsigned long long *host1024x8) {
+    hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(host1024x8, HIP_SYMBOL(g_blk), sizeof(unsigned long long) * 1024 * 8);
+}
 int cs_debug_read_stamps(unsigned long long *host64x16) {
     hipDeviceSynchronize();
     return (int)hipMemcpyFromSymbol(host64x16, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64 * 16);

@@ -20,3 +20,15 @@ print("  K inside produce: entry->trig", med(st[:, 3] - st[:, 2]), " trig pair",
       " selects+ballot", med(st[:, 6] - st[:, 5]), " publish (LDS)", med(st[:, 1] - st[:, 6]))
 print("  D: top-up/reset", med(st[:, 9] - st[:, 8]), " ring+detect", med(st[:, 10] - st[:, 9]), " flags+rows+stores", med(st[:, 11] - st[:, 10]),
       " publish", med(st[:, 12] - st[:, 11]), " step-to-step", med(st[1:, 8] - st[:-1, 8]))
+mean = lambda a: int(np.mean(a[5:60]))
+print("  MEANS  K: wait+fix", mean(st[:, 2] - st[:, 0]), " produce", mean(st[:, 1] - st[:, 2]), " step-to-step", mean(st[1:, 0] - st[:-1, 0]),
+      "| D: top", mean(st[:, 9] - st[:, 8]), " ring+detect", mean(st[:, 10] - st[:, 9]), " rows+stores", mean(st[:, 11] - st[:, 10]),
+      " publish(+ack wait)", mean(st[:, 12] - st[:, 11]), " step-to-step", mean(st[1:, 8] - st[:-1, 8]))
+kw = st[5:60, 2] - st[5:60, 0]
+print("  K wait+fix per step:", [int(v) for v in kw])
+dw = st[5:60, 10] - st[5:60, 9]
+print("  D ring+detect per step:", [int(v) for v in dw])
+dt = st[5:60, 9] - st[5:60, 8]
+print("  D top per step:", [int(v) for v in dt])
+dp = st[5:60, 12] - st[5:60, 11]
+print("  D publish per step:", [int(v) for v in dp])

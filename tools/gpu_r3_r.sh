@@ -1,0 +1,12 @@
+#!/bin/bash
+set -u
+R="${GRAFT_REPO_ROOT:?}"
+cd "$R"
+for rep in 1 2; do for v in BASE NOTOPUP NORESET NOTOPUP_NORESET; do
+  COOPSEARCH_LIB=$R/build/var/abl_$v.so python tools/oct_sweep.py --n 3 --batches 4096 --kernels od --reps 10 --tag $v-T100 2>/dev/null
+  COOPSEARCH_LIB=$R/build/var/abl_$v.so python tools/oct_sweep.py --n 3 --batches 4096 --kernels od --T 20 --reps 40 --tag $v-T20 2>/dev/null
+done; done | python -c "
+import sys, json
+for ln in sys.stdin:
+    d = json.loads(ln); print(d['tag'], d['us_per_step'], '%.3e' % d['env_steps_per_s'])
+"
