@@ -72,7 +72,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads reported under 'also'")
-    ap.add_argument("--kernel", default="auto", choices=["auto", "group", "solo", "duo", "od", "oct", "lane"],
+    ap.add_argument("--kernel", default="auto", choices=["auto", "group", "solo", "duo", "od", "ode", "oct", "lane"],
                     help="flight_easy kernel: 16 lanes per env (solo / duo wavefront roles, or chosen by batch), 8 lanes per env "
                          "(od: kinematics + detection wavefront pair, oct: one wavefront), one lane per env, or everything by "
                          "batch size (auto: od up to 16384 envs, oct below 131072, lane from there)")
@@ -153,6 +153,8 @@ def kernel_label(env_name, n, B, mode, kernel):
         return f"k_rollout_lane<{n}>"
     if mode == "step":
         return f"k_step<{n},0>"
+    if kernel == "ode" or (kernel == "auto" and B <= 8192):       # CS_ODE_UPTO: K + D + emitting wavefront per 8 envs
+        return f"k_rollout_od<{n},E>"
     if kernel == "od" or (kernel == "auto" and B <= 16384):      # CS_OD_UPTO
         return f"k_rollout_od<{n}>"
     if kernel == "oct" or kernel == "auto":                         # CS_OCT_FROM < B < CS_LANE_FROM

@@ -883,11 +883,18 @@ __device__ __forceinline__ void start_pose(const DevParams &p, int i, double &x,
 #ifdef CS_TIMELINE
 __device__ unsigned long long g_blk[1024][8];   // per workgroup: K entry / loop / loop end / exit, D the same
 #define BLK_STAMP(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) g_blk[blockIdx.x][k] = __builtin_readcyclecounter(); } while (0)
+__device__ unsigned g_spin[1024][4];   // per workgroup: polls K / D / E spent waiting for the other side
+#define SPIN_DECL unsigned spin_count = 0
+#define SPIN_TICK (++spin_count)
+#define SPIN_STORE(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) g_spin[blockIdx.x][k] = spin_count; } while (0)
 extern __device__ unsigned long long g_stamps[64][16];
 #define RT_STAMP(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_stamps[63][3 + (k)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define RT_STAMP(k) do {} while (0)
 #define BLK_STAMP(k) do {} while (0)
+#define SPIN_DECL do {} while (0)
+#define SPIN_TICK ((void)0)
+#define SPIN_STORE(k) do {} while (0)
 #endif
 // Target placement of a reset (flight_env_easy.py:95-134) for the env whose 16-lane group this is: lane t gets target t's
 // position in (mx, my); the env's MT19937 cursor / word count / pre-twisted count advance by what the reference's
@@ -1908,6 +1915,9 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io
 #define CS_LANE_FROM 131072     /* default kernel of cs_rollout from this many envs: one env per lane (65536: octet 7.6e9
                                    against lane 7.1e9 env-steps/s at 3 agents, 5.0e9 against 4.8e9 at 5; 262144: 8.0 / 10.4) */
 #endif
+#ifndef CS_ODE_UPTO
+#define CS_ODE_UPTO 8192        /* ... up to this many envs with the third (emitting) wavefront: five 3-wavefront workgroups per CU */
+#endif
 #ifndef CS_OD_UPTO
 #define CS_OD_UPTO 16384        /* cs_rollout up to this many envs: the octet pair kernel */
 #endif
@@ -2913,12 +2923,13 @@ __device__ __forceinline__ void start_pick(const StartTab<N> &st, int i, double 
 // e.ty, the state blob and (normalised, found = 0) the env's get_state row in `tile`; each env's stream cursor, word count,
 // twisted-ahead count and hit tape advance by what the reference's sequential algorithm consumes.  One env per 16-lane
 // group and round (lane = polar attempt; `slots`: four rows of 16 positions, the hand-over from group to octet, free between
-// rounds); pre(w) may hand a group the four stream words of its FIRST batch (fetched ahead of time).
-template <int N, bool DRAIN, class Pre>
+// rounds); pre(w) may hand a group the four stream words of its FIRST batch (fetched ahead of time); before_tile() runs
+// before the first write to `tile`.
+template <int N, bool DRAIN, class BeforeTile, class Pre>
 __device__ __forceinline__ void oct_place_targets(const DevParams &cp, int wave_b0, int nvalid, int lane, bool live,
                                                   unsigned long long need, const double *rtab, double2 (*slots)[G], float *tile,
                                                   int W, unsigned *rowbuf, EnvO<N> &e, unsigned (&tape)[TAPE_DW], bool &tape_ok,
-                                                  Pre pre) {
+                                                  BeforeTile before_tile, Pre pre) {
     const CS_AS4 DevParams *q = cold_params4();
     const int t16 = lane & (G - 1), gshift16 = lane & ~(G - 1), grp = lane >> 4, sh8 = lane & ~(OG - 1), t = lane & (OG - 1);
     const int n_targets = q->n_targets, target_mode = q->target_mode;
@@ -3007,6 +3018,7 @@ __device__ __forceinline__ void oct_place_targets(const DevParams &cp, int wave_
             if (fin) {
                 typedef double v2d __attribute__((ext_vector_type(2)));
                 reinterpret_cast<CS_AS1 v2d *>(tgt + (size_t)br * G * 2)[t16] = v2d{mx, my};
+                before_tile();   // (the octet pair's emitting wavefront may still be reading the old rows)
                 if (t16 < n_targets) {
                     float *rs = tile + (src >> 3) * W + 4 * N + 3 * t16;
                     rs[0] = (float)((mx - mid) * inv_half);   // norm_target
@@ -3175,7 +3187,7 @@ __global__ __launch_bounds__(OCT_BLOCK, CS_OCT_WAVES) void k_rollout_oct(DevPara
             const bool mine = (need >> sh8) & 1ull;
             const StartTab<N> st = start_tab<N>();
             oct_place_targets<N, true>(cp, wave_b0, nvalid, lane, live, need, rtab, sh.tgt, sh.tile, W, sh.rowbuf, e, tape, tape_ok,
-                                       [](unsigned (&)[4]) { return false; });
+                                       []() {}, [](unsigned (&)[4]) { return false; });
             if (mine) {
                 e.episodes += 1;
                 e.found = 0;
@@ -3404,19 +3416,43 @@ __device__ __forceinline__ int lds_peek(const int *w) {
 #else
 #define OD_COLD() p
 #endif
-template <int N, bool VEC, bool EMIT>
-__global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams p, StepIO io) {
+// E3: a THIRD wavefront per 8 envs, E, owns the get_state tile and writes every output (reward, terminated, win, obs, state) --
+// a quarter of D's plain step.  D, which also carries every reset and row top-up, is the pair's slower half (K alone sustains
+// ~3500 cycles per step, D ~2650 + ~1450 of events); without the emission it has the slack to absorb its events.  D hands each
+// step's reward / terminated / win / found mask to E through a ring of OdOut records; E reads the agents' floats from K's
+// ring slot.  Three wavefronts of 128 VGPRs: five workgroups per CU, so this variant serves batches up to 8192 envs.
+struct __attribute__((aligned(16))) OdOut {
+    float reward[OCT_ENVS];
+    int term[OCT_ENVS], win[OCT_ENVS];
+    unsigned found[OCT_ENVS];
+};
+template <int N, bool VEC, bool EMIT, bool E3>
+__global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams p, StepIO io) {
+    static_assert(!E3 || (VEC && EMIT), "the emitting wavefront has the full-wavefront, obs + state stores only");
     __shared__ double T[TRIG_ROWS * TRIG_COLS];
     __shared__ OdShared sh;
+    __shared__ OdOut outs[E3 ? OD_RING : 1];
+    __shared__ int e_steps;   // E: steps written out so far
     const int lane = threadIdx.x & 63;
-    const bool is_k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0;
+    // Which wavefront of the workgroup plays which role decides who shares a SIMD: at 4096 envs a CU holds two workgroups,
+    // six wavefronts on four SIMDs, handed out in order -- wavefront 0 of one workgroup lands beside wavefront 1 of the other,
+    // wavefront 1 beside wavefront 2.  With E (busy a third of the time) in the middle, K and D -- the two full-time
+    // wavefronts -- only ever share with an E.  Measured (us per step, 100-step launches, 3 agents x 4096 envs): K,E,D 1.62;
+    // D,E,K 1.62; E,K,D 1.72; K,D,E 1.81; E,D,K 1.74; D,K,E 1.74.
+#ifndef CS_ODE_ROLES
+#define CS_ODE_ROLES 0x120   /* nibble w = role of wavefront w of the workgroup (0: K, 1: D, 2: E) */
+#endif
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int role = E3 ? (CS_ODE_ROLES >> (4 * wv)) & 15 : wv;   // 0: K, 1: D, 2: E
+    const bool is_k = role == 0;
+    SPIN_DECL;
     const int o = lane >> 3, sh8 = lane & ~(OG - 1);
     int t = lane & (OG - 1);   // (made opaque once per step: lane predicates are recomputed, not held in SGPR pairs)
     const int wave_b0 = io.env0 + blockIdx.x * OCT_ENVS;
     const int b_end = io.env0 + io.env_n;
     const int b = wave_b0 + o;
     const bool live = VEC || b < b_end;
-    BLK_STAMP(is_k ? 0 : 4);
+    if (role < 2) BLK_STAMP(is_k ? 0 : 4);
     const int nvalid = b_end - wave_b0 < OCT_ENVS ? b_end - wave_b0 : OCT_ENVS;   // >= 1: the grid covers env_n exactly
     const int W = 4 * N + 3 * p.n_targets;
     bool ag = t < N;
@@ -3552,7 +3588,9 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
             const int act_after = ap[0];
             if (s + 3 < io.T) ap += astep;
             // flow control: slot s % OD_RING is free once D has finished step s - OD_RING
-            while (peek(&sh.d_steps) <= s - OD_RING) {
+            // (E3: ... once E has written step s - OD_RING out; E never passes D)
+            while (peek(E3 ? &e_steps : &sh.d_steps) <= s - OD_RING) {
+                SPIN_TICK;
                 handle_fix(s);
                 __builtin_amdgcn_s_sleep(2);
             }
@@ -3565,6 +3603,7 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
             act_next = act_after;
         }
         BLK_STAMP(2);
+        SPIN_STORE(0);
         // D may still report an unpredicted termination of a step K has long left behind: stay until it has judged step T - 2
         // (the last one whose successor exists)
         while (peek(&sh.d_steps) < io.T - 1) {
@@ -3575,6 +3614,88 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
         if (live && ag)   // agents are K's part of the state
             reinterpret_cast<double4 *>(OD_COLD().agent + (size_t)b * CS_MAX_AGENTS * 4)[t] = make_double4(e.x, e.y, e.yaw, 0.0);
         BLK_STAMP(3);
+        return;
+    }
+
+    if (E3 && role == 2) {
+        // ------------------------------------------------------------------------------------------ E: emission
+        const double2 *t2 = reinterpret_cast<const double2 *>(p.tgt + bl * G * 2);
+        const double2 ta = t2[t], tb = t2[t + OG];
+        load_trig_to_lds(T);   // (K's table: E only joins the barrier; D zeroed the counters before it)
+        float *row = sh.tile + o * W;
+        // persistent rows: targets' normalised coordinates (rewritten by D when an env resets) and found flags (get_state, :190-216)
+        if (t < p.n_targets) {
+            row[4 * N + 3 * t + 0] = (float)((ta.x - p.mid) * p.inv_half);   // norm_target
+            row[4 * N + 3 * t + 1] = (float)((ta.y - p.mid) * p.inv_half);
+        }
+        if (t + OG < p.n_targets) {
+            row[4 * N + 3 * (t + OG) + 0] = (float)((tb.x - p.mid) * p.inv_half);
+            row[4 * N + 3 * (t + OG) + 1] = (float)((tb.y - p.mid) * p.inv_half);
+        }
+        auto peek = [](const int *w) __attribute__((always_inline)) { return lds_peek(w); };
+        constexpr int W_MAX = 4 * N + 3 * CS_MAX_TARGETS;
+        constexpr int Q = (OCT_ENVS * W_MAX / 4 + 63) / 64;   // float4 chunks per lane of the largest tile
+        const int ol = lane < OCT_ENVS * N ? lane : OCT_ENVS * N - 1;
+        const int orow = ol / N, oag = ol - orow * N;
+        const int obs_lds = orow * W + 4 * oag;
+        const int rtw = lane & 7;
+        float *p_rew = io.reward + wave_b0 + rtw;
+        uint8_t *p_term = io.terminated + wave_b0 + rtw, *p_win = io.win + wave_b0 + rtw;
+        v4f *p_obs = reinterpret_cast<v4f *>(io.obs + (size_t)wave_b0 * N * 4) + ol;
+        v4f *p_st = reinterpret_cast<v4f *>(io.state + (size_t)wave_b0 * W);
+        int chunk[Q];
+#pragma unroll
+        for (int q = 0; q < Q; q++) chunk[q] = lane + 64 * q < OCT_ENVS * W / 4 - 1 ? lane + 64 * q : OCT_ENVS * W / 4 - 1;
+        for (int s = 0; s < io.T; s++) {
+            asm volatile("" : "+v"(t));
+            ag = t < N;
+            while (peek(&sh.d_steps) <= s) { SPIN_TICK; __builtin_amdgcn_s_sleep(1); }   // D has judged step s: its record and K's slot are final
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const OdRing &r = sh.ring[s & (OD_RING - 1)];
+            const OdOut &d = outs[s & (OD_RING - 1)];
+            if (ag) {
+                const double2 xy = r.pos[o][t];
+                const float2 cs = r.cssn[o][t];
+                row[4 * t + 0] = (float)((xy.x - p.mid) * p.inv_half);
+                row[4 * t + 1] = (float)((xy.y - p.mid) * p.inv_half);
+                row[4 * t + 2] = cs.x;
+                row[4 * t + 3] = cs.y;
+            }
+            const unsigned found = d.found[o];
+            if (t < p.n_targets) row[4 * N + 3 * t + 2] = ((found >> t) & 1u) ? 1.0f : 0.0f;
+            if (t + OG < p.n_targets) row[4 * N + 3 * (t + OG) + 2] = ((found >> (t + OG)) & 1u) ? 1.0f : 0.0f;
+            const float o_rew = d.reward[rtw];
+            const int o_term = d.term[rtw], o_win = d.win[rtw];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            v4f o_obs, o_st[Q];
+            {
+                const float *src = sh.tile + obs_lds;
+                o_obs = v4f{src[0], src[1], src[2], src[3]};
+                const float4 *src4 = reinterpret_cast<const float4 *>(sh.tile);
+#pragma unroll
+                for (int q = 0; q < Q; q++) {
+                    const float4 v = src4[chunk[q]];
+                    o_st[q] = v4f{v.x, v.y, v.z, v.w};
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            *p_rew = o_rew;
+            *p_term = (uint8_t)o_term;
+            *p_win = (uint8_t)o_win;
+            p_rew += p.B;
+            p_term += p.B;
+            p_win += p.B;
+            __builtin_nontemporal_store(o_obs, p_obs);
+            p_obs += (size_t)p.B * N;
+#pragma unroll
+            for (int q = 0; q < Q; q++) __builtin_nontemporal_store(o_st[q], p_st + chunk[q]);
+            p_st += (size_t)p.B * W / 4;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (the tile reads above are complete: their values are in registers)
+            if (lane == 0) lds_post(&e_steps, s + 1);
+        }
+        SPIN_STORE(2);
         return;
     }
 
@@ -3595,6 +3716,7 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
         sh.fix_req = 0;
         sh.fix_ack = 0;
         sh.fix_mask = 0u;
+        e_steps = 0;
     }
     load_reset_tab(sh.rtab, lane);
     load_trig_to_lds(T);   // (K's table; D only joins its barrier -- after which K produces ahead, up to OD_RING steps)
@@ -3605,15 +3727,17 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
         if (t < p.n_targets) row[4 * N + 3 * t + 2] = ((e.found >> t) & 1u) ? 1.0f : 0.0f;
         if (t + OG < p.n_targets) row[4 * N + 3 * (t + OG) + 2] = ((e.found >> (t + OG)) & 1u) ? 1.0f : 0.0f;
     };
-    if (t < p.n_targets) {
-        row[4 * N + 3 * t + 0] = (float)((e.tx[0] - p.mid) * p.inv_half);   // norm_target
-        row[4 * N + 3 * t + 1] = (float)((e.ty[0] - p.mid) * p.inv_half);
+    if (!E3) {   // (E3: the tile is E's)
+        if (t < p.n_targets) {
+            row[4 * N + 3 * t + 0] = (float)((e.tx[0] - p.mid) * p.inv_half);   // norm_target
+            row[4 * N + 3 * t + 1] = (float)((e.ty[0] - p.mid) * p.inv_half);
+        }
+        if (t + OG < p.n_targets) {
+            row[4 * N + 3 * (t + OG) + 0] = (float)((e.tx[1] - p.mid) * p.inv_half);
+            row[4 * N + 3 * (t + OG) + 1] = (float)((e.ty[1] - p.mid) * p.inv_half);
+        }
+        put_found();
     }
-    if (t + OG < p.n_targets) {
-        row[4 * N + 3 * (t + OG) + 0] = (float)((e.tx[1] - p.mid) * p.inv_half);
-        row[4 * N + 3 * (t + OG) + 1] = (float)((e.ty[1] - p.mid) * p.inv_half);
-    }
-    put_found();
     auto peek = [](const int *w) __attribute__((always_inline)) { return lds_peek(w); };
     auto post = [&](int *w, int v) __attribute__((always_inline)) {   // (lds_post above: LDS-only ordering)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -3639,8 +3763,8 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
     // issued a few hundred cycles ago and take a memory round trip (measured: a plain vmcnt(0) here cost ~1000 cycles per event).
     constexpr int STEP_STORES = 3 + 1 + (OCT_ENVS * (4 * N + 3 * CS_MAX_TARGETS) / 4 + 63) / 64;   // reward, terminated, win, obs, Q state chunks (EMIT && VEC: exactly these)
     auto wait_for_requests = [&]() __attribute__((always_inline)) {
-        if (EMIT && VEC && STEP_STORES <= 15) __builtin_amdgcn_s_waitcnt(0x0F70 | STEP_STORES);   // vmcnt(STEP_STORES)
-        else drain_vmem();
+        if (!E3 && EMIT && VEC && STEP_STORES <= 15) __builtin_amdgcn_s_waitcnt(0x0F70 | STEP_STORES);   // vmcnt(STEP_STORES)
+        else drain_vmem();   // (E3: D stores nothing per step)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
     int cand = -1;                       // env (octet) of the wavefront whose row is on its way into sh.rowbuf
@@ -3686,7 +3810,14 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
             const bool mine = (need >> sh8) & 1ull;
             const StartTab<N> st = start_tab<N>();
             // round 0's attempt batches were requested when the envs' steps terminated (same mask -> same groups)
+            // (E3: the tile still holds the rows of step s - 1 until E has written them out: the new targets wait for that)
             oct_place_targets<N, CS_OD_DRAIN != 0>(cp, wave_b0, nvalid, lane, live, need, sh.rtab, sh.tgt, sh.tile, W, sh.rowbuf, e, tape, tape_ok,
+                                                   [&]() __attribute__((always_inline)) {
+                                                       if (E3) {
+                                                           while (lds_peek(&e_steps) < s) __builtin_amdgcn_s_sleep(1);
+                                                           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                                                       }
+                                                   },
                                                    [&](unsigned (&w)[4]) __attribute__((always_inline)) {
                                                        const bool ok = CS_OD_ASYNC && need == pre_need && ((pre_valid >> grp) & 1u);
                                                        if (ok) {
@@ -3726,7 +3857,7 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
             }
             if (__ballot(mine && near)) {
                 oct_detect<N>(p, sh.dpos, o, t, sh8, mine, e, tape);
-                put_found();
+                if (!E3) put_found();
             } else if (mine) {   // what the pass does when no pair is in range: no draw, reward -1
                 e.newly = 0u;
                 e.curr_reward = -1;
@@ -3738,7 +3869,7 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
         const bool stepping = live && !(done && freeze);
         DUO_STAMP(9);
         // ---- K's step s (normally produced long ago): out flags, the agents' four floats (get_obs / get_state), positions
-        while (peek(&sh.k_steps) <= s) __builtin_amdgcn_s_sleep(1);
+        while (peek(&sh.k_steps) <= s) { SPIN_TICK; __builtin_amdgcn_s_sleep(1); }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #ifdef CS_OD_ABL_NODET   /* experiment: what K alone sustains */
         post(&sh.d_steps, s + 1);
@@ -3746,7 +3877,7 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
 #endif
         const OdRing &r = sh.ring[s & (OD_RING - 1)];
         if (live) e.flags = (e.flags & ~0xff00) | (int)(r.out[o] << 8);
-        if (ag) {
+        if (!E3 && ag) {
             const double2 xy = r.pos[o][t];
             const float2 cs = r.cssn[o][t];
             row[4 * t + 0] = (float)((xy.x - p.mid) * p.inv_half);
@@ -3771,24 +3902,39 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
             if (lane == 0) sh.fix_mask = m8;
             post(&sh.fix_req, s + 1);
         }
-        if (__ballot(stepping && e.newly != 0u)) put_found();   // wave-uniform: some env found a target in this step
-        if (t == 0) {
-            sh.reward[o] = (float)reward;
-            sh.term[o] = term ? 1 : 0;
-            sh.win[o] = (e.flags & FLAG_WIN) ? 1 : 0;
+        if (E3) {   // this step's record for E (published with d_steps below)
+            if (t == 0) {
+                OdOut &d = outs[s & (OD_RING - 1)];
+                d.reward[o] = (float)reward;
+                d.term[o] = term ? 1 : 0;
+                d.win[o] = (e.flags & FLAG_WIN) ? 1 : 0;
+                d.found[o] = e.found;
+            }
+        } else {
+            if (__ballot(stepping && e.newly != 0u)) put_found();   // wave-uniform: some env found a target in this step
+            if (t == 0) {
+                sh.reward[o] = (float)reward;
+                sh.term[o] = term ? 1 : 0;
+                sh.win[o] = (e.flags & FLAG_WIN) ? 1 : 0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // ---- this step's outputs (all LDS reads first, then the stores)
-        const float o_rew = sh.reward[rtw];   // duplicates write the same value
-        const int o_term = sh.term[rtw], o_win = sh.win[rtw];
+        float o_rew = 0.f;
+        int o_term = 0, o_win = 0;
+        if (!E3) {
+            o_rew = sh.reward[rtw];   // duplicates write the same value
+            o_term = sh.term[rtw];
+            o_win = sh.win[rtw];
+        }
         v4f o_obs = {0.f, 0.f, 0.f, 0.f}, o_st[Q];
-        if (EMIT || io.obs) {
+        if (!E3 && (EMIT || io.obs)) {
             const float *src = sh.tile + obs_lds;
             o_obs = v4f{src[0], src[1], src[2], src[3]};
         }
-        if (VEC && (EMIT || io.state)) {
+        if (!E3 && VEC && (EMIT || io.state)) {
             const float4 *src4 = reinterpret_cast<const float4 *>(sh.tile);
 #pragma unroll
             for (int q = 0; q < Q; q++) {
@@ -3832,17 +3978,19 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
                             ((unsigned)((vb >> 48) & 1ull) << 3);
             }
         }
-        *p_rew = o_rew;
-        *p_term = (uint8_t)o_term;
-        *p_win = (uint8_t)o_win;
-        p_rew += p.B;
-        p_term += p.B;
-        p_win += p.B;
-        if (EMIT || io.obs) {   // one float4 per (env, agent)
+        if (!E3) {
+            *p_rew = o_rew;
+            *p_term = (uint8_t)o_term;
+            *p_win = (uint8_t)o_win;
+            p_rew += p.B;
+            p_term += p.B;
+            p_win += p.B;
+        }
+        if (!E3 && (EMIT || io.obs)) {   // one float4 per (env, agent)
             __builtin_nontemporal_store(o_obs, p_obs);
             p_obs += (size_t)p.B * N;
         }
-        if (EMIT || io.state) {
+        if (!E3 && (EMIT || io.state)) {
             if (VEC) {
 #pragma unroll
                 for (int q = 0; q < Q; q++) __builtin_nontemporal_store(o_st[q], p_st + chunk[q]);
@@ -3860,6 +4008,7 @@ __global__ __launch_bounds__(OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams 
         DUO_STAMP(12);
     }
     BLK_STAMP(6);
+    SPIN_STORE(1);
     if (live) {   // header, cursor and tape are D's part of the state; targets were stored at each reset
         const DevParams &cp = OD_COLD();
         if (t == 0) {
@@ -4457,13 +4606,16 @@ void launch_od(const cs_config *cfg, const DevParams &p, StepIO io, hipStream_t 
         io.env0 = 0;
         io.env_n = full;
         const dim3 grid((unsigned)(full / OCT_ENVS));
-        if (io.obs && io.state) hipLaunchKernelGGL((k_rollout_od<N, true, true>), grid, dim3(OD_BLOCK), 0, s, p, io);
-        else hipLaunchKernelGGL((k_rollout_od<N, true, false>), grid, dim3(OD_BLOCK), 0, s, p, io);
+        // three wavefronts per 8 envs (K, D and the emitting E) while five such workgroups per CU hold the batch in one round
+        const bool e3 = (io.flags & CS_KERNEL_ODE) || (!(io.flags & CS_KERNEL_OD) && p.B <= CS_ODE_UPTO);
+        if (io.obs && io.state && e3) hipLaunchKernelGGL((k_rollout_od<N, true, true, true>), grid, dim3(OD_BLOCK + 64), 0, s, p, io);
+        else if (io.obs && io.state) hipLaunchKernelGGL((k_rollout_od<N, true, true, false>), grid, dim3(OD_BLOCK), 0, s, p, io);
+        else hipLaunchKernelGGL((k_rollout_od<N, true, false, false>), grid, dim3(OD_BLOCK), 0, s, p, io);
     }
     if (p.B - full > 0) {   // the tail (or an unaligned output tensor): plain stores, runtime checks
         io.env0 = full;
         io.env_n = p.B - full;
-        hipLaunchKernelGGL((k_rollout_od<N, false, false>), dim3((unsigned)((p.B - full + OCT_ENVS - 1) / OCT_ENVS)), dim3(OD_BLOCK), 0, s, p, io);
+        hipLaunchKernelGGL((k_rollout_od<N, false, false, false>), dim3((unsigned)((p.B - full + OCT_ENVS - 1) / OCT_ENVS)), dim3(OD_BLOCK), 0, s, p, io);
     }
 }
 // Kernel choice for flight_easy: one env per 16-lane group (lowest latency, fills the chip from B = 4096) or one
@@ -4471,19 +4623,19 @@ void launch_od(const cs_config *cfg, const DevParams &p, StepIO io, hipStream_t 
 inline bool use_lane_kernel(const cs_config *c, int flags, bool rollout) {
     if (flags & CS_KERNEL_LANE) return true;
     if (flags & CS_KERNEL_GROUP) return false;
-    if (rollout && (flags & (CS_KERNEL_OCT | CS_KERNEL_OD))) return false;
+    if (rollout && (flags & (CS_KERNEL_OCT | CS_KERNEL_OD | CS_KERNEL_ODE))) return false;
     // single steps have no octet variant: the lane kernel takes over from the 16-lane step kernel at 32768 envs as before
     return c->batch >= (rollout ? CS_LANE_FROM : 32768);
 }
 // cs_rollout: the octet kernel (one env per 8 lanes) between the pair kernel's range and the lane kernel's
 inline bool use_oct_kernel(const cs_config *c, int flags) {
     if (flags & CS_KERNEL_OCT) return true;
-    if (flags & (CS_KERNEL_GROUP | CS_KERNEL_LANE | CS_KERNEL_SOLO | CS_KERNEL_DUO | CS_KERNEL_OD)) return false;
+    if (flags & (CS_KERNEL_GROUP | CS_KERNEL_LANE | CS_KERNEL_SOLO | CS_KERNEL_DUO | CS_KERNEL_OD | CS_KERNEL_ODE)) return false;
     return c->batch > CS_OCT_FROM && c->batch < CS_LANE_FROM;
 }
 // cs_rollout: the octet PAIR kernel (kinematics wavefront + detection wavefront per 8 envs)
 inline bool use_od_kernel(const cs_config *c, int flags) {
-    if (flags & CS_KERNEL_OD) return true;
+    if (flags & (CS_KERNEL_OD | CS_KERNEL_ODE)) return true;
     if (flags & (CS_KERNEL_GROUP | CS_KERNEL_LANE | CS_KERNEL_SOLO | CS_KERNEL_DUO | CS_KERNEL_OCT)) return false;
     return c->batch <= CS_OD_UPTO;
 }
@@ -4818,6 +4970,10 @@ int cs_metrics(const cs_config *cfg, void *state_dev, double *out4_dev, void *st
 }
 
 #ifdef CS_TIMELINE
+int cs_debug_read_spin(unsigned *host1024x4) {
+    hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(host1024x4, HIP_SYMBOL(g_spin), sizeof(unsigned) * 1024 * 4);
+}
 int cs_debug_read_blk(unsigned long long *host1024x8) {
     hipDeviceSynchronize();
     return (int)hipMemcpyFromSymbol(host1024x8, HIP_SYMBOL(g_blk), sizeof(unsigned long long) * 1024 * 8);

@@ -70,10 +70,11 @@ class BatchedFlightEnv:
                 rollout picks between "solo" -- one wavefront per four envs does the whole step -- and "duo" -- a
                 kinematics wavefront and a detection wavefront per four envs, for batches that leave a wave slot per
                 SIMD empty), "oct" (rollout only: 8 lanes per env, lane t owns agent t and targets t, t + 8), "od"
-                (rollout only: the octet layout with a kinematics wavefront running one step ahead of a detection
-                wavefront), "lane" (one env per lane: no replicated arithmetic, for large batches) or "auto" (rollout:
-                "od" up to 16384 envs, "oct" below 131072, "lane" from there; single steps: the 16-lane step kernel,
-                "lane" from 32768).  All produce bit-identical results.
+                (rollout only: the octet layout with a kinematics wavefront running steps ahead of a detection
+                wavefront), "ode" ("od" with a third wavefront per 8 envs that writes the outputs), "lane" (one env per
+                lane: no replicated arithmetic, for large batches) or "auto" (rollout: "ode" up to 8192 envs, "od" up to
+                16384, "oct" below 131072, "lane" from there; single steps: the 16-lane step kernel, "lane" from 32768).
+                All produce bit-identical results.
     step_advance  step(): refresh the hit tapes every STEP_ADVANCE_EVERY single steps (default).  False leaves every
                 MT19937 word to be twisted on demand by the step kernel itself -- same results, one more dependent load per
                 launch.
@@ -134,8 +135,8 @@ class BatchedFlightEnv:
             self._state = torch.zeros(B, self.state_shape, dtype=torch.float32, device=self.device)
             self._avail = torch.ones(B, self.n_actions, dtype=torch.float32, device=self.device)
             self._metrics = torch.zeros(4, dtype=torch.float64, device=self.device)
-        if kernel not in ("auto", "group", "lane", "solo", "duo", "oct", "od"):
-            raise ValueError("kernel must be 'auto', 'group', 'lane', 'solo', 'duo', 'oct' or 'od'")
+        if kernel not in ("auto", "group", "lane", "solo", "duo", "oct", "od", "ode"):
+            raise ValueError("kernel must be 'auto', 'group', 'lane', 'solo', 'duo', 'oct', 'od' or 'ode'")
         self.kernel = kernel
         self.freeze_done = bool(freeze_done)
         self.auto_reset = bool(auto_reset)
@@ -267,6 +268,8 @@ class BatchedFlightEnv:
             f |= _lib.KERNEL_OCT
         elif self.kernel == "od":    # rollout(): the octet layout, kinematics and detection wavefronts pipelined
             f |= _lib.KERNEL_OD
+        elif self.kernel == "ode":   # ... plus an emitting wavefront
+            f |= _lib.KERNEL_ODE
         return f
 
     def step(self, actions, out=None):

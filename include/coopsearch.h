@@ -68,8 +68,10 @@ enum {
     CS_KERNEL_OCT = 128, /* cs_rollout, flight_easy: force the 8-lanes-per-env kernel (lane t owns agent t and targets t, t + 8;
                             nothing replicated but the header: four and more wavefronts per SIMD -- the default between
                             the pair kernel's range and the lane kernel's); same results */
-    CS_KERNEL_OD = 256   /* cs_rollout, flight_easy: force the octet PAIR kernel (the 8-lane layout with a kinematics wavefront
-                            running one step ahead of a detection wavefront, per 8 envs); same results */
+    CS_KERNEL_OD = 256,  /* cs_rollout, flight_easy: force the octet PAIR kernel (the 8-lane layout with a kinematics wavefront
+                            running steps ahead of a detection wavefront, per 8 envs); same results */
+    CS_KERNEL_ODE = 512  /* ... with a third wavefront per 8 envs that writes the outputs (default up to 8192 envs when obs
+                            and state are both requested); same results */
 };
 
 /* Environment constants: common/arguments.py:27-34 (map_size, target_num, target_mode, agent_mode, n_agents,

@@ -273,7 +273,7 @@ def test_flight_fused_auto_reset_matches_oracle(n, agent_mode):
         assert hdr(env)[:, _lib.H_EPISODES].min() >= 4
 
 
-@pytest.mark.parametrize("kernel", ["oct", "od"])
+@pytest.mark.parametrize("kernel", ["oct", "od", "ode"])
 @pytest.mark.parametrize("variant,n,agent_mode,target_mode,B,T,kw", [
     ("flight_easy", 3, 0, 0, 509, 230, {}),                    # 509 = 63 full octet wavefronts' worth + a tail of 5 envs
     ("flight_easy", 5, 0, 0, 256, 230, {}),
@@ -330,7 +330,7 @@ def test_octet_rollout_matches_oracle_bit_exact(variant, n, agent_mode, target_m
         assert hdr(env)[:, _lib.H_EPISODES].min() >= 2
 
 
-@pytest.mark.parametrize("kernel", ["group", "solo", "duo", "lane", "oct", "od"])
+@pytest.mark.parametrize("kernel", ["group", "solo", "duo", "lane", "oct", "od", "ode"])
 def test_rollout_kernel_equals_stepwise(kernel):
     B, n, T = 1000, 3, 200   # not a multiple of 64: exercises the partial last wavefront
     args = cs.make_env_args("flight_easy", n_agents=n)
@@ -682,7 +682,7 @@ def test_flight_rollout_call_equals_stepwise(B, n, T):
         assert torch.equal(r1[k], r2[k]), k
 
 
-@pytest.mark.parametrize("kernel", ["group", "solo", "duo", "lane", "oct", "od"])
+@pytest.mark.parametrize("kernel", ["group", "solo", "duo", "lane", "oct", "od", "ode"])
 def test_long_horizon_matches_oracle(kernel):
     """20 000 steps per env with auto-reset: ~100+ episodes, the circular MT19937 state wraps ~70 times (cursor,
     mirrored head, reset-time batches landing anywhere in the ring).  Rewards are compared every step (in rollout

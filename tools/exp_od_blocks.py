@@ -17,7 +17,7 @@ a = ap.parse_args()
 L = _lib.load()
 L.cs_debug_read_blk.argtypes = [C.c_void_p]
 dev = torch.device("cuda", 0)
-env = cs.BatchedFlightEnv(cs.make_env_args("flight_easy", n_agents=a.n), batch=a.B, device=dev, freeze_done=False, auto_reset=True, kernel="od")
+env = cs.BatchedFlightEnv(cs.make_env_args("flight_easy", n_agents=a.n), batch=a.B, device=dev, freeze_done=False, auto_reset=True, kernel=os.environ.get("KERNEL", "ode"))
 acts = torch.randint(0, 3, (a.T, a.B, a.n), dtype=torch.int32, device=dev)
 out = env.rollout(acts, update_views=False)
 nb = a.B // 8
@@ -41,4 +41,9 @@ for rep in range(a.reps):
     print("   loop:                                 K", q(k2 - k1), "  D", q(d2 - d1))
     print("   epilogue (loop end -> exit):          K", q(k3 - k2), "  D", q(d3 - d2))
     print("   exit after first entry:               K", q(k3), "  D", q(d3))
+    sp = (C.c_uint * (1024 * 4))()
+    L.cs_debug_read_spin.argtypes = [C.c_void_p]
+    assert L.cs_debug_read_spin(sp) == 0
+    spn = np.frombuffer(sp, dtype=np.uint32).reshape(1024, 4)[:nb]
+    print("   polls spent waiting per launch (p10 med max):  K for a slot", q(spn[:, 0]), "  D for K", q(spn[:, 1]), "  E for D", q(spn[:, 2]))
     print("   D loop of the slowest / median workgroup per step:", (d2 - d1).max() // a.T, int(np.median(d2 - d1)) // a.T)

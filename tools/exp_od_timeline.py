@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import cooperative_search_amd as cs
 n, B, T = int(os.environ.get("N", 3)), int(os.environ.get("B", 4096)), 64
-env = cs.BatchedFlightEnv(cs.make_env_args("flight_easy", n_agents=n), batch=B, freeze_done=False, auto_reset=True, kernel="od")
+env = cs.BatchedFlightEnv(cs.make_env_args("flight_easy", n_agents=n), batch=B, freeze_done=False, auto_reset=True, kernel=os.environ.get("KERNEL", "ode"))
 acts = torch.randint(0, 3, (T, B, n), dtype=torch.int32, device="cuda")
 out = env.rollout(acts); out = env.rollout(acts, out=out, update_views=False)
 torch.cuda.synchronize()

@@ -3,8 +3,8 @@ set -u
 R="${GRAFT_REPO_ROOT:?}"
 cd "$R"
 for rep in 1 2; do for v in ${VARIANTS:-BASE RING2 RING8}; do
-  COOPSEARCH_LIB=$R/build/var/abl_$v.so python tools/oct_sweep.py --n 3 --batches 4096 --kernels od --reps 10 --tag $v-T100 2>/dev/null
-  COOPSEARCH_LIB=$R/build/var/abl_$v.so python tools/oct_sweep.py --n 3 --batches 4096 --kernels od --T 20 --reps 40 --tag $v-T20 2>/dev/null
+  COOPSEARCH_LIB=$R/build/var/abl_$v.so python tools/oct_sweep.py --n 3 --batches 4096 --kernels ${KERNEL:-od} --reps 10 --tag $v-T100 2>/dev/null
+  COOPSEARCH_LIB=$R/build/var/abl_$v.so python tools/oct_sweep.py --n 3 --batches 4096 --kernels ${KERNEL:-od} --T 20 --reps 40 --tag $v-T20 2>/dev/null
 done; done | grep '^{"tag' | python3 -c "
 import sys, json
 for ln in sys.stdin:

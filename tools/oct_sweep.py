@@ -20,6 +20,7 @@ ap.add_argument("--kernels", default="duo,solo,oct,lane")
 ap.add_argument("--T", type=int, default=100)
 ap.add_argument("--reps", type=int, default=6)
 ap.add_argument("--tag", default=os.environ.get("COOPSEARCH_LIB", "in-tree"))
+ap.add_argument("--detect-prob", type=float, default=None, help="override detect_prob (0: no target is ever found -> no wins)")
 ap.add_argument("--no-reset", action="store_true", help="done envs keep stepping (no auto-reset): what the resets cost at run time")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -28,7 +29,10 @@ for n in [int(v) for v in a.n.split(",")]:
         for kernel in a.kernels.split(","):
             if kernel in ("duo", "solo", "od") and B > 65536:
                 continue
-            env = cs.BatchedFlightEnv(cs.make_env_args("flight_easy", n_agents=n), batch=B, device=dev, freeze_done=False,
+            eargs = cs.make_env_args("flight_easy", n_agents=n)
+            if a.detect_prob is not None:
+                eargs.detect_prob = a.detect_prob
+            env = cs.BatchedFlightEnv(eargs, batch=B, device=dev, freeze_done=False,
                                       auto_reset=not a.no_reset, kernel=kernel)
             acts = torch.randint(0, 3, (a.T, B, n), dtype=torch.int32, device=dev)
             out = env.rollout(acts, update_views=False)
