@@ -5,7 +5,7 @@ import warnings
 
 from . import build as _build
 
-ABI_VERSION = 4   # CS_ABI_VERSION of include/coopsearch.h; bumped whenever an export or a struct changes
+ABI_VERSION = 5   # CS_ABI_VERSION of include/coopsearch.h; bumped whenever an export or a struct changes
 MT_STRIDE = 672    # CS_MT_STRIDE
 MAX_AGENTS = 8
 MAX_TARGETS = 16

@@ -32,8 +32,8 @@
 extern "C" {
 #endif
 
-#define CS_ABI_VERSION 4   /* 2: cs_layout.ahead_off (pre-twisted MT words), cs_mt_canonical; 3: cs_layout.job_off;
-                              4: cs_source_hash, CS_KERNEL_OCT */
+#define CS_ABI_VERSION 5   /* 2: cs_layout.ahead_off (pre-twisted MT words), cs_mt_canonical; 3: cs_layout.job_off;
+                              4: cs_source_hash, CS_KERNEL_OCT; 5: CS_KERNEL_ODE */
 #define CS_MAX_AGENTS 8
 #define CS_MAX_TARGETS 16
 #define CS_MAX_MAP 64

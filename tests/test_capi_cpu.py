@@ -33,7 +33,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert set(syms) == set(_lib.EXPORTS), (syms, _lib.EXPORTS)
     for s in syms:
         assert hasattr(L, s), s
-    assert L.cs_abi_version() == _lib.ABI_VERSION == 4
+    assert L.cs_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_staleness_is_decided_by_source_content_not_mtime(tmp_path, monkeypatch):

@@ -1,12 +1,13 @@
 """Batch sweep of the flight_easy rollout kernels (SURVEY.md section 8d asks for 2^12..2^22): env-steps/s and the
-algorithmic-bytes roofline fraction per batch size: the 16-lane kernels of rounds 1-2 (solo / duo), the octet kernels (od: pair
-of wavefronts per 8 envs, oct: one wavefront per 8 envs) and the lane kernel.  Writes a markdown table."""
+algorithmic-bytes roofline fraction per batch size: the 16-lane kernels of rounds 1-2 (solo / duo), the octet kernels (ode:
+kinematics, detection and emitting wavefront per 8 envs; od: kinematics and detection wavefront; oct: one wavefront per 8 envs)
+and the lane kernel.  Writes a markdown table."""
 import json, subprocess, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rows = []
 for n in (3, 5):
     for B in (1024, 2048, 4096, 8192, 16384, 32768, 65536, 262144, 1048576, 4194304):
-        for kernel in ("solo", "duo", "od", "oct", "lane"):
+        for kernel in ("solo", "duo", "ode", "od", "oct", "lane"):
             if kernel == "lane" and B in (2048, 8192):
                 continue
             if kernel in ("solo", "duo") and B > (1 << 16):
@@ -14,6 +15,8 @@ for n in (3, 5):
             if kernel in ("od", "oct") and B > (1 << 20):
                 continue
             if kernel == "duo" and B > (1 << 14):
+                continue
+            if kernel == "ode" and B > (1 << 15):
                 continue
             steps = 40 if B >= (1 << 22) else (400 if B >= (1 << 18) else 1000)   # 2^22: the output tables of 100 steps would not fit
             out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-also",

@@ -17,10 +17,12 @@ raw = json.load(open(raw_path))
 # (bench label @ steps per launch, workload tag, kernels, steps per launch of that pass): bench.py only uses an entry for
 # a run with the SAME number of steps per launch (prologue traffic per env-step depends on the launch length)
 LABELS = [
-    ("k_rollout_od<3>@100", "c2_rollout", ["k_rollout_od<3, true, true>"], 100),
-    ("k_rollout_od<3>@20", "c2_rollout20", ["k_rollout_od<3, true, true>"], 20),
+    ("k_rollout_od<3,E>@100", "c2_rollout", ["k_rollout_od<3, true, true, true>"], 100),
+    ("k_rollout_od<3,E>@20", "c2_rollout20", ["k_rollout_od<3, true, true, true>"], 20),
     ("k_step<3,0>@1", "c2_step", ["k_step<3, 0>"], 1),
-    ("k_rollout_od<5>@100", "c3_rollout", ["k_rollout_od<5, true, true>"], 100),
+    ("k_rollout_od<5>@100", "c3_rollout", ["k_rollout_od<5, true, true, false>"], 100),
+    ("k_rollout_od<5,E>@100", "c5_rollout", ["k_rollout_od<5, true, true, true>"], 100),
+    ("k_rollout_od<3>@100", "od3_16384", ["k_rollout_od<3, true, true, false>"], 100),
     ("k_rollout_oct<3>@100", "oct3_32768", ["k_rollout_oct<3, true, true>"], 100),
     ("k_rollout_oct<5>@100", "oct5_32768", ["k_rollout_oct<5, true, true>"], 100),
     ("k_rollout_lane<5>@100", "c5s_rollout", ["k_rollout_lane<5, true>", "k_rollout_lane<5, false>"], 100),
