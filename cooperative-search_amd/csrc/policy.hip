@@ -231,41 +231,47 @@ struct ConvParams {
     float *feat;                                   // [n_maps][16]
 };
 
-// four workgroups per CU (<= 128 VGPRs, 20 bytes of scratch) instead of three: 46 -> 44 us at 8192 maps
+// Round 3: register-tiled.  The first version computed one output position per thread and pass and read every tap from LDS
+// on its own: 16 ds_read_b32 per conv1 position, 36 per conv2 position, 36 strided ones per thread in the linear layer --
+// ~40 000 LDS instructions per map against ~33 000 packed FMAs, LDS-issue bound at 25 TFLOP/s.  Now a thread owns a STRIP of
+// three horizontally adjacent outputs (24 x 8 = 192 strips: one pass) and fetches the strip's input window in wide reads
+// (conv1: 4 rows x 8 floats as float2; conv2: conv1's four channels interleaved per position as {c0, c2, c1, c3}, so one
+// ds_read_b64 brings the channel pair a packed FMA consumes); conv2's output is stored transposed ((pos % 16) * 36 + pos / 16)
+// so that the linear layer's 36 terms of a thread are contiguous (9 float4).  Every output's FMA chain -- taps in the same
+// order, the same channel pairing, the same butterfly -- is unchanged: the features are bit-identical to the first version's.
+// four workgroups per CU (<= 128 VGPRs)
 __global__ __launch_bounds__(PBLOCK, 4) void k_conv_features(ConvParams p) {
-    __shared__ float s_map[MAPW * MAPW];
-    __shared__ float s_c1[C1CH][C1P * C1P];   // conv1 output with the zero border conv2's padding needs
-    __shared__ float s_c2[NPOS];
-    const int t = threadIdx.x;
-    // two output channels (conv1) / two input channels (conv2) / two terms (linear) per v_pk_fma_f32
     using v2f = __attribute__((ext_vector_type(2))) float;
+    __shared__ __attribute__((aligned(16))) float s_map[MAPW * MAPW];
+    __shared__ __attribute__((aligned(16))) float s_c1[C1P * C1P * C1CH];   // [26 x 26] x {c0, c2, c1, c3}, zero border (conv2's padding)
+    __shared__ __attribute__((aligned(16))) float s_c2[NPOS];               // transposed: element pos at (pos % 16) * 36 + pos / 16
+    const int t = threadIdx.x;
     static_assert(C1CH == 4, "channel pairs (0,1) and (2,3)");
-    v2f w1[2][16], bias1[2], w2[2][9];
+    static_assert(PBLOCK >= 192 && C1W % 3 == 0, "one strip of three outputs per thread");
+    // 105 uniform weights do not fit the ~100 SGPRs a wavefront has, and VGPRs are short too (36 linear weights per thread are
+    // resident): conv2's 37 stay scalar, conv1's 64 sit in LDS as channel pairs and are read where they are used (one
+    // address for the whole wavefront: a broadcast read)
+    __shared__ v2f s_w1[2][16];
+    v2f bias1[2], w2[2][9];
     float bias2;
+    if (t < 32) s_w1[t >> 4][t & 15] = v2f{p.c1w[(2 * (t >> 4)) * 16 + (t & 15)], p.c1w[(2 * (t >> 4) + 1) * 16 + (t & 15)]};
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) w1[h][i] = v2f{p.c1w[(2 * h) * 16 + i], p.c1w[(2 * h + 1) * 16 + i]};
-        bias1[h] = v2f{p.c1b[2 * h], p.c1b[2 * h + 1]};
-    }
-    // 105 uniform weights do not fit the ~100 SGPRs a wavefront has: conv2's 37 are parked in VGPRs (the copy through
-    // inline asm keeps the compiler from treating them as scalars again), conv1's 68 stay scalar
-    auto to_vgpr = [](float sv) {
-        float vv;
-        asm volatile("v_mov_b32 %0, %1" : "=v"(vv) : "s"(sv));
-        return vv;
-    };
+    for (int h = 0; h < 2; h++) bias1[h] = v2f{p.c1b[2 * h], p.c1b[2 * h + 1]};
 #pragma unroll
     for (int h = 0; h < 2; h++)   // pair h: input channels h and h + 2
 #pragma unroll
-        for (int k = 0; k < 9; k++) w2[h][k] = v2f{to_vgpr(p.c2w[h * 9 + k]), to_vgpr(p.c2w[(h + 2) * 9 + k])};
-    bias2 = to_vgpr(p.c2b[0]);
-    for (int i = t; i < C1CH * C1P * C1P; i += PBLOCK) (&s_c1[0][0])[i] = 0.0f;
+        for (int k = 0; k < 9; k++) w2[h][k] = v2f{p.c2w[h * 9 + k], p.c2w[(h + 2) * 9 + k]};
+    bias2 = p.c2b[0];
+    for (int i = t; i < C1CH * C1P * C1P; i += PBLOCK) s_c1[i] = 0.0f;
     const int j = t >> 4, sl = t & 15;   // linear: 16 threads per output feature, its 36 weights in registers
     const float lbias = p.lb[j];
     float lwr[NPOS / 16];
 #pragma unroll
     for (int i = 0; i < NPOS / 16; i++) lwr[i] = p.lw[j * NPOS + sl + 16 * i];
+    // this thread's strip: outputs (oy, ox0 .. ox0 + 2)
+    const bool strip = t < (C1W / 3) * C1W;
+    const int ts = strip ? t : 0;
+    const int oy = ts / (C1W / 3), ox0 = 3 * (ts % (C1W / 3));
 
     // The next map is fetched into registers while this one computes, and a map's 16 features are stored one
     // iteration late: at the top of an iteration the only memory operations in flight are then the prefetch loads
@@ -296,42 +302,65 @@ __global__ __launch_bounds__(PBLOCK, 4) void k_conv_features(ConvParams p) {
         }
         if (pend_m >= 0 && sl == 0) p.feat[(size_t)pend_m * NFEAT + j] = pend;
         __syncthreads();
-        for (int pos = t; pos < NPOS; pos += PBLOCK) {   // conv1 + ReLU: 4 channels per position
-            const int oy = pos / C1W, ox = pos % C1W;
-            float in[16];
+        if (strip) {   // conv1 (k = 4, stride 2) + ReLU: three positions x four channels from a 4 x 8 input window
+            v2f acc[3][2];
 #pragma unroll
-            for (int ky = 0; ky < 4; ky++)
+            for (int d = 0; d < 3; d++) {
+                acc[d][0] = bias1[0];
+                acc[d][1] = bias1[1];
+            }
 #pragma unroll
-                for (int kx = 0; kx < 4; kx++) in[ky * 4 + kx] = s_map[(2 * oy + ky) * MAPW + 2 * ox + kx];
+            for (int ky = 0; ky < 4; ky++) {
+                const v2f *r = reinterpret_cast<const v2f *>(s_map + (2 * oy + ky) * MAPW + 2 * ox0);   // even index: 8-byte aligned
+                const v2f a0 = r[0], a1 = r[1], a2 = r[2], a3 = r[3];
+                const float in[8] = {a0.x, a0.y, a1.x, a1.y, a2.x, a2.y, a3.x, a3.y};
+#pragma unroll
+                for (int kx = 0; kx < 4; kx++)
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {   // (per output and channel pair: taps in the order ky * 4 + kx, as before)
+                        const v2f w = s_w1[h][ky * 4 + kx];
+#pragma unroll
+                        for (int d = 0; d < 3; d++) acc[d][h] = __builtin_elementwise_fma(w, v2f{in[2 * d + kx], in[2 * d + kx]}, acc[d][h]);
+                    }
+            }
+#pragma unroll
+            for (int d = 0; d < 3; d++)
+                reinterpret_cast<float4 *>(s_c1)[(oy + 1) * C1P + ox0 + d + 1] =
+                    make_float4(fmaxf(acc[d][0].x, 0.0f), fmaxf(acc[d][1].x, 0.0f), fmaxf(acc[d][0].y, 0.0f), fmaxf(acc[d][1].y, 0.0f));
+        }
+        __syncthreads();
+        if (strip) {   // conv2 (k = 3, pad 1) + ReLU: channels (0, 2) then (1, 3), halves added
+            v2f acc[3];
+#pragma unroll
+            for (int d = 0; d < 3; d++) acc[d] = v2f{bias2, 0.0f};
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                v2f acc = bias1[h];
 #pragma unroll
-                for (int i = 0; i < 16; i++) acc = __builtin_elementwise_fma(w1[h][i], v2f{in[i], in[i]}, acc);
-                s_c1[2 * h][(oy + 1) * C1P + ox + 1] = fmaxf(acc.x, 0.0f);
-                s_c1[2 * h + 1][(oy + 1) * C1P + ox + 1] = fmaxf(acc.y, 0.0f);
+                for (int ky = 0; ky < 3; ky++) {   // one window row of the pair (h, h + 2) at a time: 10 registers, not 30
+                    v2f q[5];
+#pragma unroll
+                    for (int c = 0; c < 5; c++) q[c] = reinterpret_cast<const v2f *>(s_c1)[2 * ((oy + ky) * C1P + ox0 + c) + h];
+#pragma unroll
+                    for (int d = 0; d < 3; d++)   // (per output: taps in the order h, ky, kx, as before)
+#pragma unroll
+                        for (int kx = 0; kx < 3; kx++) acc[d] = __builtin_elementwise_fma(w2[h][ky * 3 + kx], q[d + kx], acc[d]);
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                const int pos = oy * C1W + ox0 + d;
+                s_c2[(pos & 15) * (NPOS / 16) + (pos >> 4)] = fmaxf(acc[d].x + acc[d].y, 0.0f);
             }
         }
         __syncthreads();
-        for (int pos = t; pos < NPOS; pos += PBLOCK) {   // conv2 (pad 1) + ReLU: channels (0, 2) then (1, 3), halves added
-            const int oy = pos / C1W, ox = pos % C1W;
-            v2f acc = {bias2, 0.0f};
-#pragma unroll
-            for (int h = 0; h < 2; h++)
-#pragma unroll
-                for (int ky = 0; ky < 3; ky++)
-#pragma unroll
-                    for (int kx = 0; kx < 3; kx++)
-                        acc = __builtin_elementwise_fma(w2[h][ky * 3 + kx],
-                                                        v2f{s_c1[h][(oy + ky) * C1P + ox + kx], s_c1[h + 2][(oy + ky) * C1P + ox + kx]},
-                                                        acc);
-            s_c2[pos] = fmaxf(acc.x + acc.y, 0.0f);
-        }
-        __syncthreads();
         v2f acc2 = {0.0f, 0.0f};   // linear 576 -> 16: feature j by 16 threads, 36 terms each, butterfly over the 16 lanes
+        const float4 *c2v = reinterpret_cast<const float4 *>(s_c2 + sl * (NPOS / 16));
 #pragma unroll
-        for (int i = 0; i < NPOS / 16; i += 2)
-            acc2 = __builtin_elementwise_fma(v2f{lwr[i], lwr[i + 1]}, v2f{s_c2[sl + 16 * i], s_c2[sl + 16 * (i + 1)]}, acc2);
+        for (int i = 0; i < NPOS / 16; i += 4) {
+            const float4 v = c2v[i / 4];
+            acc2 = __builtin_elementwise_fma(v2f{lwr[i], lwr[i + 1]}, v2f{v.x, v.y}, acc2);
+            acc2 = __builtin_elementwise_fma(v2f{lwr[i + 2], lwr[i + 3]}, v2f{v.z, v.w}, acc2);
+        }
         float acc = acc2.x + acc2.y;
 #pragma unroll
         for (int off = 8; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
