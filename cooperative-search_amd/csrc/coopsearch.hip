@@ -4231,7 +4231,7 @@ __device__ __forceinline__ void map_build_pass(const DevParams &p, int k, const 
     }
 }
 
-template <int N, int ILP>
+template <int N, int ILP, int BLK = MAP_BLOCK>
 __device__ __forceinline__ void map_sweep(const DevParams &p, MapPassLds *s_pass, float *obs, int apply, int parity, int b,
                                           int yblk) {
     const MapJob *job = job_ptr(p, parity, b);
@@ -4242,19 +4242,19 @@ __device__ __forceinline__ void map_sweep(const DevParams &p, MapPassLds *s_pass
     float4 *m4 = reinterpret_cast<float4 *>(p.prob + (size_t)b * p.cells);
     const int nchunks = p.cells / 4;
     // the map loads do not depend on anything below: issue them first
-    const int c_first = yblk * ILP * MAP_BLOCK + threadIdx.x;
+    const int c_first = yblk * ILP * BLK + threadIdx.x;
     float4 v_in[ILP];
 #pragma unroll
     for (int k = 0; k < ILP; k++) {
         v_in[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c_first + k * MAP_BLOCK < nchunks) v_in[k] = m4[c_first + k * MAP_BLOCK];
+        if (c_first + k * BLK < nchunks) v_in[k] = m4[c_first + k * BLK];
     }
 
     if (dirty || reset_pass) {
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
         // wave 0 builds the step's pass and wave 1 the reset-time pass (a one-wave workgroup builds both in turn)
         for (int k = 1; k >= 0; k--) {
-            if (wave != (MAP_BLOCK >= 128 ? 1 - k : 0) || !(k == 1 ? dirty : reset_pass)) continue;
+            if (wave != (BLK >= 128 ? 1 - k : 0) || !(k == 1 ? dirty : reset_pass)) continue;
             double jx[N], jy[N];
 #pragma unroll
             for (int i = 0; i < N; i++) {
@@ -4270,7 +4270,7 @@ __device__ __forceinline__ void map_sweep(const DevParams &p, MapPassLds *s_pass
     const size_t row_w = (size_t)p.cells + 4;
 #pragma unroll
     for (int kc = 0; kc < ILP; kc++) {
-        const int c = c_first + kc * MAP_BLOCK;
+        const int c = c_first + kc * BLK;
         if (c >= nchunks) break;
         float4 v = v_in[kc];
         if ((dirty || reset_pass) && map_update_chunk(p, s_pass, dirty, reset_pass, c, v)) m4[c] = v;
@@ -4296,11 +4296,15 @@ __global__ __launch_bounds__(MAP_BLOCK) void k_map(DevParams p, float *obs, int 
 
 // The update alone (no observation rows wanted): without the n output copies to hide it, the sweep is bound by the
 // per-workgroup prologue (job record -> lattice bitmap -> barrier), so one workgroup per env does the whole map.
-constexpr int MAP_UPD_ILP = (CS_MAX_MAP * CS_MAX_MAP / 4 + MAP_BLOCK - 1) / MAP_BLOCK;
+#ifndef CS_MAP_UPD_BLOCK
+#define CS_MAP_UPD_BLOCK 256
+#endif
+constexpr int MAP_UPD_BLOCK = CS_MAP_UPD_BLOCK;
+constexpr int MAP_UPD_ILP = (CS_MAX_MAP * CS_MAX_MAP / 4 + MAP_UPD_BLOCK - 1) / MAP_UPD_BLOCK;
 template <int N>
-__global__ __launch_bounds__(MAP_BLOCK) void k_map_update(DevParams p, int parity) {
+__global__ __launch_bounds__(MAP_UPD_BLOCK) void k_map_update(DevParams p, int parity) {
     __shared__ MapPassLds s_pass[2];
-    map_sweep<N, MAP_UPD_ILP>(p, s_pass, nullptr, 1, parity, blockIdx.x, 0);
+    map_sweep<N, MAP_UPD_ILP, MAP_UPD_BLOCK>(p, s_pass, nullptr, 1, parity, blockIdx.x, 0);
 }
 
 // flight rollouts: the map sweep of step t and the kinematics / detection of step t + 1 in ONE launch.  The two do not
@@ -4766,7 +4770,7 @@ int cs_step(const cs_config *cfg, void *state_dev, const void *actions_dev, int 
         if (obs_dev) {
             CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_map<N>, map_grid(p), dim3(MAP_BLOCK), 0, s, p, obs_dev, 1, 0));
         } else {
-            CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_map_update<N>, dim3((unsigned)p.B), dim3(MAP_BLOCK), 0, s, p, 0));
+            CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_map_update<N>, dim3((unsigned)p.B), dim3(MAP_UPD_BLOCK), 0, s, p, 0));
         }
     }
     return launched("cs_step");
@@ -4924,7 +4928,7 @@ int cs_rollout_policy_flight(const cs_config *cfg, void *state_dev, const float 
             CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_map<N>, map_grid(p), dim3(MAP_BLOCK), 0, s, p,
                                                             obs_dev + (size_t)t * B * obs_w, 1, 0));
         } else {   // the update alone: fusing it into the conv kernel was measured slower
-            CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_map_update<N>, dim3((unsigned)p.B), dim3(MAP_BLOCK), 0, s, p, 0));
+            CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_map_update<N>, dim3((unsigned)p.B), dim3(MAP_UPD_BLOCK), 0, s, p, 0));
         }
     }
     return launched("cs_rollout_policy_flight");

@@ -235,15 +235,21 @@ struct ConvParams {
 // on its own: 16 ds_read_b32 per conv1 position, 36 per conv2 position, 36 strided ones per thread in the linear layer --
 // ~40 000 LDS instructions per map against ~33 000 packed FMAs, LDS-issue bound at 25 TFLOP/s.  Now a thread owns a STRIP of
 // three horizontally adjacent outputs (24 x 8 = 192 strips: one pass) and fetches the strip's input window in wide reads
-// (conv1: 4 rows x 8 floats as float2; conv2: conv1's four channels interleaved per position as {c0, c2, c1, c3}, so one
-// ds_read_b64 brings the channel pair a packed FMA consumes); conv2's output is stored transposed ((pos % 16) * 36 + pos / 16)
+// (conv1: 4 rows x 8 floats as float2; conv2: conv1's channels stored as two planes of PAIRS, {c0, c2} and {c1, c3}, so one
+// ds_read_b64 brings the pair a packed FMA consumes -- interleaving all four per position put the 64 lanes of a read on 8 bank
+// groups, 62 % of the LDS's busy cycles were bank conflicts); conv2's output is stored transposed ((pos % 16) * 36 + pos / 16)
 // so that the linear layer's 36 terms of a thread are contiguous (9 float4).  Every output's FMA chain -- taps in the same
 // order, the same channel pairing, the same butterfly -- is unchanged: the features are bit-identical to the first version's.
 // four workgroups per CU (<= 128 VGPRs)
 __global__ __launch_bounds__(PBLOCK, 4) void k_conv_features(ConvParams p) {
     using v2f = __attribute__((ext_vector_type(2))) float;
-    __shared__ __attribute__((aligned(16))) float s_map[MAPW * MAPW];
-    __shared__ __attribute__((aligned(16))) float s_c1[C1P * C1P * C1CH];   // [26 x 26] x {c0, c2, c1, c3}, zero border (conv2's padding)
+    // Row pitches chosen for the LDS banks: a 64-bit read is served 16 lanes at a time (16 x 8 B = all 32 banks), and 16 lanes
+    // are two rows of 8 strips whose windows start 6 dwords apart -- {0, 6, .., 30, 4, 10} mod 32; the second row's starts are
+    // the OTHER eight even residues exactly when two map rows / one conv1 row are 16 dwords apart mod 32
+    constexpr int MAPP = 56;   // floats per staged map row (50 used): 2 * 56 = 112 = 16 mod 32
+    constexpr int C1Q = 40;    // channel pairs per conv1 row (26 used): 2 * 40 = 80 = 16 mod 32
+    __shared__ __attribute__((aligned(16))) float s_map[MAPW * MAPP];
+    __shared__ __attribute__((aligned(16))) float s_c1[2 * C1P * C1Q * 2];   // two planes of [26][40] channel PAIRS: {c0, c2}, then {c1, c3}; zero border (conv2's padding)
     __shared__ __attribute__((aligned(16))) float s_c2[NPOS];               // transposed: element pos at (pos % 16) * 36 + pos / 16
     const int t = threadIdx.x;
     static_assert(C1CH == 4, "channel pairs (0,1) and (2,3)");
@@ -262,7 +268,7 @@ __global__ __launch_bounds__(PBLOCK, 4) void k_conv_features(ConvParams p) {
 #pragma unroll
         for (int k = 0; k < 9; k++) w2[h][k] = v2f{p.c2w[h * 9 + k], p.c2w[(h + 2) * 9 + k]};
     bias2 = p.c2b[0];
-    for (int i = t; i < C1CH * C1P * C1P; i += PBLOCK) s_c1[i] = 0.0f;
+    for (int i = t; i < 2 * C1P * C1Q * 2; i += PBLOCK) s_c1[i] = 0.0f;
     const int j = t >> 4, sl = t & 15;   // linear: 16 threads per output feature, its 36 weights in registers
     const float lbias = p.lb[j];
     float lwr[NPOS / 16];
@@ -291,14 +297,19 @@ __global__ __launch_bounds__(PBLOCK, 4) void k_conv_features(ConvParams p) {
     float pend = 0.0f;
     int pend_m = -1;
     for (int m = blockIdx.x; m < p.n_maps; m += gridDim.x) {
-        if (p.vec4) {
-            reinterpret_cast<float4 *>(s_map)[t] = pre0;
-            reinterpret_cast<float4 *>(s_map)[t + PBLOCK] = pre1;
-            if (t + 2 * PBLOCK < MAPW * MAPW / 4) reinterpret_cast<float4 *>(s_map)[t + 2 * PBLOCK] = pre2;
+        if (p.vec4) {   // (50 is even: a pair of floats never straddles two rows)
+            auto put = [&](int chunk, const float4 &v) __attribute__((always_inline)) {
+                const int e0 = 4 * chunk, e1 = e0 + 2;
+                *reinterpret_cast<v2f *>(s_map + (e0 / MAPW) * MAPP + e0 % MAPW) = v2f{v.x, v.y};
+                *reinterpret_cast<v2f *>(s_map + (e1 / MAPW) * MAPP + e1 % MAPW) = v2f{v.z, v.w};
+            };
+            put(t, pre0);
+            put(t + PBLOCK, pre1);
+            if (t + 2 * PBLOCK < MAPW * MAPW / 4) put(t + 2 * PBLOCK, pre2);
             if (m + (int)gridDim.x < p.n_maps) CONV_FETCH(m + gridDim.x);
         } else {   // unaligned maps (caller-assembled rows): plain loads
             const float *src = p.maps + (size_t)m * p.map_stride;
-            for (int i = t; i < MAPW * MAPW; i += PBLOCK) s_map[i] = src[i];
+            for (int i = t; i < MAPW * MAPW; i += PBLOCK) s_map[(i / MAPW) * MAPP + i % MAPW] = src[i];
         }
         if (pend_m >= 0 && sl == 0) p.feat[(size_t)pend_m * NFEAT + j] = pend;
         __syncthreads();
@@ -311,7 +322,7 @@ __global__ __launch_bounds__(PBLOCK, 4) void k_conv_features(ConvParams p) {
             }
 #pragma unroll
             for (int ky = 0; ky < 4; ky++) {
-                const v2f *r = reinterpret_cast<const v2f *>(s_map + (2 * oy + ky) * MAPW + 2 * ox0);   // even index: 8-byte aligned
+                const v2f *r = reinterpret_cast<const v2f *>(s_map + (2 * oy + ky) * MAPP + 2 * ox0);   // even index: 8-byte aligned
                 const v2f a0 = r[0], a1 = r[1], a2 = r[2], a3 = r[3];
                 const float in[8] = {a0.x, a0.y, a1.x, a1.y, a2.x, a2.y, a3.x, a3.y};
 #pragma unroll
@@ -324,9 +335,11 @@ __global__ __launch_bounds__(PBLOCK, 4) void k_conv_features(ConvParams p) {
                     }
             }
 #pragma unroll
-            for (int d = 0; d < 3; d++)
-                reinterpret_cast<float4 *>(s_c1)[(oy + 1) * C1P + ox0 + d + 1] =
-                    make_float4(fmaxf(acc[d][0].x, 0.0f), fmaxf(acc[d][1].x, 0.0f), fmaxf(acc[d][0].y, 0.0f), fmaxf(acc[d][1].y, 0.0f));
+            for (int d = 0; d < 3; d++) {   // plane 0: channels {0, 2}, plane 1: {1, 3} -- the pairs conv2's packed FMAs take
+                v2f *o = reinterpret_cast<v2f *>(s_c1) + (oy + 1) * C1Q + ox0 + d + 1;
+                o[0] = v2f{fmaxf(acc[d][0].x, 0.0f), fmaxf(acc[d][1].x, 0.0f)};
+                o[C1P * C1Q] = v2f{fmaxf(acc[d][0].y, 0.0f), fmaxf(acc[d][1].y, 0.0f)};
+            }
         }
         __syncthreads();
         if (strip) {   // conv2 (k = 3, pad 1) + ReLU: channels (0, 2) then (1, 3), halves added
@@ -339,7 +352,7 @@ __global__ __launch_bounds__(PBLOCK, 4) void k_conv_features(ConvParams p) {
                 for (int ky = 0; ky < 3; ky++) {   // one window row of the pair (h, h + 2) at a time: 10 registers, not 30
                     v2f q[5];
 #pragma unroll
-                    for (int c = 0; c < 5; c++) q[c] = reinterpret_cast<const v2f *>(s_c1)[2 * ((oy + ky) * C1P + ox0 + c) + h];
+                    for (int c = 0; c < 5; c++) q[c] = reinterpret_cast<const v2f *>(s_c1)[h * C1P * C1Q + (oy + ky) * C1Q + ox0 + c];
 #pragma unroll
                     for (int d = 0; d < 3; d++)   // (per output: taps in the order h, ky, kx, as before)
 #pragma unroll
