@@ -3383,6 +3383,8 @@ struct __attribute__((aligned(16))) OdShared {
     int d_steps;                             // D: steps finished so far (slot s may be overwritten once d_steps > s)
     int fix_req, fix_ack;                    // D -> K: "step fix_req - 1 ended an episode you could not predict" / K -> D: redone
     unsigned fix_mask;                       // ... for the envs in this mask (bit o)
+    int e_steps;                             // E (three-wavefront variant): steps written out so far
+    // (d_steps, fix_req and e_steps within a few dwords of each other: K reads its two words with ONE ds_read2_b32)
     union {   // never live together: a requested row is consumed at the top of a step, before any reset of that step
         unsigned rowbuf[MT_N + 16];          // one MT19937 row (+ the 16 words lanes 48..63 of the tenth dword column land on)
         double2 tgt[4][CS_MAX_TARGETS];      // D: reset hand-over (16-lane group -> octet), free between rounds
@@ -3406,6 +3408,16 @@ __device__ __forceinline__ int lds_peek(const int *w) {
     int v;
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_offset_of(w)) : "memory");
     return v;
+}
+// two words OFF0 and OFF1 dwords behind `base` in one LDS round trip
+template <int OFF0, int OFF1>
+__device__ __forceinline__ int2 lds_peek2(const int *base) {
+    static_assert(OFF0 >= 0 && OFF0 < 256 && OFF1 >= 0 && OFF1 < 256, "ds_read2_b32 offsets are 8-bit dword counts");
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    v2i v;
+    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3\n\ts_waitcnt lgkmcnt(0)"
+                 : "=v"(v) : "v"(lds_offset_of(base)), "n"(OFF0), "n"(OFF1) : "memory");
+    return make_int2(v.x, v.y);
 }
 
 #ifndef CS_OD_COLD_PARAMS
@@ -3432,7 +3444,7 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
     __shared__ double T[TRIG_ROWS * TRIG_COLS];
     __shared__ OdShared sh;
     __shared__ OdOut outs[E3 ? OD_RING : 1];
-    __shared__ int e_steps;   // E: steps written out so far
+    int &e_steps = sh.e_steps;
     const int lane = threadIdx.x & 63;
     // Which wavefront of the workgroup plays which role decides who shares a SIMD: at 4096 envs a CU holds two workgroups,
     // six wavefronts on four SIMDs, handed out in order -- wavefront 0 of one workgroup lands beside wavefront 1 of the other,
@@ -3587,14 +3599,21 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
             DUO_STAMP(0);
             const int act_after = ap[0];
             if (s + 3 < io.T) ap += astep;
-            // flow control: slot s % OD_RING is free once D has finished step s - OD_RING
-            // (E3: ... once E has written step s - OD_RING out; E never passes D)
-            while (peek(E3 ? &e_steps : &sh.d_steps) <= s - OD_RING) {
-                SPIN_TICK;
-                handle_fix(s);
-                __builtin_amdgcn_s_sleep(2);
+            // flow control: slot s % OD_RING is free once D has finished step s - OD_RING (E3: ... once E has written step
+            // s - OD_RING out; E never passes D).  The progress word and D's fix request come in ONE LDS round trip, and the
+            // common case -- slot free, nothing to fix -- touches none of the fix-up code (whose state updates otherwise cost a
+            // row of register copies at every pass through the loop head).
+            constexpr int OFF_FIX = (int)(offsetof(OdShared, fix_req) - offsetof(OdShared, d_steps)) / 4;
+            constexpr int OFF_E = (int)(offsetof(OdShared, e_steps) - offsetof(OdShared, d_steps)) / 4;
+            const int2 pv = E3 ? lds_peek2<OFF_E, OFF_FIX>(&sh.d_steps) : lds_peek2<0, OFF_FIX>(&sh.d_steps);
+            if (__builtin_expect(pv.x <= s - OD_RING || pv.y != fix_seen, 0)) {
+                for (;;) {
+                    handle_fix(s);
+                    if (peek(E3 ? &e_steps : &sh.d_steps) > s - OD_RING) break;
+                    SPIN_TICK;
+                    __builtin_amdgcn_s_sleep(2);
+                }
             }
-            handle_fix(s);
             DUO_STAMP(2);
             produce(s, act, true);
             DUO_STAMP(1);
