@@ -350,6 +350,58 @@ def test_rollout_kernel_equals_stepwise(kernel):
             assert torch.equal(r1[k], r2[k]), k
 
 
+@pytest.mark.parametrize("kernel", ["oct", "od", "ode"])
+@pytest.mark.parametrize("n,time_limit", [(3, 200), (3, 1), (3, 2), (5, 3), (2, 5)])
+def test_octet_kernels_short_launches_and_back_to_back_resets(kernel, n, time_limit):
+    """Launch lengths around and below the pair kernels' ring depth (1, 2, 3, 4, 5, 9 steps: pipeline fill and drain with
+    nothing in between), chained on one env so that every hand-over between launches is exercised, with episodes as short as
+    ONE step (time_limit 1: every env resets at every step -- the emitting wavefront may still be writing a step's rows
+    when the detection wavefront resets their targets).  Bit for bit against the 16-lane step kernel, step by step, in
+    every output and in the raw state after each launch.  B = 77: nine full octet wavefronts' worth + a tail of 5 envs."""
+    B = 77
+    args = cs.make_env_args("flight_easy", n_agents=n)
+    args.time_limit = time_limit
+    seeds = np.arange(B, dtype=np.uint32) + 31 * n + time_limit
+    g = torch.Generator("cuda").manual_seed(5 + n)
+    for kw in (dict(freeze_done=False, auto_reset=True), dict(freeze_done=True), dict(freeze_done=False)):
+        e1 = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, kernel="group", **kw)
+        e2 = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, kernel=kernel, **kw)
+        t = 0
+        for T in (1, 2, 3, 4, 5, 9, 1, 4, 2):
+            acts = torch.randint(0, 3, (T, B, n), dtype=torch.int32, device="cuda", generator=g)
+            out = e2.rollout(acts)
+            for k in range(T):
+                r, term, win = e1.step(acts[k])
+                assert torch.equal(r, out["reward"][k]) and torch.equal(term, out["terminated"][k]) and torch.equal(win, out["win"][k]), (kw, t + k)
+                assert torch.equal(e1.get_obs(), out["obs"][k]) and torch.equal(e1.get_state(), out["state"][k]), (kw, t + k)
+            r1, r2 = raw_state(e1), raw_state(e2)
+            for key in ("tgt", "agent", "hdr", "mt"):
+                assert torch.equal(r1[key], r2[key]), (key, kw, t)
+            t += T
+
+
+@pytest.mark.parametrize("kernel", ["oct", "od", "ode"])
+def test_octet_kernels_partial_outputs(kernel):
+    """rollout(out=...) without obs / state buffers (the pair kernel then runs without its emitting wavefront): rewards,
+    flags and the final state equal the full-output run's."""
+    B, n, T = 264, 3, 60
+    args = cs.make_env_args("flight_easy", n_agents=n)
+    args.time_limit = 25
+    seeds = np.arange(B, dtype=np.uint32) + 1234
+    acts = torch.randint(0, 3, (T, B, n), dtype=torch.int32, device="cuda", generator=torch.Generator("cuda").manual_seed(3))
+    e1 = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, kernel=kernel, freeze_done=False, auto_reset=True)
+    e2 = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, kernel=kernel, freeze_done=False, auto_reset=True)
+    full = e1.rollout(acts)
+    lean = e2.rollout(acts, emit=False)
+    assert lean.get("obs") is None and lean.get("state") is None
+    for key in ("reward", "terminated", "win"):
+        assert torch.equal(full[key], lean[key]), key
+    r1, r2 = raw_state(e1), raw_state(e2)
+    for key in ("tgt", "agent", "hdr", "mt"):
+        assert torch.equal(r1[key], r2[key]), key
+    assert torch.equal(e1.get_obs(), e2.get_obs()) and torch.equal(e1.get_state(), e2.get_state())
+
+
 @pytest.mark.parametrize("n", [3, 5])
 def test_group_and_lane_kernels_can_be_interleaved(n):
     """Both kernels share one state layout (incl. the mirrored head of the MT rows that only the lane kernel reads
