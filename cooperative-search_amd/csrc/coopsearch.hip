@@ -3329,8 +3329,8 @@ __global__ __launch_bounds__(OCT_BLOCK, CS_OCT_WAVES) void k_rollout_oct(DevPara
 }
 
 // =========================================================================================================
-// Octet pair (flight_easy): the octet layout with the TWO ROLES of the pair kernel -- per 8 envs a kinematics
-// wavefront K and a detection wavefront D, one pair per workgroup, one workgroup barrier per step.
+// Octet pair (flight_easy): the octet layout split by ROLE -- per 8 envs a kinematics wavefront K, a detection
+// wavefront D and (up to 8192 envs) an emitting wavefront E, one such team per workgroup, no barrier in the loops.
 //
 // In the octet kernel one wavefront walks the whole dependent chain of a step -- kinematics (~1800 cycles for 3 agents),
 // then detection + reward + rows (~1500) -- and at the batch sizes where every SIMD holds at most one or two wavefronts
@@ -3349,8 +3349,11 @@ __global__ __launch_bounds__(OCT_BLOCK, CS_OCT_WAVES) void k_rollout_oct(DevPara
 //      counter.  When D reports a termination K could not predict (a win at step s), K restores that env from ring slot s
 //      and REDOES every step it has already produced past s, for that env only (D holds slot s and waits meanwhile).
 //   D  lane t owns targets t, t + 8, the env's header and its hit tape: sensor tests on the ring's positions, draws,
-//      reward, termination, the persistent get_state rows and every output store; resets (target placement on the 16-lane
-//      code, reset-time pass) and row top-ups.
+//      reward, termination; resets (oct_place_targets, reset-time pass) and row top-ups; without E also the persistent
+//      get_state rows and every output store.
+//   E  (template flag E3) owns the get_state tile and writes reward, terminated, win, obs, state of each step from K's
+//      ring slot and the record D leaves per step (OdOut): a quarter of D's plain step, which D -- the role that also carries
+//      every event -- no longer has to do.
 // Arithmetic per env is the octet kernel's (same functions), so results are bit-identical.
 // =========================================================================================================
 #ifndef CS_OD_WAVES
