@@ -380,6 +380,45 @@ def test_octet_kernels_short_launches_and_back_to_back_resets(kernel, n, time_li
             t += T
 
 
+@pytest.mark.parametrize("kernel", ["od", "ode"])
+@pytest.mark.parametrize("kw", [
+    dict(n_agents=3, target_num=1, target_mode=1, detect_prob=1.0, view_range=40),   # a win within a step or two of every reset
+    dict(n_agents=2, target_num=2, target_mode=1, detect_prob=1.0, view_range=25),
+    dict(n_agents=5, target_num=3, target_mode=0, detect_prob=0.9, view_range=30, agent_mode=3),
+])
+def test_pair_kernels_under_constant_mispredictions(kernel, kw):
+    """The kinematics wavefront runs ahead on the assumption that only the step counter ends an episode; here nearly every
+    episode ends with a WIN a step or two after its reset, so the detection wavefront's fix requests (restore from the
+    ring, redo the speculative steps, acknowledge) and the resets behind them come every other step in every workgroup --
+    also while the emitting wavefront is still writing the previous step out.  1000 envs x 300 steps in launches of uneven
+    length, bit for bit against the 16-lane step kernel."""
+    B, T = 1000, 300
+    args = _custom_args("flight_easy", **dict(kw))
+    n = args.n_agents
+    seeds = np.arange(B, dtype=np.uint32) + 5150
+    g = torch.Generator("cuda").manual_seed(17)
+    for mode in (dict(freeze_done=False, auto_reset=True), dict(freeze_done=True)):
+        e1 = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, kernel="group", **mode)
+        e2 = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, kernel=kernel, **mode)
+        t, wins = 0, 0
+        for L in (7, 64, 3, 100, 26, 100):
+            acts = torch.randint(0, 3, (L, B, n), dtype=torch.int32, device="cuda", generator=g)
+            out = e2.rollout(acts)
+            for k in range(L):
+                r, term, win = e1.step(acts[k])
+                assert torch.equal(r, out["reward"][k]) and torch.equal(term, out["terminated"][k]) and torch.equal(win, out["win"][k]), (mode, t + k)
+                if k % 9 == 0 or k == L - 1:
+                    assert torch.equal(e1.get_obs(), out["obs"][k]) and torch.equal(e1.get_state(), out["state"][k]), (mode, t + k)
+            wins += int(out["win"].sum().item())
+            r1, r2 = raw_state(e1), raw_state(e2)
+            for key in ("tgt", "agent", "hdr", "mt"):
+                assert torch.equal(r1[key], r2[key]), (key, mode, t)
+            t += L
+        assert t == T
+        if mode.get("auto_reset"):
+            assert wins > B * 10, wins   # the scenario does what it says: tens of wins per env
+
+
 @pytest.mark.parametrize("kernel", ["oct", "od", "ode"])
 def test_octet_kernels_partial_outputs(kernel):
     """rollout(out=...) without obs / state buffers (the pair kernel then runs without its emitting wavefront): rewards,
