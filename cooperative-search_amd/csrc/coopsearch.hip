@@ -3496,6 +3496,12 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
 
     if (is_k) {
         // ------------------------------------------------------------------------------------------ K: kinematics
+        // with the emitting wavefront K bounds the pipeline: it wins the issue arbitration against whoever shares its SIMD
+        // (an E of the neighbouring workgroup at 4096 envs, two or three other wavefronts at 8192: -2 % / -4 % per step)
+#ifndef CS_ODE_KPRIO
+#define CS_ODE_KPRIO 3
+#endif
+        if (E3) __builtin_amdgcn_s_setprio(CS_ODE_KPRIO);
         {
             const double4 a = reinterpret_cast<const double4 *>(p.agent + bl * CS_MAX_AGENTS * 4)[t];
             e.x = a.x;
@@ -3722,6 +3728,9 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
     }
 
     // ---------------------------------------------------------------------------------------------- D: detection
+#ifdef CS_OD_DPRIO
+    if (!E3) __builtin_amdgcn_s_setprio(CS_OD_DPRIO);
+#endif
     e.ahead = live ? p.ahead[bl] : (1 << 20);
     {
         const double2 *t2 = reinterpret_cast<const double2 *>(p.tgt + bl * G * 2);
