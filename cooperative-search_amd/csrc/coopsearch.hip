@@ -1916,7 +1916,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io
                                    against lane 7.1e9 env-steps/s at 3 agents, 5.0e9 against 4.8e9 at 5; 262144: 8.0 / 10.4) */
 #endif
 #ifndef CS_ODE_UPTO
-#define CS_ODE_UPTO 8192        /* ... up to this many envs with the third (emitting) wavefront: five 3-wavefront workgroups per CU */
+#define CS_ODE_UPTO 10240       /* ... up to this many envs with the third (emitting) wavefront: five 3-wavefront workgroups per CU x 256 CUs x 8 envs */
 #endif
 #ifndef CS_OD_UPTO
 #define CS_OD_UPTO 16384        /* cs_rollout up to this many envs: the octet pair kernel */
@@ -3330,7 +3330,7 @@ __global__ __launch_bounds__(OCT_BLOCK, CS_OCT_WAVES) void k_rollout_oct(DevPara
 
 // =========================================================================================================
 // Octet pair (flight_easy): the octet layout split by ROLE -- per 8 envs a kinematics wavefront K, a detection
-// wavefront D and (up to 8192 envs) an emitting wavefront E, one such team per workgroup, no barrier in the loops.
+// wavefront D and (up to 10240 envs) an emitting wavefront E, one such team per workgroup, no barrier in the loops.
 //
 // In the octet kernel one wavefront walks the whole dependent chain of a step -- kinematics (~1800 cycles for 3 agents),
 // then detection + reward + rows (~1500) -- and at the batch sizes where every SIMD holds at most one or two wavefronts
@@ -3435,7 +3435,7 @@ __device__ __forceinline__ int2 lds_peek2(const int *base) {
 // a quarter of D's plain step.  D, which also carries every reset and row top-up, is the pair's slower half (K alone sustains
 // ~3500 cycles per step, D ~2650 + ~1450 of events); without the emission it has the slack to absorb its events.  D hands each
 // step's reward / terminated / win / found mask to E through a ring of OdOut records; E reads the agents' floats from K's
-// ring slot.  Three wavefronts of 128 VGPRs: five workgroups per CU, so this variant serves batches up to 8192 envs.
+// ring slot.  Three wavefronts of 128 VGPRs: five workgroups per CU, so this variant serves batches up to 10240 envs.
 struct __attribute__((aligned(16))) OdOut {
     float reward[OCT_ENVS];
     int term[OCT_ENVS], win[OCT_ENVS];
