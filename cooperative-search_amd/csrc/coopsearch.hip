@@ -3731,6 +3731,10 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
 #ifdef CS_OD_DPRIO
     if (!E3) __builtin_amdgcn_s_setprio(CS_OD_DPRIO);
 #endif
+#ifndef CS_ODE_DPRIO
+#define CS_ODE_DPRIO 2   /* three-wavefront variant: K (3) > D (2) > E (0) where wavefronts share a SIMD: -3 % per step at 8192 envs */
+#endif
+    if (E3) __builtin_amdgcn_s_setprio(CS_ODE_DPRIO);
     e.ahead = live ? p.ahead[bl] : (1 << 20);
     {
         const double2 *t2 = reinterpret_cast<const double2 *>(p.tgt + bl * G * 2);
