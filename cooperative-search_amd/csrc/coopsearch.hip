@@ -972,6 +972,99 @@ __device__ __forceinline__ void reset_targets(const DevParams &p, unsigned *mt, 
     }
 }
 
+#define CS_AS1 __attribute__((address_space(1)))
+#define CS_AS4 __attribute__((address_space(4)))
+__device__ __forceinline__ const CS_AS4 DevParams *cold_params4() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    auto q = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(q));
+    return (const CS_AS4 DevParams *)q;
+#else
+    return nullptr;   // host pass: never executed
+#endif
+}
+
+// the reset's target tables into LDS: rtab[0..15] = a*cx, [16..31] = a*cy, [32..47] = 2*a*dx, [48..63] = 2*a*dy
+// (DevParams::tx0, ty0, jx2, jy2: adjacent in the kernarg segment); one lane per entry
+__device__ __forceinline__ void load_reset_tab(double *rtab, int lane) {
+    const CS_AS4 DevParams *q = cold_params4();
+    static_assert(CS_MAX_TARGETS == G, "one table row per 16 lanes");
+    static_assert(offsetof(DevParams, jy2) - offsetof(DevParams, tx0) == 3 * G * sizeof(double), "tables are adjacent");
+    rtab[lane] = q->tx0[lane];   // lane 0..63 runs through tx0, ty0, jx2, jy2
+}
+
+template <int N>
+struct StartTab {
+    double x[N], y[N], yaw;
+};
+template <int N>
+__device__ __forceinline__ StartTab<N> start_tab() {
+    const CS_AS4 DevParams *q = cold_params4();
+    StartTab<N> st;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        st.x[i] = q->start_x[i];
+        st.y[i] = q->start_y[i];
+    }
+    st.yaw = q->start_yaw;
+    return st;
+}
+template <int N>
+__device__ __forceinline__ void start_pick(const StartTab<N> &st, int i, double &x, double &y) {
+    x = st.x[0];
+    y = st.y[0];
+#pragma unroll
+    for (int k = 1; k < N; k++) {
+        x = i == k ? st.x[k] : x;
+        y = i == k ? st.y[k] : y;
+    }
+}
+
+// One attempt batch of a reset's target placement from TWISTED words only, for the env whose 16-lane group this is (lane =
+// polar attempt / uniform target): the 16-lane form of what oct_place_targets does per round.  `w`: this lane's four stream
+// words at cursor + 4 * t16.  Returns true if the batch completes the placement (always for uniform targets; ~99 % of the
+// time for the jittered ones): (mx, my) is then target t16's position and `words` the stream words consumed.  Nothing is
+// written: a caller whose batch does not suffice falls back to reset_targets() from the untouched cursor.
+__device__ __forceinline__ bool reset_batch_twisted(const unsigned (&w_in)[4], const double *rtab, unsigned fmask, int n_targets,
+                                                    int target_mode, double L, int t16, int gshift16, double &mx, double &my,
+                                                    int &words) {
+    unsigned w[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) w[k] = mt_temper(w_in[k]);
+    // numpy random_sample: 53-bit double from two words
+    const double u1 = ((double)(w[0] >> 5) * 67108864.0 + (double)(w[1] >> 6)) / 9007199254740992.0;
+    const double u2 = ((double)(w[2] >> 5) * 67108864.0 + (double)(w[3] >> 6)) / 9007199254740992.0;
+    mx = rtab[t16];
+    my = rtab[G + t16];
+    if (target_mode != 0) {   // x, y = map_size*np.random.rand() per target, flight_env_easy.py:122-127
+        mx = L * u1;
+        my = L * u2;
+        words = 4 * n_targets;
+        return true;
+    }
+    const int need_total = __popc(fmask);
+    words = 0;
+    if (need_total == 0) return true;
+    const double x1 = 2.0 * u1 - 1.0, x2 = 2.0 * u2 - 1.0;
+    const double r2 = x1 * x1 + x2 * x2;
+    const bool accept = !(r2 >= 1.0 || r2 == 0.0);
+    const double f = sqrt(-2.0 * log(accept ? r2 : 0.5) / (accept ? r2 : 0.5));
+    const double g1 = f * x2, g2 = f * x1;
+    const unsigned amask = (unsigned)((__ballot(accept) >> gshift16) & 0xffffull);
+    const int have = __popc(amask);
+    if (have < need_total) return false;   // group-uniform
+    const bool jit = (fmask >> t16) & 1u;
+    const int k = __popc(fmask & ((1u << t16) - 1u));   // which accepted attempt is this target's
+    const int sel = kth_set_bit16(amask, k < 16 ? k : 0);
+    const double s1 = __shfl(g1, sel & 15, G), s2 = __shfl(g2, sel & 15, G);
+    if (jit) {
+        mx += rtab[2 * G + t16] * (s1 - 0.5);  // dx*2*(randn-0.5)
+        my += rtab[3 * G + t16] * (s2 - 0.5);
+    }
+    words = 4 * (kth_set_bit16(amask, need_total - 1) + 1);   // up to and including the attempt that supplied the last needed pair
+    return true;
+}
+
 // TRIG = false: the caller steps the env right away (fused auto-reset), so the headings' sin / cos -- recomputed by the
 // kinematics of that step -- are not evaluated here.
 template <int N, bool TRIG = true>
@@ -2178,6 +2271,8 @@ __global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO i
     const int b0 = b - lane;  // first env of this wavefront
     const int b_end = io.env0 + io.env_n;
     const bool live = b < b_end;
+    __shared__ double rtab[4 * G];   // the reset's target tables (load_reset_tab)
+    if (wave == 0) load_reset_tab(rtab, lane);
     load_trig_to_lds(T);
     if (b0 >= b_end) return;  // whole wavefront out of range
     const int t16 = lane & (G - 1), gshift = lane & ~(G - 1), grp = lane >> 4;
@@ -2265,7 +2360,49 @@ __global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO i
                 if (src >= 0) {
                     const int br = b0 + src;
                     const DevParams &cp = cold_params();
-                    env_reset<N, false>(cp, T, br, t16, gshift, 0, g);
+                    // The usual reset -- the attempt batch lies within the twisted words, its 16 attempts suffice, no target
+                    // lands within view of a start pose (then the reset-time pass draws nothing) -- on the lean path of the
+                    // octet kernels: scalars through the constant address space, tables from LDS, one batch, nothing else.
+                    // With 64 envs per wavefront there is a reset in nearly every step; through env_reset (every parameter a
+                    // dependent flat load, N start poses with a division each) they cost 16 % of the kernel at 2^18 envs.
+                    bool lean = g.ahead >= 4 * G;
+                    if (lean) {
+                        const CS_AS4 DevParams *q4 = cold_params4();
+                        const int nt = q4->n_targets, tm = q4->target_mode;
+                        const unsigned fm = tm == 0 ? ~q4->deter_mask & tmask : 0u;
+                        const CS_AS1 unsigned *wrow = (const CS_AS1 unsigned *)q4->mt + (size_t)br * MT_STRIDE + wrap624(g.mt_pos + 4 * t16);
+                        unsigned w4[4];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) w4[k] = wrow[k];   // (words 0..31 are mirrored behind the row)
+                        double mx, my;
+                        int words;
+                        lean = reset_batch_twisted(w4, rtab, fm, nt, tm, q4->L, t16, gshift, mx, my, words);
+                        const StartTab<N> st = start_tab<N>();
+                        const double vr2 = q4->view_r2;
+                        bool near = false;
+#pragma unroll
+                        for (int i = 0; i < N; i++) {
+                            const double ddx = mx - st.x[i], ddy = my - st.y[i];
+                            near = near | ((t16 < nt) & (ddx * ddx + ddy * ddy <= vr2));
+                        }
+                        lean = lean && ((__ballot(near) >> gshift) & 0xffffull) == 0ull;   // group-uniform
+                        if (lean) {
+                            g.tx = mx;
+                            g.ty = my;
+                            g.ntx = (float)((mx - q4->mid) * q4->inv_half);   // norm_target
+                            g.nty = (float)((my - q4->mid) * q4->inv_half);
+                            g.mt_pos = wrap624(g.mt_pos + words);
+                            g.words += (unsigned long long)words;
+                            g.ahead -= words;
+                            g.episodes += 1;
+                            g.found = 0u;
+                            g.newly = 0u;
+                            g.target_find = 0;
+                            g.curr_reward = -1;      // the reset-time pass with no pair in range: no draw, reward -1 (quirk Q3)
+                            g.flags = FLAG_DIRTY;
+                        }
+                    }
+                    if (!lean) env_reset<N, false>(cp, T, br, t16, gshift, 0, g);
                     reinterpret_cast<double2 *>(cp.tgt + (size_t)br * G * 2)[t16] = make_double2(g.tx, g.ty);
                     if (t16 < p.n_targets) {
                         float *rs = tile + (size_t)src * W + 4 * N + 3 * t16;
@@ -2300,10 +2437,18 @@ __global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO i
                     e.words = w_new;
                     e.time_step = 0;
                     e.total_reward = 0;
+                    {   // start poses: the host's table; every agent starts with the same heading: one evaluation
+                        const StartTab<N> st = start_tab<N>();
+                        double s0, c0;
+                        trig_heading(T, st.yaw, s0, c0);
 #pragma unroll
-                    for (int i = 0; i < N; i++) {
-                        start_pose<N>(p, i, e.ax[i], e.ay[i], e.yaw[i]);
-                        trig_heading(T, e.yaw[i], e.sn[i], e.cs[i]);
+                        for (int i = 0; i < N; i++) {
+                            e.ax[i] = st.x[i];
+                            e.ay[i] = st.y[i];
+                            e.yaw[i] = st.yaw;
+                            e.sn[i] = s0;
+                            e.cs[i] = c0;
+                        }
                     }
                     done = false;
                 }
@@ -2871,54 +3016,6 @@ __device__ __forceinline__ void oct_advance_finish(const DevParams &p, int wave_
 //    pending for another round, its partial placement in LDS;
 //  * start poses are a table the host filled (DevParams::start_x / start_y), not N divisions.
 // ---------------------------------------------------------------------------------------------------------
-#define CS_AS1 __attribute__((address_space(1)))
-#define CS_AS4 __attribute__((address_space(4)))
-__device__ __forceinline__ const CS_AS4 DevParams *cold_params4() {
-#if defined(__HIP_DEVICE_COMPILE__)
-    auto q = __builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(q));
-    return (const CS_AS4 DevParams *)q;
-#else
-    return nullptr;   // host pass: never executed
-#endif
-}
-
-// the reset's target tables into LDS: rtab[0..15] = a*cx, [16..31] = a*cy, [32..47] = 2*a*dx, [48..63] = 2*a*dy
-// (DevParams::tx0, ty0, jx2, jy2: adjacent in the kernarg segment); one lane per entry
-__device__ __forceinline__ void load_reset_tab(double *rtab, int lane) {
-    const CS_AS4 DevParams *q = cold_params4();
-    static_assert(CS_MAX_TARGETS == G, "one table row per 16 lanes");
-    static_assert(offsetof(DevParams, jy2) - offsetof(DevParams, tx0) == 3 * G * sizeof(double), "tables are adjacent");
-    rtab[lane] = q->tx0[lane];   // lane 0..63 runs through tx0, ty0, jx2, jy2
-}
-
-template <int N>
-struct StartTab {
-    double x[N], y[N], yaw;
-};
-template <int N>
-__device__ __forceinline__ StartTab<N> start_tab() {
-    const CS_AS4 DevParams *q = cold_params4();
-    StartTab<N> st;
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        st.x[i] = q->start_x[i];
-        st.y[i] = q->start_y[i];
-    }
-    st.yaw = q->start_yaw;
-    return st;
-}
-template <int N>
-__device__ __forceinline__ void start_pick(const StartTab<N> &st, int i, double &x, double &y) {
-    x = st.x[0];
-    y = st.y[0];
-#pragma unroll
-    for (int k = 1; k < N; k++) {
-        x = i == k ? st.x[k] : x;
-        y = i == k ? st.y[k] : y;
-    }
-}
-
 // Target placement for the envs in `need` (bit 8 o = env o of the wavefront resets): new targets into the octet's e.tx /
 // e.ty, the state blob and (normalised, found = 0) the env's get_state row in `tile`; each env's stream cursor, word count,
 // twisted-ahead count and hit tape advance by what the reference's sequential algorithm consumes.  One env per 16-lane
