@@ -2385,7 +2385,6 @@ __global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO i
                             const double ddx = mx - st.x[i], ddy = my - st.y[i];
                             near = near | ((t16 < nt) & (ddx * ddx + ddy * ddy <= vr2));
                         }
-                        lean = lean && ((__ballot(near) >> gshift) & 0xffffull) == 0ull;   // group-uniform
                         if (lean) {
                             g.tx = mx;
                             g.ty = my;
@@ -2398,8 +2397,19 @@ __global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO i
                             g.found = 0u;
                             g.newly = 0u;
                             g.target_find = 0;
+                            g.time_step = 0;
+                            g.total_reward = 0;
                             g.curr_reward = -1;      // the reset-time pass with no pair in range: no draw, reward -1 (quirk Q3)
                             g.flags = FLAG_DIRTY;
+                            if ((__ballot(near) >> gshift) & 0xffffull) {   // group-uniform: the reset-time pass draws (5 agents at
+                                g.flags = 0;                                // agent_mode 0: the start poses at x = L/4, 3L/4 see targets)
+#pragma unroll
+                                for (int i = 0; i < N; i++) {
+                                    g.ax[i] = st.x[i];
+                                    g.ay[i] = st.y[i];
+                                }
+                                detect_pass<N>(cp, br, t16, gshift, g, mt_prefetch(cp.mt + (size_t)br * MT_STRIDE, g.mt_pos, t16));
+                            }
                         }
                     }
                     if (!lean) env_reset<N, false>(cp, T, br, t16, gshift, 0, g);
