@@ -2004,6 +2004,9 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io
 #ifndef CS_LANE_REFRESH_MAX_N
 #define CS_LANE_REFRESH_MAX_N 5   /* measured at B = 262144: 4 agents 29.9 -> 34-38 %, 5 agents 23.5 -> 28 % */
 #endif
+#ifndef CS_LANE_FROM_SMALL_TEAMS
+#define CS_LANE_FROM_SMALL_TEAMS 65536   /* ... for teams of up to 4 agents (lane_from) */
+#endif
 #ifndef CS_LANE_FROM
 #define CS_LANE_FROM 131072     /* default kernel of cs_rollout from this many envs: one env per lane (65536: octet 7.6e9
                                    against lane 7.1e9 env-steps/s at 3 agents, 5.0e9 against 4.8e9 at 5; 262144: 8.0 / 10.4) */
@@ -4764,6 +4767,10 @@ void launch_od(const cs_config *cfg, const DevParams &p, StepIO io, hipStream_t 
         hipLaunchKernelGGL((k_rollout_od<N, false, false, false>), dim3((unsigned)((p.B - full + OCT_ENVS - 1) / OCT_ENVS)), dim3(OD_BLOCK), 0, s, p, io);
     }
 }
+// cs_rollout: the lane kernel's lower bound.  With its lean reset (round 3) it passes the octet kernel at 65536 envs for teams
+// of up to 4 (3 agents: 7.4e9 against 7.0e9; 98304 envs: 8.5e9 against 7.5e9; 4 agents at 131072: 9.0e9 against 6.6e9); 5 agents
+// and more: within +-5 % of each other up to 131072 envs (the 250-VGPR variant, one to two wavefronts per SIMD), kept as it was.
+inline long long lane_from(const cs_config *c) { return c->n_agents <= 4 ? CS_LANE_FROM_SMALL_TEAMS : CS_LANE_FROM; }
 // Kernel choice for flight_easy: one env per 16-lane group (lowest latency, fills the chip from B = 4096) or one
 // env per lane (no replicated arithmetic; wins once the batch gives every SIMD a wavefront anyway).
 inline bool use_lane_kernel(const cs_config *c, int flags, bool rollout) {
@@ -4771,13 +4778,13 @@ inline bool use_lane_kernel(const cs_config *c, int flags, bool rollout) {
     if (flags & CS_KERNEL_GROUP) return false;
     if (rollout && (flags & (CS_KERNEL_OCT | CS_KERNEL_OD | CS_KERNEL_ODE))) return false;
     // single steps have no octet variant: the lane kernel takes over from the 16-lane step kernel at 32768 envs as before
-    return c->batch >= (rollout ? CS_LANE_FROM : 32768);
+    return c->batch >= (rollout ? lane_from(c) : 32768);
 }
 // cs_rollout: the octet kernel (one env per 8 lanes) between the pair kernel's range and the lane kernel's
 inline bool use_oct_kernel(const cs_config *c, int flags) {
     if (flags & CS_KERNEL_OCT) return true;
     if (flags & (CS_KERNEL_GROUP | CS_KERNEL_LANE | CS_KERNEL_SOLO | CS_KERNEL_DUO | CS_KERNEL_OD | CS_KERNEL_ODE)) return false;
-    return c->batch > CS_OCT_FROM && c->batch < CS_LANE_FROM;
+    return c->batch > CS_OCT_FROM && c->batch < lane_from(c);
 }
 // cs_rollout: the octet PAIR kernel (kinematics wavefront + detection wavefront per 8 envs)
 inline bool use_od_kernel(const cs_config *c, int flags) {
