@@ -145,7 +145,7 @@ def largest_divisor_leq(k, cap):
 
 def kernel_label(env_name, n, B, mode, kernel):
     """The kernel cs_step / cs_rollout dispatches to (csrc/coopsearch.hip: use_lane_kernel, duo_pays)."""
-    lane_from = (65536 if n <= 4 else 131072) if mode == "rollout" else 32768   # lane_from() (rollout); single steps: 32768
+    lane_from = (131072 if n <= 4 else 1048576) if mode == "rollout" else 32768   # lane_from() (rollout); single steps: 32768
     lane = env_name == "flight_easy" and (kernel == "lane" or (kernel == "auto" and B >= lane_from))
     if env_name == "flight":   # rollout call: step t + 1 rides inside the map sweep of step t, one launch per step
         return f"k_flight_pipe<{n}>" if mode == "rollout" else f"k_step<{n},1> + k_map<{n}>"

@@ -2004,8 +2004,8 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io
 #ifndef CS_LANE_REFRESH_MAX_N
 #define CS_LANE_REFRESH_MAX_N 5   /* measured at B = 262144: 4 agents 29.9 -> 34-38 %, 5 agents 23.5 -> 28 % */
 #endif
-#ifndef CS_LANE_FROM_SMALL_TEAMS
-#define CS_LANE_FROM_SMALL_TEAMS 65536   /* ... for teams of up to 4 agents (lane_from) */
+#ifndef CS_LANE_FROM_LARGE_TEAMS
+#define CS_LANE_FROM_LARGE_TEAMS 1048576   /* ... for teams of 5 and more agents (lane_from) */
 #endif
 #ifndef CS_LANE_FROM
 #define CS_LANE_FROM 131072     /* default kernel of cs_rollout from this many envs: one env per lane (65536: octet 7.6e9
@@ -4767,10 +4767,10 @@ void launch_od(const cs_config *cfg, const DevParams &p, StepIO io, hipStream_t 
         hipLaunchKernelGGL((k_rollout_od<N, false, false, false>), dim3((unsigned)((p.B - full + OCT_ENVS - 1) / OCT_ENVS)), dim3(OD_BLOCK), 0, s, p, io);
     }
 }
-// cs_rollout: the lane kernel's lower bound.  With its lean reset (round 3) it passes the octet kernel at 65536 envs for teams
-// of up to 4 (3 agents: 7.4e9 against 7.0e9; 98304 envs: 8.5e9 against 7.5e9; 4 agents at 131072: 9.0e9 against 6.6e9); 5 agents
-// and more: within +-5 % of each other up to 131072 envs (the 250-VGPR variant, one to two wavefronts per SIMD), kept as it was.
-inline long long lane_from(const cs_config *c) { return c->n_agents <= 4 ? CS_LANE_FROM_SMALL_TEAMS : CS_LANE_FROM; }
+// cs_rollout: the lane kernel's lower bound, by bench.py's protocol (tools/gpu_r3_z.sh): 3 agents 65536 envs octet 7.8e9 against
+// lane 7.3e9, 98304 8.0 / 8.2, 131072 8.2 / 10.4; 5 agents (the 250-VGPR lane variant) 262144 octet 5.6e9 against lane 4.9e9,
+// 524288 5.7 / 5.0, 2^20 5.8 / 6.4.
+inline long long lane_from(const cs_config *c) { return c->n_agents <= 4 ? CS_LANE_FROM : CS_LANE_FROM_LARGE_TEAMS; }
 // Kernel choice for flight_easy: one env per 16-lane group (lowest latency, fills the chip from B = 4096) or one
 // env per lane (no replicated arithmetic; wins once the batch gives every SIMD a wavefront anyway).
 inline bool use_lane_kernel(const cs_config *c, int flags, bool rollout) {
