@@ -1025,17 +1025,17 @@ __device__ __forceinline__ void start_pick(const StartTab<N> &st, int i, double 
 // words at cursor + 4 * t16.  Returns true if the batch completes the placement (always for uniform targets; ~99 % of the
 // time for the jittered ones): (mx, my) is then target t16's position and `words` the stream words consumed.  Nothing is
 // written: a caller whose batch does not suffice falls back to reset_targets() from the untouched cursor.
-__device__ __forceinline__ bool reset_batch_twisted(const unsigned (&w_in)[4], const double *rtab, unsigned fmask, int n_targets,
-                                                    int target_mode, double L, int t16, int gshift16, double &mx, double &my,
-                                                    int &words) {
+__device__ __forceinline__ bool reset_batch_twisted(const unsigned (&w_in)[4], double tx0, double ty0, double jx2, double jy2,
+                                                    unsigned fmask, int n_targets, int target_mode, double L, int t16,
+                                                    int gshift16, double &mx, double &my, int &words) {
     unsigned w[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) w[k] = mt_temper(w_in[k]);
     // numpy random_sample: 53-bit double from two words
     const double u1 = ((double)(w[0] >> 5) * 67108864.0 + (double)(w[1] >> 6)) / 9007199254740992.0;
     const double u2 = ((double)(w[2] >> 5) * 67108864.0 + (double)(w[3] >> 6)) / 9007199254740992.0;
-    mx = rtab[t16];
-    my = rtab[G + t16];
+    mx = tx0;
+    my = ty0;
     if (target_mode != 0) {   // x, y = map_size*np.random.rand() per target, flight_env_easy.py:122-127
         mx = L * u1;
         my = L * u2;
@@ -1058,8 +1058,8 @@ __device__ __forceinline__ bool reset_batch_twisted(const unsigned (&w_in)[4], c
     const int sel = kth_set_bit16(amask, k < 16 ? k : 0);
     const double s1 = __shfl(g1, sel & 15, G), s2 = __shfl(g2, sel & 15, G);
     if (jit) {
-        mx += rtab[2 * G + t16] * (s1 - 0.5);  // dx*2*(randn-0.5)
-        my += rtab[3 * G + t16] * (s2 - 0.5);
+        mx += jx2 * (s1 - 0.5);  // dx*2*(randn-0.5)
+        my += jy2 * (s2 - 0.5);
     }
     words = 4 * (kth_set_bit16(amask, need_total - 1) + 1);   // up to and including the attempt that supplied the last needed pair
     return true;
@@ -1102,6 +1102,87 @@ __device__ __forceinline__ void env_reset(const DevParams &p, const double *T, i
     } else {
         detect_finish<N>(p, t, gshift, e, false);   // what the pass does when no pair is in range: no draw, reward -1
     }
+}
+
+// env_reset(init = 0) for the 16-lane kernels' fused auto-resets, the usual case on a lean path: when the first attempt batch lies
+// within the twisted words and its 16 attempts suffice (~99 %), the placement is ONE reset_batch_twisted on parameters read
+// through the constant address space (scalar loads; the lane's table entries requested first, used last), the start poses come
+// from the host's table, and the reset-time pass (quirk Q3) is two assignments unless a target landed within view of a start
+// pose.  Everything else falls back to env_reset from the untouched state.  Same results, value for value.
+// `rtab`: the target tables in LDS (load_reset_tab) or nullptr (then this lane's four entries are loaded from the kernarg segment).
+template <int N, bool TRIG>
+__device__ __forceinline__ void env_reset_fast(const DevParams &cp, const double *T, const double *rtab, int b, int t, int gshift,
+                                               Env<N> &e) {
+    bool lean = e.ahead >= 4 * G;   // group-uniform
+    if (lean) {
+        const CS_AS4 DevParams *q4 = cold_params4();
+        double tx0, ty0, jx2, jy2;
+        if (rtab) {
+            tx0 = rtab[t];
+            ty0 = rtab[G + t];
+            jx2 = rtab[2 * G + t];
+            jy2 = rtab[3 * G + t];
+        } else {
+            tx0 = q4->tx0[t];
+            ty0 = q4->ty0[t];
+            jx2 = q4->jx2[t];
+            jy2 = q4->jy2[t];
+        }
+        const int nt = q4->n_targets, tm = q4->target_mode;
+        const unsigned tmask = nt >= 32 ? ~0u : ((1u << nt) - 1u);
+        const unsigned fm = tm == 0 ? ~q4->deter_mask & tmask : 0u;
+        const CS_AS1 unsigned *mtb = (const CS_AS1 unsigned *)q4->mt;
+        const CS_AS1 unsigned *wrow = mtb + (size_t)b * MT_STRIDE + wrap624(e.mt_pos + 4 * t);
+        unsigned w4[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) w4[k] = wrow[k];   // (words 0..31 are mirrored behind the row)
+        double mx, my;
+        int words;
+        lean = reset_batch_twisted(w4, tx0, ty0, jx2, jy2, fm, nt, tm, q4->L, t, gshift, mx, my, words);
+        if (lean) {
+            const StartTab<N> st = start_tab<N>();
+            const double vr2 = q4->view_r2;
+            bool near = false;
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                const double ddx = mx - st.x[i], ddy = my - st.y[i];
+                near = near | ((t < nt) & (ddx * ddx + ddy * ddy <= vr2));
+                e.ax[i] = st.x[i];
+                e.ay[i] = st.y[i];
+                e.yaw[i] = st.yaw;
+            }
+            if (TRIG) {   // every agent starts with the same heading: one evaluation
+                double s0, c0;
+                trig_heading(T, st.yaw, s0, c0);
+#pragma unroll
+                for (int i = 0; i < N; i++) {
+                    e.sn[i] = s0;
+                    e.cs[i] = c0;
+                }
+            }
+            e.tx = mx;
+            e.ty = my;
+            e.ntx = (float)((mx - q4->mid) * q4->inv_half);   // norm_target
+            e.nty = (float)((my - q4->mid) * q4->inv_half);
+            e.mt_pos = wrap624(e.mt_pos + words);
+            e.words += (unsigned long long)words;
+            e.ahead -= words;
+            e.episodes += 1;
+            e.found = 0u;
+            e.newly = 0u;
+            e.target_find = 0;
+            e.time_step = 0;
+            e.total_reward = 0;
+            e.curr_reward = -1;      // the reset-time pass with no pair in range: no draw, reward -1
+            e.flags = FLAG_DIRTY;
+            if ((__ballot(near) >> gshift) & 0xffffull) {   // group-uniform: the pass draws
+                e.flags = 0;
+                detect_pass<N>(cp, b, t, gshift, e, mt_prefetch(cp.mt + (size_t)b * MT_STRIDE, e.mt_pos, t));
+            }
+            return;
+        }
+    }
+    env_reset<N, TRIG>(cp, T, b, t, gshift, 0, e);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1328,7 +1409,7 @@ __device__ __forceinline__ void step_once(const DevParams &p, const double *T, c
         e.flags &= ~(FLAG_DIRTY | FLAG_RESET_PASS);  // pending-map-update flags describe THIS launch only
         if (done && (io.flags & CS_AUTO_RESET)) {
             const unsigned long long words_before = e.words;
-            env_reset<N, false>(cold_params(), T, b, t, gshift, 0, e);   // cold path: parameters read where they are needed
+            env_reset_fast<N, false>(cold_params(), T, nullptr, b, t, gshift, e);   // cold path: parameters read where they are needed
             if (VARIANT == 1) {  // flight: the map kernel must replay the reset-time update before this step's
                 e.newly_reset = e.newly;
                 e.flags |= FLAG_RESET_PASS;
@@ -1693,7 +1774,7 @@ __global__ __launch_bounds__(DUO_BLOCK, 2) void k_rollout_duo(DevParams p, StepI
             if (done && auto_reset) {
                 const unsigned long long words_before = e.words;
                 const DevParams &cp = cold_params();
-                env_reset<N, false>(cp, T, b, t, gshift, 0, e);
+                env_reset_fast<N, false>(cp, T, nullptr, b, t, gshift, e);
                 reinterpret_cast<double2 *>(cp.tgt + (size_t)b * G * 2)[t] = make_double2(e.tx, e.ty);
                 const unsigned long long used = e.words - words_before;   // its draw slots leave the tape
                 tape_shift<8>(tape, used < 2ull * 319ull ? (int)(used >> 1) : 319);
@@ -2363,59 +2444,9 @@ __global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO i
                 if (src >= 0) {
                     const int br = b0 + src;
                     const DevParams &cp = cold_params();
-                    // The usual reset -- the attempt batch lies within the twisted words, its 16 attempts suffice, no target
-                    // lands within view of a start pose (then the reset-time pass draws nothing) -- on the lean path of the
-                    // octet kernels: scalars through the constant address space, tables from LDS, one batch, nothing else.
-                    // With 64 envs per wavefront there is a reset in nearly every step; through env_reset (every parameter a
-                    // dependent flat load, N start poses with a division each) they cost 16 % of the kernel at 2^18 envs.
-                    bool lean = g.ahead >= 4 * G;
-                    if (lean) {
-                        const CS_AS4 DevParams *q4 = cold_params4();
-                        const int nt = q4->n_targets, tm = q4->target_mode;
-                        const unsigned fm = tm == 0 ? ~q4->deter_mask & tmask : 0u;
-                        const CS_AS1 unsigned *wrow = (const CS_AS1 unsigned *)q4->mt + (size_t)br * MT_STRIDE + wrap624(g.mt_pos + 4 * t16);
-                        unsigned w4[4];
-#pragma unroll
-                        for (int k = 0; k < 4; k++) w4[k] = wrow[k];   // (words 0..31 are mirrored behind the row)
-                        double mx, my;
-                        int words;
-                        lean = reset_batch_twisted(w4, rtab, fm, nt, tm, q4->L, t16, gshift, mx, my, words);
-                        const StartTab<N> st = start_tab<N>();
-                        const double vr2 = q4->view_r2;
-                        bool near = false;
-#pragma unroll
-                        for (int i = 0; i < N; i++) {
-                            const double ddx = mx - st.x[i], ddy = my - st.y[i];
-                            near = near | ((t16 < nt) & (ddx * ddx + ddy * ddy <= vr2));
-                        }
-                        if (lean) {
-                            g.tx = mx;
-                            g.ty = my;
-                            g.ntx = (float)((mx - q4->mid) * q4->inv_half);   // norm_target
-                            g.nty = (float)((my - q4->mid) * q4->inv_half);
-                            g.mt_pos = wrap624(g.mt_pos + words);
-                            g.words += (unsigned long long)words;
-                            g.ahead -= words;
-                            g.episodes += 1;
-                            g.found = 0u;
-                            g.newly = 0u;
-                            g.target_find = 0;
-                            g.time_step = 0;
-                            g.total_reward = 0;
-                            g.curr_reward = -1;      // the reset-time pass with no pair in range: no draw, reward -1 (quirk Q3)
-                            g.flags = FLAG_DIRTY;
-                            if ((__ballot(near) >> gshift) & 0xffffull) {   // group-uniform: the reset-time pass draws (5 agents at
-                                g.flags = 0;                                // agent_mode 0: the start poses at x = L/4, 3L/4 see targets)
-#pragma unroll
-                                for (int i = 0; i < N; i++) {
-                                    g.ax[i] = st.x[i];
-                                    g.ay[i] = st.y[i];
-                                }
-                                detect_pass<N>(cp, br, t16, gshift, g, mt_prefetch(cp.mt + (size_t)br * MT_STRIDE, g.mt_pos, t16));
-                            }
-                        }
-                    }
-                    if (!lean) env_reset<N, false>(cp, T, br, t16, gshift, 0, g);
+                    // (with 64 envs per wavefront there is a reset in nearly every step: through env_reset alone they cost 16 %
+                    // of the kernel at 2^18 envs; env_reset_fast: the lean path for the usual case)
+                    env_reset_fast<N, false>(cp, T, rtab, br, t16, gshift, g);
                     reinterpret_cast<double2 *>(cp.tgt + (size_t)br * G * 2)[t16] = make_double2(g.tx, g.ty);
                     if (t16 < p.n_targets) {
                         float *rs = tile + (size_t)src * W + 4 * N + 3 * t16;
