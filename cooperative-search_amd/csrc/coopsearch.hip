@@ -1409,7 +1409,10 @@ __device__ __forceinline__ void step_once(const DevParams &p, const double *T, c
         e.flags &= ~(FLAG_DIRTY | FLAG_RESET_PASS);  // pending-map-update flags describe THIS launch only
         if (done && (io.flags & CS_AUTO_RESET)) {
             const unsigned long long words_before = e.words;
-            env_reset_fast<N, false>(cold_params(), T, nullptr, b, t, gshift, e);   // cold path: parameters read where they are needed
+            // cold path: parameters read where they are needed.  (flight: the step role of k_flight_pipe is held to 128 VGPRs;
+            // with the lean path compiled in it spills 12 of them and the pipelined sweep loses 3 %: env_reset as it was)
+            if (VARIANT == 0) env_reset_fast<N, false>(cold_params(), T, nullptr, b, t, gshift, e);
+            else env_reset<N, false>(cold_params(), T, b, t, gshift, 0, e);
             if (VARIANT == 1) {  // flight: the map kernel must replay the reset-time update before this step's
                 e.newly_reset = e.newly;
                 e.flags |= FLAG_RESET_PASS;
