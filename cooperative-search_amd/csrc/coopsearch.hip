@@ -1388,7 +1388,7 @@ __device__ __forceinline__ void emit_flush_store(const DevParams &p, const StepI
 
 // One env.step for the group's env, state in registers.  `act` are this step's actions, `win` the MT window at
 // e.mt_pos (both already loaded); called by all 64 lanes of the wavefront (`live` = the lane's env exists).
-template <int N, int VARIANT>
+template <int N, int VARIANT, bool FASTRESET = (VARIANT == 0)>
 __device__ __forceinline__ void step_once(const DevParams &p, const double *T, const StepIO &io, WaveTile &tile, int b,
                                           int lane, size_t slot0, const EmitPlan<N> &plan, bool live, const int (&act)[N],
                                           MtWin &win, bool prefetch_next, bool flush_prev, size_t prev_slot0,
@@ -1409,9 +1409,9 @@ __device__ __forceinline__ void step_once(const DevParams &p, const double *T, c
         e.flags &= ~(FLAG_DIRTY | FLAG_RESET_PASS);  // pending-map-update flags describe THIS launch only
         if (done && (io.flags & CS_AUTO_RESET)) {
             const unsigned long long words_before = e.words;
-            // cold path: parameters read where they are needed.  (flight: the step role of k_flight_pipe is held to 128 VGPRs;
-            // with the lean path compiled in it spills 12 of them and the pipelined sweep loses 3 %: env_reset as it was)
-            if (VARIANT == 0) env_reset_fast<N, false>(cold_params(), T, nullptr, b, t, gshift, e);
+            // cold path: parameters read where they are needed.  (FASTRESET off: the step role of k_flight_pipe is held to 128
+            // VGPRs; with the lean path compiled in it spills 12 of them and the pipelined sweep loses 3 %: env_reset as it was)
+            if (FASTRESET) env_reset_fast<N, false>(cold_params(), T, nullptr, b, t, gshift, e);
             else env_reset<N, false>(cold_params(), T, b, t, gshift, 0, e);
             if (VARIANT == 1) {  // flight: the map kernel must replay the reset-time update before this step's
                 e.newly_reset = e.newly;
@@ -1453,7 +1453,7 @@ __device__ __forceinline__ void step_once(const DevParams &p, const double *T, c
 }
 
 // One launch's share of a single step: workgroup `blk` of BLOCK threads = 16 envs.
-template <int N, int VARIANT, bool TAPE = true>
+template <int N, int VARIANT, bool TAPE = true, bool FASTRESET = true>
 __device__ __forceinline__ void step_block(const DevParams &p, const StepIO &io, double *T, WaveTile *tiles, int blk) {
     const int gid = blk * BLOCK + threadIdx.x;
     const int b = gid / G, t = gid % G;
@@ -1490,7 +1490,7 @@ __device__ __forceinline__ void step_block(const DevParams &p, const StepIO &io,
         win = mt_prefetch(p.mt + (size_t)b * MT_STRIDE, e.mt_pos, t);
     }
     const EmitPlan<N> plan = make_emit_plan<N>(p, lane, nvalid);
-    step_once<N, VARIANT>(p, T, io, tiles[threadIdx.x >> 6], b, lane, (size_t)wave_b0, plan, live, act, win, false, false, 0, false, e,
+    step_once<N, VARIANT, FASTRESET>(p, T, io, tiles[threadIdx.x >> 6], b, lane, (size_t)wave_b0, plan, live, act, win, false, false, 0, false, e,
                           tape, STEP_TAPE, tape_ok);
     if (live) {
         env_store<N>(p, b, t, e, false);
@@ -4511,7 +4511,7 @@ __global__ __launch_bounds__(BLOCK, CS_PIPE_WAVES) void k_flight_pipe(DevParams 
     const int blk = blockIdx.x;
     const int q = blk / stride, r = blk - q * stride;
     if (r == 0 && q < nstep) {
-        step_block<N, 1, false>(p, io, T, tiles, q);
+        step_block<N, 1, false, false>(p, io, T, tiles, q);
     } else {
         const int before = q + 1 < nstep ? q + 1 : nstep;   // step workgroups with a lower index
         const int m = blk - before;
