@@ -59,6 +59,7 @@ C5_GLOBAL_BATCH = 65536  # BASELINE.json config 5
 MIN_GPU_S = 1.0          # headline: repeat the K-step region until this much GPU time has been measured
 MIN_GPU_S_ALSO = 0.25    # secondary workloads
 MIN_REPEATS, MAX_REPEATS = 5, 20000
+PG_WATCHDOG_S = 120      # --pg auto at N = 1: how long the optional RCCL communicator may take to come up
 
 
 def parse_args(argv=None):
@@ -72,7 +73,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads reported under 'also'")
-    ap.add_argument("--kernel", default="auto", choices=["auto", "group", "solo", "duo", "od", "ode", "oct", "lane"],
+    ap.add_argument("--kernel", default="auto", choices=["auto", "group", "solo", "duo", "od", "ode", "oct", "lane", "lanev"],
                     help="flight_easy kernel: 16 lanes per env (solo / duo wavefront roles, or chosen by batch), 8 lanes per env "
                          "(od: kinematics + detection wavefront pair, oct: one wavefront), one lane per env, or everything by "
                          "batch size (auto: od up to 16384 envs, oct below 131072, lane from there)")
@@ -82,6 +83,9 @@ def parse_args(argv=None):
                          "not come up; 'auto' (default) = try it, report the failure in the line and carry on without "
                          "(the collective is outside the timed region); 'off' = none.  N > 1 always has one.")
     ap.add_argument("--force-pg", dest="pg", action="store_const", const="on", help="same as --pg on")
+    ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)   # "env,n,batch,budget": see cpu_baseline()
+    ap.add_argument("--no-numa-bind", action="store_true",
+                    help="do not bind the rank to the CPUs of its GPU's NUMA node (bound by default when sysfs tells)")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU-only check of the N-rank control flow (launcher, gloo process group, metric all-gather); "
                          "no kernels run and the line says so")
@@ -191,17 +195,49 @@ def cpu_model():
     return "unknown"
 
 
+def physical_cores():
+    """(number of physical cores this process may run on, threads per core): sibling lists of the CPUs in the affinity mask."""
+    cpus = sorted(os.sched_getaffinity(0))
+    cores = set()
+    for c in cpus:
+        try:
+            sib = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip()
+        except OSError:
+            sib = str(c)
+        cores.add(sib)
+    return max(1, len(cores)), max(1, round(len(cpus) / max(1, len(cores))))
+
+
 def cpu_baseline(env_name, n, batch, budget_s=10.0):
+    """The CPU baseline in a CHILD process with a pinned OpenMP team: OMP_PROC_BIND=close and OMP_PLACES=cores have to be in
+    the environment before libgomp initialises, and the parent has long loaded its OpenMP runtimes (torch's, numpy's) and
+    carries the GPU runtime's helper threads.  The child never touches the GPU: it imports numpy and the oracle only.
+    Unpinned, the same measurement was bimodal (p10 / p90 of the per-region rates 8x apart: threads migrating between
+    cores and SMT siblings in the middle of a region)."""
+    env = dict(os.environ)
+    env.update({"OMP_PROC_BIND": "close", "OMP_PLACES": "cores", "OMP_DYNAMIC": "false", "OMP_WAIT_POLICY": "active"})
+    env.pop("OMP_NUM_THREADS", None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", f"{env_name},{n},{batch},{budget_s}"]
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    if out.returncode != 0 or not lines:
+        raise RuntimeError(f"cpu baseline child failed (rc {out.returncode}): {out.stderr[-500:]}")
+    return json.loads(lines[-1])
+
+
+def cpu_baseline_inproc(env_name, n, batch, budget_s=10.0):
     """The C oracle (a port of the reference's algorithm, parity-pinned by tests/) timed on this host's cores on a
     bounded sample of the same workload: same batch, auto-reset, obs+state emission, x*x squares (its fast mode).
     flight_easy: orc_batch_rollout_rep -- ONE OpenMP region per 400 steps (the 100-step action table walked four times),
-    env-major, so the fork/join cost is paid once per 400 steps and an env stays in its core's cache.  Thread counts from
-    1 to all logical CPUs are calibrated first (median of three regions each); the two best share the time budget and
+    env-major, so the fork/join cost is paid once per 400 steps and an env stays in its core's cache.  The team is pinned
+    (see cpu_baseline): one thread per PHYSICAL core at most -- SMT siblings are never used -- and thread counts from 1 to
+    the number of physical cores are calibrated first (median of three regions each); the two best share the time budget and
     `value` is the MEDIAN per-region rate of the better one (`cores` = that thread count); the others are listed in
     `thread_scaling_env_steps_per_s`."""
     import numpy as np
     from oracle import oracle as orc
-    max_threads = max(1, min(orc.OracleBatch.max_threads(), os.cpu_count() or 1))
+    n_cores, smt = physical_cores()
+    max_threads = max(1, min(orc.OracleBatch.max_threads(), n_cores))
     flight = env_name == "flight"
     B = batch if not flight else min(batch, 256)
     T, R = (100, 4) if not flight else (10, 1)
@@ -223,7 +259,7 @@ def cpu_baseline(env_name, n, batch, budget_s=10.0):
                 rates.append(B * T * rep / (time.perf_counter() - t0))
             return rates
 
-        cands = sorted({1, 2, 4, 8, 16, 32, 64, max_threads // 2, max_threads} & set(range(1, max_threads + 1)))
+        cands = sorted({1, 2, 4, 8, 16, 32, 64, 128, max_threads // 2, max_threads} & set(range(1, max_threads + 1)))
         scaling = {}
         for th in cands:   # calibration: the MEDIAN of three regions per thread count (single regions are noisy at high
             #                thread counts: SMT siblings, 4096 envs over 128 threads); the slow single thread runs quarter regions
@@ -249,10 +285,73 @@ def cpu_baseline(env_name, n, batch, budget_s=10.0):
     return {"value": value, "unit": "env-steps/s", "cores": best, "kind": "port",
             "sample": f"C oracle (oracle/flight_oracle.c orc_batch_rollout_rep: one OpenMP region per {T * R} steps, "
                       f"env-major), {B} envs x {T * R * reps} steps on {best} threads (best of {cands}), auto-reset, "
-                      f"obs+state emitted, {dt:.1f} s wall on {cpu_model()} ({os.cpu_count()} logical CPUs)",
+                      f"obs+state emitted, {dt:.1f} s wall on {cpu_model()} ({os.cpu_count()} logical CPUs, {n_cores} physical cores)",
             "region_rate_p10_median_p90": spread, "statistic": "median over the timed regions",
+            "p90_over_p10": (spread[2] / spread[0]) if spread and spread[0] > 0 else None,
+            "pinning": {"OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES"),
+                        "physical_cores": n_cores, "threads_per_core": smt,
+                        "note": "own process, one thread per physical core at most (no SMT siblings)"},
             "single_thread_value": single, "speedup_vs_single_thread": value / single,
             "thread_scaling_env_steps_per_s": scaling}
+
+
+# ------------------------------------------------------------------------------------------------ rank -> CPU binding
+def parse_cpulist(text):
+    """'0-63,128-191' -> {0..63, 128..191}"""
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_local_cpus(local_rank, sysfs="/sys"):
+    """(numa node, CPUs) next to the GPU this rank will use, from sysfs alone -- NO GPU call: the binding has to be in place
+    before the HIP runtime starts its helper threads.  GPUs = the KFD topology nodes this process may read that have SIMDs,
+    in node order (the order HIP enumerates them in); the node's drm_render_minor leads to the PCI device's local_cpulist.
+    None when sysfs does not tell (no KFD, fewer GPUs than local_rank, a device filter in the environment)."""
+    if any(os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL")):
+        return None   # the runtime's numbering is no longer the topology's
+    base = os.path.join(sysfs, "class/kfd/kfd/topology/nodes")
+    try:
+        nodes = sorted((int(d) for d in os.listdir(base) if d.isdigit()))
+    except OSError:
+        return None
+    minors = []
+    for nd in nodes:
+        try:
+            props = dict(ln.split()[:2] for ln in open(os.path.join(base, str(nd), "properties")) if len(ln.split()) >= 2)
+        except OSError:
+            continue   # another container's GPU: not ours to read, not ours to enumerate
+        if int(props.get("simd_count", "0")) > 0:
+            minors.append(int(props.get("drm_render_minor", "-1")))
+    if local_rank >= len(minors) or minors[local_rank] < 0:
+        return None
+    dev = os.path.join(sysfs, f"class/drm/renderD{minors[local_rank]}/device")
+    try:
+        cpus = parse_cpulist(open(os.path.join(dev, "local_cpulist")).read())
+        node = int(open(os.path.join(dev, "numa_node")).read().strip() or -1)
+    except (OSError, ValueError):
+        return None
+    return (node, cpus) if cpus else None
+
+
+def bind_rank_to_gpu_node(local_rank, sysfs="/sys"):
+    """Restricts this process (and every thread it starts later: HIP's, RCCL's) to the CPUs of its GPU's NUMA node.  The
+    path shards with no data-path collective, so the host cost of a launch (7 us per call against a 40 us region) is the one
+    thing that can bend a weak-scaling line: a rank launching across the socket interconnect pays it on every call.
+    Returns a description for the JSON line, or None when nothing was bound."""
+    found = gpu_local_cpus(local_rank, sysfs)
+    if not found:
+        return None
+    node, cpus = found
+    allowed = cpus & os.sched_getaffinity(0)
+    if not allowed:
+        return None
+    os.sched_setaffinity(0, allowed)
+    return {"numa_node": node, "cpus": len(allowed), "source": "KFD topology + drm local_cpulist, before any GPU call"}
 
 
 # ------------------------------------------------------------------------------------------------ timed region
@@ -460,7 +559,11 @@ def dry_run(a, rank, world):
     if rank == 0:
         print(json.dumps({"metric": "env-steps/sec", "value": None, "unit": "env-steps/s", "n_gpus": world,
                           "steps": a.steps, "warmup": a.warmup, "dry_run": True,
-                          "eval": {"envs": int(part[3].item()), "world_size": world}}), flush=True)
+                          "eval": {"envs": int(part[3].item()), "world_size": world},
+                          "c5_strong_total": {"value": None, "n_gpus": world, "envs_total": C5_GLOBAL_BATCH,
+                                              "envs_per_gpu": C5_GLOBAL_BATCH // world if C5_GLOBAL_BATCH % world == 0 else None},
+                          "c5_weak_total": {"value": None, "n_gpus": world, "envs_total": 8192 * world, "envs_per_gpu": 8192}}),
+              flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -469,6 +572,12 @@ def dry_run(a, rank, world):
 def main():
     argv = sys.argv[1:]
     a = parse_args(argv)
+    if a.cpu_baseline_child:   # the pinned child of cpu_baseline(): numpy + the oracle only, never the GPU
+        env_name, n, batch, budget = a.cpu_baseline_child.split(",")
+        print(json.dumps(cpu_baseline_inproc(env_name, int(n), int(batch), float(budget))), flush=True)
+        return
+    # the host driver supports dmabuf IPC only: has to be in the environment before ANYTHING initialises HSA
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     in_torchrun = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if a.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -486,6 +595,12 @@ def main():
         raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
     if a.dry_run:
         return dry_run(a, rank, world)
+    cpu_binding = None
+    if not a.no_numa_bind and os.environ.get("BENCH_SHARE_GPU") != "1":
+        try:
+            cpu_binding = bind_rank_to_gpu_node(local_rank)   # before the first GPU call of this process
+        except OSError as exc:
+            sys.stderr.write(f"bench.py: rank {rank}: no CPU binding ({exc})\n")
     # Exactly ONE line goes to stdout: native libraries write there too (RCCL prints its version banner through C stdio
     # when the first communicator comes up, and the buffer is flushed at exit -- AFTER the JSON line).  From here on file
     # descriptor 1 is stderr; the JSON line is written to the saved descriptor at the very end.
@@ -512,7 +627,7 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
-    pg, pg_error = False, None
+    pg, pg_error, pg_hung = False, None, False
     if world > 1 or in_torchrun or a.pg != "off":
         # one rank outside torchrun: its own rendezvous on the loopback
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -521,18 +636,41 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("LOCAL_RANK", "0")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        try:
+        optional = not (world > 1 or in_torchrun or a.pg == "on")   # N = 1, --pg auto: the line says so; everything else fails loudly
+
+        def bring_up():
             if share:
                 dist.init_process_group("gloo")
             else:
+                torch.cuda.set_device(dev_index)
                 dist.init_process_group("nccl", device_id=dev)
+
+        if not optional:
+            bring_up()
             pg = True
-        except Exception as exc:   # noqa: BLE001 -- N = 1, --pg auto: the line says so; everything else fails loudly
-            if world > 1 or in_torchrun or a.pg == "on":
-                raise
-            pg_error = f"{type(exc).__name__}: {exc}"[:300]
-            sys.stderr.write(f"bench.py: RCCL process group at world_size 1 failed ({pg_error}); continuing without\n")
+        else:
+            # a broken RCCL stack usually HANGS in the eager communicator init instead of raising: the optional one-rank group
+            # comes up on a watchdog thread; if it has not within PG_WATCHDOG_S the bench carries on without it (the collective
+            # is outside the timed region) and leaves through os._exit so that the stuck thread cannot hold the process
+            import threading
+            box = {}
+
+            def guarded():
+                try:
+                    bring_up()
+                    box["ok"] = True
+                except Exception as exc:   # noqa: BLE001
+                    box["err"] = f"{type(exc).__name__}: {exc}"[:300]
+
+            th = threading.Thread(target=guarded, daemon=True, name="rccl-init")
+            th.start()
+            th.join(PG_WATCHDOG_S)
+            if box.get("ok"):
+                pg = True
+            else:
+                pg_error = box.get("err") or f"init_process_group('nccl') did not return within {PG_WATCHDOG_S} s"
+                pg_hung = th.is_alive()
+                sys.stderr.write(f"bench.py: RCCL process group at world_size 1 failed ({pg_error}); continuing without\n")
     comm = Comm(world, dev, share, pg)
 
     import cooperative_search_amd as cs
@@ -575,6 +713,7 @@ def main():
                        "steps_per_launch": res["steps_per_launch"], "auto_reset": True, "emits": "obs+state every step",
                        "kernel": a.kernel, "hip_graph": mode == "step" and not a.no_graph,
                        "backend": ("gloo (BENCH_SHARE_GPU test mode)" if share else "nccl (RCCL)") if pg else None,
+                       "cpu_binding": cpu_binding,
                        **({"backend_error": pg_error} if pg_error else {})},
             "timing": {"clock": "HIP events on the launch stream, median over repeats of the K-step region, max over ranks",
                        "repeats": res["repeats"], "timed_gpu_s": res["timed_gpu_s"],
@@ -621,12 +760,24 @@ def main():
     if rank == 0:
         if also:
             line["also"] = also
+            # BASELINE config 5 (flight_easy 5a15t, 65536 envs over the node) as fields of their own, whole-job totals over
+            # all N ranks: the strong point (65536 / N envs per GPU) and the weak point (8192 envs per GPU)
+            for key, tag in (("c5_strong_total", "c5 strong"), ("c5_weak_total", "c5 weak")):
+                ent = next((x for x in also if str(x.get("workload", "")).startswith(tag)), None)
+                if ent:
+                    line[key] = {"value": ent["value"], "unit": "env-steps/s", "n_gpus": world,
+                                 "envs_total": (C5_GLOBAL_BATCH if tag == "c5 strong" else 8192 * world),
+                                 "envs_per_gpu": (C5_GLOBAL_BATCH // world if tag == "c5 strong" else 8192),
+                                 "roofline_frac_per_gpu": ent["roofline"]["frac"]}
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(env_name, n, B)
         emit_line(line)
     if pg:
         dist.barrier()
         dist.destroy_process_group()
+    if pg_hung:   # the watchdog gave up on a communicator init that is still stuck: do not let it hold the exit
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -14,7 +14,7 @@ H_WORDS = 16
 H_FOUND, H_NEWLY, H_TARGET_FIND, H_FLAGS, H_TIME_STEP, H_TOTAL_REWARD, H_MT_POS, H_EPISODES = range(8)
 H_WORDS_LO, H_WORDS_HI, H_CURR_REWARD, H_NEWLY_RESET = 8, 9, 10, 11
 SELECT_SOFTMAX, SELECT_SAMPLE = 1, 2
-FREEZE_DONE, AUTO_RESET, ACTIONS_I64, KERNEL_GROUP, KERNEL_LANE, KERNEL_SOLO, KERNEL_DUO, KERNEL_OCT, KERNEL_OD, KERNEL_ODE = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
+FREEZE_DONE, AUTO_RESET, ACTIONS_I64, KERNEL_GROUP, KERNEL_LANE, KERNEL_SOLO, KERNEL_DUO, KERNEL_OCT, KERNEL_OD, KERNEL_ODE, KERNEL_LANEV = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024
 
 EXPORTS = ["cs_abi_version", "cs_source_hash", "cs_last_error", "cs_state_layout", "cs_init", "cs_seed", "cs_reset", "cs_step",
            "cs_rollout", "cs_rollout_policy", "cs_rollout_policy_flight", "cs_emit", "cs_metrics", "cs_mt_canonical", "cs_mt_advance", "cs_policy_packed_floats", "cs_policy_pack", "cs_policy_forward",

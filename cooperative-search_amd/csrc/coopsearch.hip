@@ -1220,6 +1220,9 @@ __device__ unsigned long long g_stamps[64][16];
 #define CS_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && g_tl_step >= 0 && g_tl_step < 64) g_stamps[g_tl_step][k] = __builtin_readcyclecounter(); } while (0)
 __device__ int g_tl_step_dummy;
 #define LANE_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && s < 64) g_stamps[s][k] = __builtin_readcyclecounter(); } while (0)
+// the constant 100 MHz counter beside the shader-clock stamps: (delta s_memtime) / (delta s_memrealtime) x 100 MHz = the clock the
+// kernel actually ran at (the chip clocks to its power budget: fp64-dense kernels run well below 2.4 GHz)
+#define REAL_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && s < 64) g_stamps[s][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define DUO_STAMP(k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && s < 64) g_stamps[s][k] = __builtin_readcyclecounter(); } while (0)
 #define DUO_MARK(row, k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_stamps[row][k] = __builtin_readcyclecounter(); } while (0)
 #define OCT_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && s < 64) g_stamps[s][k] = __builtin_readcyclecounter(); } while (0)
@@ -1233,6 +1236,7 @@ __device__ int g_tl_step_dummy;
 #define DUO_MARK(row, k) do {} while (0)
 #define CS_STAMP(k) do {} while (0)
 #define LANE_STAMP(k) do {} while (0)
+#define REAL_STAMP(k) do {} while (0)
 #endif
 
 struct StepIO {
@@ -2416,6 +2420,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO i
         asm volatile("" : "+v"(lane));   // lane predicates are recomputed per step instead of being held (and spilled) as SGPR pairs
         const size_t slot = (size_t)s * p.B + arow;
         LANE_STAMP(0);
+        REAL_STAMP(8);
         bool done = live && (e.target_find >= p.n_targets || e.time_step >= p.time_limit);
         // ---- auto-reset: the four 16-lane groups of the wavefront each take one resetting env per round.  The env's
         //      cursor goes to its group by shuffle, the new targets come back through the lane's tile row (fp64 copies
@@ -3310,6 +3315,7 @@ __global__ __launch_bounds__(OCT_BLOCK, CS_OCT_WAVES) void k_rollout_oct(DevPara
 
     for (int s = 0; s < io.T; s++) {
         OCT_STAMP(0);
+        REAL_STAMP(8);
         // Lane predicates that never change (t < N, t != I, t < n_targets ...) are cheaper to recompute -- one v_cmp -- than to
         // keep: hoisted out of the loop each is an SGPR pair, ~30 SGPRs in all, which the scalar file does not have left
         // (they came back as v_readlane pairs at every use).  Making t opaque once per step keeps the compares in the loop.
@@ -4208,6 +4214,8 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
     }
     BLK_STAMP(7);
 }
+#include "rollout_lanev.h"   // k_rollout_lanev: the lane-per-env kernel built for three to four wavefronts per SIMD
+
 template <int N>
 __global__ __launch_bounds__(BLOCK) void k_reset(DevParams p, const uint8_t *mask, int init, float *obs, float *state) {
     __shared__ double T[TRIG_ROWS * TRIG_COLS];
@@ -4754,7 +4762,42 @@ void launch_lane(const cs_config *cfg, const DevParams &p, StepIO io, size_t sme
 inline size_t lane_smem(const cs_config *c) {
     const size_t W = 4 * (size_t)c->n_agents + 3 * (size_t)c->n_targets;
     return ((TRIG_ROWS * TRIG_COLS * 8 + 15) / 16) * 16 + (BLOCK / 64) * 64 * W * sizeof(float) +
-           (BLOCK / 64) * MT_N * sizeof(unsigned);   // + one MT19937 row per wavefront (in-loop refresh)
+           (BLOCK / 64) * MT_N * sizeof(unsigned)   // + one MT19937 row per wavefront (in-loop refresh)
+#ifdef CS_LANE_PADLDS   /* experiment: extra LDS per workgroup, i.e. fewer wavefronts per SIMD (occupancy sensitivity) */
+           + CS_LANE_PADLDS
+#endif
+        ;
+}
+// k_rollout_lanev launch(es): a VEC launch over the full wavefronts when obs and state are both written and every step's
+// block of get_state rows is 16-byte aligned, a plain launch for the remaining < 64 envs (or for everything otherwise).
+template <int N>
+void launch_lanev(const cs_config *cfg, const DevParams &p, StepIO io, hipStream_t s) {
+    const size_t W = 4 * (size_t)cfg->n_agents + 3 * (size_t)cfg->n_targets;
+    const size_t smem = LV_HEAD_BYTES + (BLOCK / 64) * lv_wave_bytes((int)W);
+    const bool aligned = io.state && io.obs && (reinterpret_cast<size_t>(io.state) & 15) == 0 &&
+                         (reinterpret_cast<size_t>(io.obs) & 15) == 0 && ((size_t)p.B * W) % 4 == 0;
+    const int full = aligned ? (p.B / 64) * 64 : 0;
+    if (full > 0) {
+        io.env0 = 0;
+        io.env_n = full;
+        hipLaunchKernelGGL((k_rollout_lanev<N, true>), dim3((unsigned)((full + BLOCK - 1) / BLOCK)), dim3(BLOCK), smem, s, p, io);
+    }
+    if (p.B - full > 0) {
+        io.env0 = full;
+        io.env_n = p.B - full;
+        hipLaunchKernelGGL((k_rollout_lanev<N, false>), dim3((unsigned)((p.B - full + BLOCK - 1) / BLOCK)), dim3(BLOCK), smem, s, p, io);
+    }
+}
+// Which lane-per-env kernel: k_rollout_lanev for teams of up to 5 (its in-loop MT19937 refresh tops up one env per wavefront
+// and step, which covers the draw rate of those teams), k_rollout_lane (+ the k_mt_advance pre-pass) for larger ones.
+#ifndef CS_LANEV_DEFAULT
+#define CS_LANEV_DEFAULT 1
+#endif
+inline bool use_lanev(const cs_config *c, int flags) {
+    if (c->n_agents > CS_LANE_REFRESH_MAX_N) return false;
+    if (flags & CS_KERNEL_LANEV) return true;
+    if (flags & CS_KERNEL_LANE) return false;
+    return CS_LANEV_DEFAULT != 0;
 }
 // Octet launch(es): a VEC launch over the full wavefronts (8 envs each) when every step's block of get_state rows is
 // 16-byte aligned, a plain launch for the remaining < 8 envs (or for everything otherwise).
@@ -4808,7 +4851,7 @@ inline long long lane_from(const cs_config *c) { return c->n_agents <= 4 ? CS_LA
 // Kernel choice for flight_easy: one env per 16-lane group (lowest latency, fills the chip from B = 4096) or one
 // env per lane (no replicated arithmetic; wins once the batch gives every SIMD a wavefront anyway).
 inline bool use_lane_kernel(const cs_config *c, int flags, bool rollout) {
-    if (flags & CS_KERNEL_LANE) return true;
+    if (flags & (CS_KERNEL_LANE | CS_KERNEL_LANEV)) return true;
     if (flags & CS_KERNEL_GROUP) return false;
     if (rollout && (flags & (CS_KERNEL_OCT | CS_KERNEL_OD | CS_KERNEL_ODE))) return false;
     // single steps have no octet variant: the lane kernel takes over from the 16-lane step kernel at 32768 envs as before
@@ -4817,13 +4860,13 @@ inline bool use_lane_kernel(const cs_config *c, int flags, bool rollout) {
 // cs_rollout: the octet kernel (one env per 8 lanes) between the pair kernel's range and the lane kernel's
 inline bool use_oct_kernel(const cs_config *c, int flags) {
     if (flags & CS_KERNEL_OCT) return true;
-    if (flags & (CS_KERNEL_GROUP | CS_KERNEL_LANE | CS_KERNEL_SOLO | CS_KERNEL_DUO | CS_KERNEL_OD | CS_KERNEL_ODE)) return false;
+    if (flags & (CS_KERNEL_GROUP | CS_KERNEL_LANE | CS_KERNEL_LANEV | CS_KERNEL_SOLO | CS_KERNEL_DUO | CS_KERNEL_OD | CS_KERNEL_ODE)) return false;
     return c->batch > CS_OCT_FROM && c->batch < lane_from(c);
 }
 // cs_rollout: the octet PAIR kernel (kinematics wavefront + detection wavefront per 8 envs)
 inline bool use_od_kernel(const cs_config *c, int flags) {
     if (flags & (CS_KERNEL_OD | CS_KERNEL_ODE)) return true;
-    if (flags & (CS_KERNEL_GROUP | CS_KERNEL_LANE | CS_KERNEL_SOLO | CS_KERNEL_DUO | CS_KERNEL_OCT)) return false;
+    if (flags & (CS_KERNEL_GROUP | CS_KERNEL_LANE | CS_KERNEL_LANEV | CS_KERNEL_SOLO | CS_KERNEL_DUO | CS_KERNEL_OCT)) return false;
     return c->batch <= CS_OD_UPTO;
 }
 
@@ -4945,7 +4988,11 @@ int cs_step(const cs_config *cfg, void *state_dev, const void *actions_dev, int 
     hipStream_t s = (hipStream_t)stream;
     StepIO io{actions_dev, reward_dev, terminated_dev, win_dev, obs_dev, state_out_dev, flags, 1};
     if (cfg->variant == 0 && use_lane_kernel(cfg, flags, false)) {
-        CS_DISPATCH_N(cfg->n_agents, launch_lane<N>(cfg, p, io, lane_smem(cfg), s));
+        if (use_lanev(cfg, flags)) {
+            CS_DISPATCH_N(cfg->n_agents, launch_lanev<N>(cfg, p, io, s));
+        } else {
+            CS_DISPATCH_N(cfg->n_agents, launch_lane<N>(cfg, p, io, lane_smem(cfg), s));
+        }
     } else if (cfg->variant == 0) {
         CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL((k_step<N, 0>), dim3(env_blocks(p)), dim3(BLOCK), 0, s, p, io));
     } else {
@@ -5003,6 +5050,8 @@ int cs_rollout(const cs_config *cfg, void *state_dev, const void *actions_dev, i
         CS_DISPATCH_N(cfg->n_agents, launch_od<N>(cfg, p, io, (hipStream_t)stream));
     } else if (use_oct_kernel(cfg, flags)) {
         CS_DISPATCH_N(cfg->n_agents, launch_oct<N>(cfg, p, io, (hipStream_t)stream));
+    } else if (use_lane_kernel(cfg, flags, true) && use_lanev(cfg, flags)) {
+        CS_DISPATCH_N(cfg->n_agents, launch_lanev<N>(cfg, p, io, (hipStream_t)stream));   // one launch: rows are refreshed inside the kernel
     } else if (use_lane_kernel(cfg, flags, true)) {
         // LANE_CHUNK steps per launch; before each chunk every env's MT19937 row is twisted fully ahead of its cursor by
         // a coalesced pre-pass, so the rollout loop itself (almost) never has to stop for a refill

@@ -135,8 +135,8 @@ class BatchedFlightEnv:
             self._state = torch.zeros(B, self.state_shape, dtype=torch.float32, device=self.device)
             self._avail = torch.ones(B, self.n_actions, dtype=torch.float32, device=self.device)
             self._metrics = torch.zeros(4, dtype=torch.float64, device=self.device)
-        if kernel not in ("auto", "group", "lane", "solo", "duo", "oct", "od", "ode"):
-            raise ValueError("kernel must be 'auto', 'group', 'lane', 'solo', 'duo', 'oct', 'od' or 'ode'")
+        if kernel not in ("auto", "group", "lane", "lanev", "solo", "duo", "oct", "od", "ode"):
+            raise ValueError("kernel must be 'auto', 'group', 'lane', 'lanev', 'solo', 'duo', 'oct', 'od' or 'ode'")
         self.kernel = kernel
         self.freeze_done = bool(freeze_done)
         self.auto_reset = bool(auto_reset)
@@ -262,8 +262,10 @@ class BatchedFlightEnv:
             f |= _lib.KERNEL_GROUP | _lib.KERNEL_SOLO
         elif self.kernel == "duo":
             f |= _lib.KERNEL_GROUP | _lib.KERNEL_DUO
-        elif self.kernel == "lane":
+        elif self.kernel == "lane":   # one env per lane, first generation (k_rollout_lane)
             f |= _lib.KERNEL_LANE
+        elif self.kernel == "lanev":  # one env per lane, targets in registers (k_rollout_lanev; teams of up to 5)
+            f |= _lib.KERNEL_LANEV
         elif self.kernel == "oct":   # rollout(): 8 lanes per env; step() has no octet variant and uses the 16-lane kernel
             f |= _lib.KERNEL_OCT
         elif self.kernel == "od":    # rollout(): the octet layout, kinematics and detection wavefronts pipelined

@@ -106,6 +106,55 @@ def test_bench_gpus_flag_spawns_that_many_ranks():
     assert line["steps"] == 20 and line["warmup"] == 5
 
 
+def test_bench_eight_rank_control_flow():
+    """The driver's 8-GPU launch, as far as a GPU-less container can take it: eight rank processes over gloo, the all-gather
+    sees all eight shards, and BASELINE config 5 shows up as fields of its own (65536 envs = 8 x 8192: the strong and the
+    weak point coincide at N = 8)."""
+    p, line = _run_bench(["--gpus", "8", "--dry-run", "--steps", "20", "--warmup", "5"], timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert line["n_gpus"] == 8 and line["eval"] == {"envs": 8 * 4096, "world_size": 8}
+    assert line["c5_strong_total"]["envs_total"] == 65536 and line["c5_strong_total"]["envs_per_gpu"] == 8192
+    assert line["c5_weak_total"]["envs_total"] == 65536 and line["c5_weak_total"]["n_gpus"] == 8
+
+
+def test_rank_binding_reads_the_gpu_numa_node_from_sysfs(tmp_path):
+    """bench.py binds each rank to the CPUs next to its GPU BEFORE any GPU call, from sysfs alone: KFD topology nodes with
+    SIMDs, in node order, are the GPUs; unreadable nodes (another container's GPUs) are skipped; the node's render minor
+    leads to the device's local_cpulist.  Layout below: what an 8-GPU MI355X node shows a one-GPU container (gpurun_out/a_topology.txt)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    nodes = tmp_path / "class/kfd/kfd/topology/nodes"
+    for k, (simd, minor) in enumerate([(0, 0), (0, 0), (1024, 128), (1024, 136)]):
+        (nodes / str(k)).mkdir(parents=True)
+        (nodes / str(k) / "properties").write_text(f"cpu_cores_count {0 if simd else 128}\nsimd_count {simd}\ndrm_render_minor {minor}\n")
+    (nodes / "4").mkdir()   # a node without readable properties
+    for minor, (node, cpus) in {128: (0, "0-3,8-11"), 136: (1, "4-7,12-15")}.items():
+        d = tmp_path / f"class/drm/renderD{minor}/device"
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text(f"{node}\n")
+        (d / "local_cpulist").write_text(cpus + "\n")
+    for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL"):
+        os.environ.pop(k, None)
+    assert bench.parse_cpulist("0-3,8-11") == {0, 1, 2, 3, 8, 9, 10, 11}
+    assert bench.gpu_local_cpus(0, str(tmp_path)) == (0, {0, 1, 2, 3, 8, 9, 10, 11})
+    assert bench.gpu_local_cpus(1, str(tmp_path)) == (1, {4, 5, 6, 7, 12, 13, 14, 15})
+    assert bench.gpu_local_cpus(2, str(tmp_path)) is None          # fewer GPUs than ranks: no binding, no error
+    assert bench.gpu_local_cpus(0, str(tmp_path / "nowhere")) is None
+    before = os.sched_getaffinity(0)
+    try:
+        got = bench.bind_rank_to_gpu_node(0, str(tmp_path))
+        want = {0, 1, 2, 3, 8, 9, 10, 11} & before
+        if want:
+            assert got["numa_node"] == 0 and os.sched_getaffinity(0) == want
+        else:
+            assert got is None
+    finally:
+        os.sched_setaffinity(0, before)
+
+
 def test_bench_launcher_propagates_rank_failure():
     """No GPU in this container: the real (non-dry) ranks must fail loudly and the launcher must return non-zero
     without printing a result line."""

@@ -119,6 +119,67 @@ def test_hip_replays_reference_golden_trace(name, kernel):
                                               env.raw()["prob"][0].cpu().numpy().reshape(-1))
 
 
+ROLLOUT_GOLDEN_CASES = [(n, k) for n in trace_names() if n.startswith("easy") for k in ("oct", "od", "ode", "lane", "lanev")]
+
+
+@pytest.mark.parametrize("name,kernel", ROLLOUT_GOLDEN_CASES)
+def test_rollout_kernels_replay_reference_golden_trace(name, kernel):
+    """The T-step rollout kernels against the reference's own traces, directly (the octet kernels were only
+    linked to the goldens through the oracle).  64 copies of the trace's env (one full wavefront of every layout: the VEC
+    variants, and the emitting wavefront of "ode") run each episode as cs_rollout launches over the recorded action table --
+    one launch per stretch between two hand-placed pokes -- and every step's reward / terminated / win / obs / state, the
+    header after every stretch and the draws consumed are the golden's."""
+    meta, z = load_trace(name)
+    n, m, B = meta["n_agents"], 15, 64
+    if kernel == "lanev" and n > 5:
+        pytest.skip("k_rollout_lanev serves teams of up to 5")
+    seeds = [meta["seed"]] * B
+    env = make_env(meta, batch=B, seeds=seeds, freeze_done=False, kernel=kernel)
+    env.seed(seeds)
+    for e, ep in enumerate(meta["episodes"]):
+        p = f"e{e}_"
+        env.reset(init=ep["init"])
+        acts = z[p + "actions"][:ep["steps"]].astype(np.int32)
+        pokes = {}
+        if p + "poke_steps" in z:
+            pokes = {int(t): k for k, t in enumerate(z[p + "poke_steps"])}
+        cuts = sorted({0, ep["steps"]} | {t for t in pokes if 0 < t < ep["steps"]})
+        w_prev = int(words(hdr(env))[0])
+        for t0, t1 in zip(cuts[:-1], cuts[1:]):
+            tag = f"{name} {p}steps {t0}..{t1 - 1} ({kernel})"
+            if t0 in pokes:
+                k = pokes[t0]
+                a = env.raw()["agent"]
+                a[:, :n, 0:2] = torch.from_numpy(z[p + "poke_agent_pos"][k]).to(a.device)
+                a[:, :n, 2] = torch.from_numpy(z[p + "poke_yaw_idx"][k] * (np.pi / 18.0)).to(a.device)
+            table = torch.from_numpy(np.repeat(acts[t0:t1, None, :], B, axis=1).copy())
+            out = env.rollout(table)
+            for key, gold in (("reward", "reward"), ("terminated", "terminated"), ("win", "win")):
+                got = out[key].cpu().numpy().astype(np.int64)
+                want = np.asarray(z[p + gold][t0:t1]).astype(np.int64)
+                assert np.array_equal(got, np.repeat(want[:, None], B, axis=1)), f"{tag} {key}"
+            obs, st = out["obs"].cpu().numpy(), out["state"].cpu().numpy()
+            for b in (0, 7, 8, B - 1):
+                np.testing.assert_allclose(obs[:, b], z[p + "obs"][t0:t1], rtol=0, atol=F32_TOL, err_msg=f"{tag} obs env {b}")
+                np.testing.assert_allclose(st[:, b], z[p + "state"][t0:t1], rtol=0, atol=F32_TOL, err_msg=f"{tag} state env {b}")
+            assert np.array_equal(obs, np.repeat(obs[:, :1], B, axis=1)) and np.array_equal(st, np.repeat(st[:, :1], B, axis=1))
+            h = hdr(env)
+            t = t1 - 1
+            for b in (0, B - 1):
+                assert h[b, _lib.H_TARGET_FIND] == int(z[p + "target_find"][t]), tag
+                assert h[b, _lib.H_TIME_STEP] == int(z[p + "time_step"][t]), tag
+                assert [(h[b, _lib.H_FOUND] >> j) & 1 for j in range(m)] == list(z[p + "found"][t]), tag + " found"
+                assert [(h[b, _lib.H_FLAGS] >> (8 + i)) & 1 for i in range(n)] == list(z[p + "out_flag"][t]), tag + " out"
+            w_now = words(h)
+            assert np.all(w_now == w_now[0])
+            assert int(w_now[0]) - w_prev == 2 * int(np.sum(z[p + "n_draws"][t0:t1])), tag + " draws consumed"
+            w_prev = int(w_now[0])
+            ag = env.raw()["agent"][:, :n].cpu().numpy()
+            np.testing.assert_allclose(ag[0, :, :2], z[p + "agent_pos"][t], rtol=0, atol=1e-9, err_msg=tag + " pos")
+            np.testing.assert_allclose(ag[0, :, 2], z[p + "yaw"][t], rtol=0, atol=0, err_msg=tag + " yaw")
+            assert np.array_equal(ag, np.repeat(ag[:1], B, axis=0))
+
+
 def compare_with_oracle(env, ob, B, n, m, tag, check_pos=True):
     h = hdr(env)
     raw = env.raw()
@@ -142,7 +203,7 @@ def compare_with_oracle(env, ob, B, n, m, tag, check_pos=True):
             np.testing.assert_allclose(tg[b], tp, rtol=0, atol=1e-12, err_msg=f"{tag} env {b} targets")
 
 
-@pytest.mark.parametrize("kernel", ["group", "group-ondemand", "solo", "duo", "lane"])
+@pytest.mark.parametrize("kernel", ["group", "group-ondemand", "solo", "duo", "lane", "lanev"])
 @pytest.mark.parametrize("variant,n,agent_mode,target_mode,B,T", [
     ("flight_easy", 3, 0, 0, 512, 200),
     ("flight_easy", 5, 0, 0, 256, 200),
@@ -181,7 +242,7 @@ def test_batched_step_matches_oracle_bit_exact(variant, n, agent_mode, target_mo
                 compare_with_oracle(env, ob, B, n, m, f"step {t}")
 
 
-@pytest.mark.parametrize("kernel", ["group", "group-ondemand", "solo", "duo", "lane"])
+@pytest.mark.parametrize("kernel", ["group", "group-ondemand", "solo", "duo", "lane", "lanev"])
 def test_auto_reset_and_unfrozen_modes_match_oracle(kernel):
     B, n, m, T = 128, 5, 15, 420   # > 2 episodes per env
     seeds = np.arange(B, dtype=np.uint32) + 5
@@ -330,7 +391,7 @@ def test_octet_rollout_matches_oracle_bit_exact(variant, n, agent_mode, target_m
         assert hdr(env)[:, _lib.H_EPISODES].min() >= 2
 
 
-@pytest.mark.parametrize("kernel", ["group", "solo", "duo", "lane", "oct", "od", "ode"])
+@pytest.mark.parametrize("kernel", ["group", "solo", "duo", "lane", "lanev", "oct", "od", "ode"])
 def test_rollout_kernel_equals_stepwise(kernel):
     B, n, T = 1000, 3, 200   # not a multiple of 64: exercises the partial last wavefront
     args = cs.make_env_args("flight_easy", n_agents=n)
@@ -573,7 +634,7 @@ def _custom_args(variant, **kw):
     return args
 
 
-@pytest.mark.parametrize("kernel", ["group", "solo", "duo", "lane"])
+@pytest.mark.parametrize("kernel", ["group", "solo", "duo", "lane", "lanev"])
 @pytest.mark.parametrize("variant,kw", [
     ("flight_easy", dict(n_agents=8, target_num=16, target_mode=1)),             # maximum sizes: 8 x 16 pairs, 2-phase draws
     ("flight_easy", dict(n_agents=7, target_num=16, target_mode=1, view_range=30)),  # nearly every pair in range: > 7 draws/step
@@ -773,7 +834,7 @@ def test_flight_rollout_call_equals_stepwise(B, n, T):
         assert torch.equal(r1[k], r2[k]), k
 
 
-@pytest.mark.parametrize("kernel", ["group", "solo", "duo", "lane", "oct", "od", "ode"])
+@pytest.mark.parametrize("kernel", ["group", "solo", "duo", "lane", "lanev", "oct", "od", "ode"])
 def test_long_horizon_matches_oracle(kernel):
     """20 000 steps per env with auto-reset: ~100+ episodes, the circular MT19937 state wraps ~70 times (cursor,
     mirrored head, reset-time batches landing anywhere in the ring).  Rewards are compared every step (in rollout
