@@ -149,12 +149,12 @@ def largest_divisor_leq(k, cap):
 
 def kernel_label(env_name, n, B, mode, kernel):
     """The kernel cs_step / cs_rollout dispatches to (csrc/coopsearch.hip: use_lane_kernel, duo_pays)."""
-    lane_from = (131072 if n <= 4 else 1048576) if mode == "rollout" else 32768   # lane_from() (rollout); single steps: 32768
-    lane = env_name == "flight_easy" and (kernel == "lane" or (kernel == "auto" and B >= lane_from))
+    lane_from = (65536 if n <= 5 else 1048576) if mode == "rollout" else 32768   # lane_from() (rollout); single steps: 32768
+    lane = env_name == "flight_easy" and (kernel in ("lane", "lanev") or (kernel == "auto" and B >= lane_from))
     if env_name == "flight":   # rollout call: step t + 1 rides inside the map sweep of step t, one launch per step
         return f"k_flight_pipe<{n}>" if mode == "rollout" else f"k_step<{n},1> + k_map<{n}>"
-    if lane:
-        return f"k_rollout_lane<{n}>"
+    if lane:   # teams of up to 5: the second-generation kernel (targets in registers) unless the first is asked for
+        return f"k_rollout_lanev<{n}>" if (n <= 5 and kernel != "lane") else f"k_rollout_lane<{n}>"
     if mode == "step":
         return f"k_step<{n},0>"
     if kernel == "ode" or (kernel == "auto" and B <= 10240):       # CS_ODE_UPTO: K + D + emitting wavefront per 8 envs
@@ -750,9 +750,13 @@ def main():
                 side_measurement(cs, dev, comm, "c4 flight 3a15t B=8192 (cs_rollout: sweep of step t beside step t + 1)",
                                  "flight", 3, 8192, "rollout", 400, 100, "auto"),
                 side_measurement(cs, dev, comm, "flight_easy 3a15t B=262144 (lane-per-env kernel: the HBM-regime kernel)",
-                                 "flight_easy", 3, 262144, "rollout", 200, 100, "lane"),
+                                 "flight_easy", 3, 262144, "rollout", 200, 100, "auto"),
                 side_measurement(cs, dev, comm, "flight_easy 3a15t B=1048576 (lane-per-env kernel; batch sweep asymptote)",
-                                 "flight_easy", 3, 1048576, "rollout", 100, 100, "lane"),
+                                 "flight_easy", 3, 1048576, "rollout", 100, 100, "auto"),
+                side_measurement(cs, dev, comm, "flight_easy 5a15t B=262144 (lane-per-env kernel)",
+                                 "flight_easy", 5, 262144, "rollout", 200, 100, "auto"),
+                side_measurement(cs, dev, comm, "flight_easy 5a15t B=1048576 (lane-per-env kernel)",
+                                 "flight_easy", 5, 1048576, "rollout", 100, 100, "auto"),
                 closed_loop_measurement(cs, dev, 3, 4096, 2000, 200),
                 closed_loop_measurement(cs, dev, 3, 65536, 400, 100),
                 closed_loop_measurement(cs, dev, 3, 8192, 400, 100, "flight"),

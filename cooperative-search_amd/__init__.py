@@ -12,7 +12,7 @@ from . import _lib as lib  # noqa: F401
 from . import dist  # noqa: F401
 from .replay import DeviceReplayBuffer  # noqa: F401
 from .agents import AgentRNN, BatchedAgents, FusedAgents, rnn_input_shape  # noqa: F401
-from .collector import EpisodeCollector, evaluate, collect_experiment_data, random_policy  # noqa: F401
+from .collector import EpisodeCollector, EpsilonSchedule, evaluate, collect_experiment_data, random_policy  # noqa: F401
 
 __all__ = ["BatchedFlightEnv", "FlightSearchEnvEasy", "FlightSearchEnv", "load_targets", "default_circle_dict",
            "get_flight_easy_args", "get_flight_args", "make_env_args", "lib"]

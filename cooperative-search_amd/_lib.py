@@ -5,7 +5,7 @@ import warnings
 
 from . import build as _build
 
-ABI_VERSION = 5   # CS_ABI_VERSION of include/coopsearch.h; bumped whenever an export or a struct changes
+ABI_VERSION = 6   # CS_ABI_VERSION of include/coopsearch.h; bumped whenever an export or a struct changes
 MT_STRIDE = 672    # CS_MT_STRIDE
 MAX_AGENTS = 8
 MAX_TARGETS = 16
@@ -18,7 +18,7 @@ FREEZE_DONE, AUTO_RESET, ACTIONS_I64, KERNEL_GROUP, KERNEL_LANE, KERNEL_SOLO, KE
 
 EXPORTS = ["cs_abi_version", "cs_source_hash", "cs_last_error", "cs_state_layout", "cs_init", "cs_seed", "cs_reset", "cs_step",
            "cs_rollout", "cs_rollout_policy", "cs_rollout_policy_flight", "cs_emit", "cs_metrics", "cs_mt_canonical", "cs_mt_advance", "cs_policy_packed_floats", "cs_policy_pack", "cs_policy_forward",
-           "cs_policy_conv_features", "cs_policy_last_error", "cs_store_episodes", "cs_episodes_last_error"]
+           "cs_policy_conv_features", "cs_policy_last_error", "cs_store_episodes", "cs_episodes_last_error", "cs_epsilon_step"]
 
 
 class CsConfig(C.Structure):
@@ -43,6 +43,12 @@ class CsLayout(C.Structure):
 class CsEpisodeOut(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("o", "u", "s", "r", "o_next", "s_next", "avail_u", "avail_u_next", "u_onehot",
                                           "padded", "terminated")]
+
+
+class CsEpsilon(C.Structure):
+    """cs_epsilon of include/coopsearch.h: the exploration schedule of common/rollout.py:35-41,75-76,133-135."""
+    _fields_ = [("epsilon", C.c_double), ("anneal", C.c_double), ("min_epsilon", C.c_double), ("per_step", C.c_int32),
+                ("reserved", C.c_int32), ("eps_dev", C.c_void_p), ("trace_dev", C.c_void_p)]
 
 
 class CoopSearchError(RuntimeError):
@@ -86,10 +92,11 @@ def load():
     L.cs_reset.argtypes = [C.POINTER(CsConfig), vp, vp, C.c_int, vp, vp, vp]
     L.cs_step.argtypes = [C.POINTER(CsConfig), vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.cs_rollout.argtypes = [C.POINTER(CsConfig), vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
-    L.cs_rollout_policy.argtypes = [C.POINTER(CsConfig), vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32,
+    L.cs_rollout_policy.argtypes = [C.POINTER(CsConfig), vp, vp, vp, vp, C.c_int, C.c_int, C.POINTER(CsEpsilon), C.c_uint64, C.c_uint32,
                                     C.c_uint64, C.c_int, vp, vp, vp, vp, vp, vp, vp]
-    L.cs_rollout_policy_flight.argtypes = [C.POINTER(CsConfig)] + [vp] * 11 + [C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32,
+    L.cs_rollout_policy_flight.argtypes = [C.POINTER(CsConfig)] + [vp] * 11 + [C.c_int, C.c_int, C.POINTER(CsEpsilon), C.c_uint64, C.c_uint32,
                                            C.c_uint64, C.c_int, vp, vp, vp, vp, vp, vp, vp]
+    L.cs_epsilon_step.argtypes = [C.POINTER(CsConfig), vp, C.c_int, vp, C.c_double, C.c_double, vp, vp]
     L.cs_emit.argtypes = [C.POINTER(CsConfig), vp, vp, vp, vp]
     L.cs_metrics.argtypes = [C.POINTER(CsConfig), vp, vp, vp]
     L.cs_mt_canonical.argtypes = [C.POINTER(CsConfig), vp, vp, vp]
@@ -100,7 +107,7 @@ def load():
     L.cs_store_episodes.argtypes = [C.c_int] * 6 + [vp] * 6 + [C.POINTER(CsEpisodeOut), vp]
     L.cs_policy_pack.argtypes = [vp] * 10 + [C.c_int, C.c_int, vp]
     L.cs_policy_forward.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int,
-                                    C.c_float, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, vp]
+                                    C.c_float, vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, vp]
     L.cs_policy_conv_features.argtypes = [vp] * 7 + [C.c_int64, C.c_int, vp, vp]
     for name in EXPORTS:
         fn = getattr(L, name)

@@ -196,11 +196,13 @@ class FusedAgents:
         sample = not (float(epsilon) == 0.0 and evaluate)
         return float(epsilon), self._lib.SELECT_SOFTMAX | (self._lib.SELECT_SAMPLE if sample else 0)
 
-    def choose_action(self, obs, epsilon=0.0, evaluate=False, want_q=False, last=None, out=None):
+    def choose_action(self, obs, epsilon=0.0, evaluate=False, want_q=False, last=None, out=None, eps_env=None):
         """obs: float32 [B, n, obs_shape] device tensor, contiguous (the env's live obs buffer works directly).
         Returns the int64 [B, n] action buffer (overwritten by the next call); it is also remembered as the
         next call's last action, like rollout.py:55-63.  A collector can pass `last` (int64 [B, n] previous actions,
-        -1 = none) and `out` (int64 [B, n] destination, e.g. row t of its action table) to avoid any copy."""
+        -1 = none) and `out` (int64 [B, n] destination, e.g. row t of its action table) to avoid any copy.
+        eps_env (float64 [B] device tensor): every env explores with its OWN epsilon (the per-env exploration schedule,
+        collector.EpsilonSchedule) instead of the scalar; ignored when evaluating, like rollout.py:35."""
         C = self._C
         width = self.cells + 4
         if obs.dtype != torch.float32 or obs.shape[-1] != width or obs.numel() != self.rows * width:
@@ -216,17 +218,22 @@ class FusedAgents:
         if self.conv:  # the map of an env's first row stands for all its rows (flight_env.py:223-230)
             self._conv_features(obs, self.n_agents * width, self.batch, self.feat)
         eps, sel = self.selection(epsilon, evaluate)
+        if evaluate and not self.softmax:
+            eps_env = None   # epsilon = 0 if evaluate (rollout.py:35)
+        if eps_env is not None and (eps_env.dtype != torch.float64 or eps_env.numel() != self.batch or not eps_env.is_contiguous()):
+            raise ValueError("eps_env must be a contiguous float64 [B] tensor")
         if self._ops is not None:
             self._ops.policy_forward(self.packed, obs, width, self.cells, last, self.feat if self.conv else None, self.n_agents,
                                      self.hidden, self.q if want_q else None, out, self.rows, self.n_agents, self.n_actions, eps,
-                                     self.seed, self.calls, self.row0, sel)
+                                     eps_env, self.seed, self.calls, self.row0, sel)
             self.calls += 1
             return out
         with self._on_device():
             self._check(self._L.cs_policy_forward(vp(self.packed), vp(obs), width, self.cells, vp(last),
                                                   vp(self.feat) if self.conv else None, self.n_agents, vp(self.hidden),
                                                   vp(self.q) if want_q else None, vp(out), self.rows, self.n_agents,
-                                                  self.n_actions, eps, self.seed, self.calls, self.row0, sel, self._stream()))
+                                                  self.n_actions, eps, vp(eps_env) if eps_env is not None else None, self.seed,
+                                                  self.calls, self.row0, sel, self._stream()))
         self.calls += 1
         return out
 
@@ -243,13 +250,13 @@ class FusedAgents:
         if self._ops is not None:
             self._ops.policy_forward(self.packed, x, x.stride(0), self.cells, None, feat, 1, self.hidden,
                                      self.q if want_q else None, self.actions, self.rows, self.n_agents, self.n_actions, 0.0,
-                                     self.seed, self.calls, self.row0, 0)
+                                     None, self.seed, self.calls, self.row0, 0)
             return self.actions
         with self._on_device():
             self._check(self._L.cs_policy_forward(vp(self.packed), vp(x), x.stride(0), self.cells, None,
                                                   vp(feat) if self.conv else None, 1, vp(self.hidden),
                                                   vp(self.q) if want_q else None, vp(self.actions), self.rows, self.n_agents,
-                                                  self.n_actions, 0.0, self.seed, self.calls, self.row0, 0, self._stream()))
+                                                  self.n_actions, 0.0, None, self.seed, self.calls, self.row0, 0, self._stream()))
         return self.actions
 
     def policy(self, epsilon=0.0, evaluate=True):

@@ -76,12 +76,50 @@ def assemble_episodes_torch(o, s, u, r, term, n_actions):
         terminated=bt(torch.where(real, term.to(torch.float32), torch.ones_like(rf))[..., None]))
 
 
+class EpsilonSchedule:
+    """The exploration schedule a RolloutWorker carries (common/rollout.py:17-19, 35-41, 75-76, 133-135; defaults of
+    common/arguments.py:78-82: epsilon 1 -> 0.05 over 10000 steps, scale 'step').  The reference has one worker and one scalar;
+    a batch of B envs is B workers, each with its OWN epsilon (float64 [B] on the device), annealed by its own executed steps
+    with the reference's rule `epsilon = epsilon - anneal_epsilon if epsilon > min_epsilon else epsilon`:
+        'step'     after every executed env step -- on the device, inside the fused rollout (cs_epsilon) or by
+                   cs_epsilon_step in a per-step loop;
+        'episode'  once before every episode (rollout.py:36-38);
+        'epoch'    once before the episode with episode_num == 0 (:39-41).
+    The values persist across generate_episodes calls (rollout.py:133-135)."""
+
+    def __init__(self, args, batch, device="cuda"):
+        self.anneal = float(args.anneal_epsilon)
+        self.min_epsilon = float(args.min_epsilon)
+        self.scale = getattr(args, "epsilon_anneal_scale", "step")
+        if self.scale not in ("step", "episode", "epoch"):
+            raise ValueError("epsilon_anneal_scale must be 'step', 'episode' or 'epoch'")
+        self.values = torch.full((int(batch),), float(args.epsilon), dtype=torch.float64, device=device)
+
+    @property
+    def per_step(self):
+        return self.scale == "step"
+
+    def anneal_once(self):
+        v = self.values
+        self.values = torch.where(v > self.min_epsilon, v - self.anneal, v)   # IEEE double subtraction, like the reference's floats
+        return self.values
+
+    def begin_episode(self, episode_num=None):
+        """What generate_episode does to epsilon before its loop (rollout.py:36-41)."""
+        if self.scale == "episode" or (self.scale == "epoch" and episode_num == 0):
+            self.anneal_once()
+        return self.values
+
+
 class EpisodeCollector:
-    def __init__(self, env):
+    def __init__(self, env, schedule=None):
+        """schedule (an `EpsilonSchedule`): the exploration schedule this collector carries across generate_episodes calls,
+        as RolloutWorker carries self.epsilon; without one, `epsilon` of each call is used as a constant."""
         self.env = env
+        self.schedule = schedule
 
     def generate_episodes(self, policy=None, actions=None, init=False, agents=None, epsilon=0.0, evaluate=True,
-                          one_launch=True, into=None):
+                          one_launch=True, into=None, episode_num=None, eps_trace=None):
         """One episode per env.  Either `actions` (open-loop table, int [T, B, n]; flight_easy runs it as ONE fused
         rollout launch), `policy(obs[B,n,obs], state[B,S], last_onehot[B,n,A], t) -> int actions [B, n]`, or `agents`
         (a `FusedAgents`: flight_easy with n <= 5 and one_launch: the WHOLE episode -- T x (network forward, env step)
@@ -89,8 +127,16 @@ class EpisodeCollector:
         [T, ...] episode tables, no copies).
         `into` (a `DeviceReplayBuffer`): the batch is written straight into the buffer's next B ring slots
         (store_episode without the intermediate copy) and the returned episode dict is None.
+        With a schedule (see __init__) and evaluate=False the envs explore with their own, annealing epsilon
+        (episode_num: the reference's argument, only the 'epoch' scale looks at it; eps_trace: float64 [T, B] that receives the
+        epsilon of every step's selection).
         Returns (episode dict of float32 [B, T, ...] tensors, episode_reward[B], win_tag[B] bool, targets_find[B])."""
         env = self.env
+        sched = self.schedule if (self.schedule is not None and not evaluate and agents is not None) else None
+        if sched is not None:
+            sched.begin_episode(episode_num)
+        kw = {} if sched is None else dict(eps_env=sched.values, anneal=sched.anneal, min_epsilon=sched.min_epsilon,
+                                           per_step=sched.per_step, eps_trace=eps_trace)
         B, n, T, A = env.batch, env.n_agents, env.time_limit, env.n_actions
         dev = env.device
         saved = (env.freeze_done, env.auto_reset)
@@ -116,12 +162,17 @@ class EpisodeCollector:
             elif agents is not None and one_launch and not env.flight and n <= 5:
                 agents.init_hidden()
                 env.rollout_policy(agents, T, epsilon, evaluate,
-                                   out=dict(actions=u, reward=r, terminated=term, obs=o[1:], state=s[1:]))
+                                   out=dict(actions=u, reward=r, terminated=term, obs=o[1:], state=s[1:]), **kw)
             elif agents is not None:
                 agents.init_hidden()
                 none = torch.full((B, n), -1, dtype=torch.int64, device=dev)
                 for t in range(T):
-                    agents.choose_action(o[t], epsilon, evaluate, last=u[t - 1] if t else none, out=u[t])
+                    agents.choose_action(o[t], epsilon, evaluate, last=u[t - 1] if t else none, out=u[t],
+                                         eps_env=sched.values if sched is not None else None)
+                    if sched is not None and (sched.per_step or eps_trace is not None):   # rollout.py:75-76, before the step it follows
+                        env.epsilon_step(sched.values, sched.anneal if sched.per_step else 0.0,
+                                         sched.min_epsilon if sched.per_step else 1e300,
+                                         eps_trace[t] if eps_trace is not None else None)
                     env.step(u[t], out=dict(reward=r[t], terminated=term[t], obs=o[t + 1], state=s[t + 1]))
                 env.refresh()
             else:
@@ -182,12 +233,29 @@ def evaluate(env, policy, batches=1):
     return m["win_rate"], m["episode_reward"], m["targets_find"]
 
 
-def collect_experiment_data(env, policy, batches=1):
-    """runner.py:139-171: percent of targets found by step t (float64[episode_limit]), reset(init=True) per
-    episode as generate_replay does, averaged over batches * B * world episodes."""
+def collect_experiment_data(env, policy, batches=1, num=None, result_path=None, return_stats=False):
+    """Runner.collect_experiment_data (runner.py:139-171): percent of targets found by step t (float64[episode_limit]),
+    reset(init=True) per episode as generate_replay does (rollout.py:143-204), averaged over batches * B * world episodes,
+    plus the three means the reference prints -- targets found, episode reward, episode length (runner.py:163-165).
+    num + result_path: rank 0 writes `average_res_<num>.npy` into result_path, the file the reference saves (:171).
+    Returns the curve, or (curve, {'targets_find', 'episode_reward', 'steps', 'episodes'}) with return_stats."""
     curve = _dist.FoundCurve(env.time_limit, env.target_num, env.device)
+    part = torch.zeros(4, dtype=torch.float64, device=env.device)   # sum target_find, sum reward, sum steps, episodes
     for _ in range(batches):
         for t, tf in _run_episodes(env, policy, init=True):
             curve.add_step(t, tf)
         curve.end_episodes(env.batch)
-    return curve.result()
+        # (a finished env is frozen: its counters are those of its last executed step, i.e. generate_replay's return values)
+        part += torch.stack([env.target_find.to(torch.float64).sum(), env.total_reward.to(torch.float64).sum(),
+                             env.time_step.to(torch.float64).sum(),
+                             torch.tensor(float(env.batch), dtype=torch.float64, device=env.device)])
+    res = curve.result()
+    tot = _dist.all_gather_sum(part)
+    n = float(tot[3].item())
+    stats = {"targets_find": float(tot[0].item()) / n, "episode_reward": float(tot[1].item()) / n,
+             "steps": float(tot[2].item()) / n, "episodes": int(n)}
+    if num is not None and result_path is not None and _dist.rank() == 0:
+        import numpy as np
+        os.makedirs(result_path, exist_ok=True)
+        np.save(os.path.join(result_path, "average_res_{}".format(num)), res)   # runner.py:171 (np.save appends .npy)
+    return (res, stats) if return_stats else res

@@ -1862,7 +1862,11 @@ struct PolicyIO {
     float *hidden;           // [B*N][64] in/out
     const int64_t *last;     // [B][N] action before the first step (< 0 = none)
     int64_t *actions;        // [T][B][N] chosen actions
-    float epsilon;
+    double epsilon;          // exploration schedule (cs_epsilon): start value when eps_dev is null,
+    double anneal, min_eps;  //   the step-scale rule of common/rollout.py:75-76,
+    int per_step;            //   applied after every executed env step if set,
+    double *eps_dev;         //   per-env values [B] in / out (null: `epsilon` throughout),
+    double *trace;           //   the value every env's selection used at every step [T][B] (null: none)
     unsigned long long seed;
     unsigned step0;          // epsilon-greedy counter of the first step (one per step, as one cs_policy_forward call each)
     unsigned long long row0; // global index of network row 0 (sharded batches)
@@ -1875,6 +1879,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io
     __shared__ WaveTile tiles[BLOCK / 64];
     __shared__ int s_act[16 * N];          // last / chosen action per row (row = env_in_block * N + agent)
     __shared__ float s_b3[16];
+    __shared__ double s_eps[BLOCK / G];    // the block's 16 envs' epsilon (cs_epsilon: annealed env by env, rollout.py:75-76)
     extern __shared__ float pol_lds[];     // s_a | s_b | s_h, each [16N][LDW]; the partial q of fc2 aliases s_a
     constexpr int ROWS = 16 * N, NA = 3;   // the env has three actions (flight_env_easy.py:32)
     float *s_a = pol_lds, *s_b = pol_lds + ROWS * LDW, *s_h = pol_lds + 2 * ROWS * LDW;
@@ -1920,6 +1925,8 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io
     const float bir = pio.w[OFF_BIH + col], biz = pio.w[OFF_BIH + 64 + col], bin = pio.w[OFF_BIH + 128 + col];
     const float bhr = pio.w[OFF_BHH + col], bhz = pio.w[OFF_BHH + 64 + col], bhn = pio.w[OFF_BHH + 128 + col];
     if (threadIdx.x < 16) s_b3[threadIdx.x] = pio.w[OFF_B3 + threadIdx.x];
+    if (threadIdx.x < BLOCK / G)
+        s_eps[threadIdx.x] = (pio.eps_dev && b0 + (int)threadIdx.x < p.B) ? pio.eps_dev[b0 + threadIdx.x] : pio.epsilon;
     // hidden state and last actions of the block's rows -> LDS
     const int srow = threadIdx.x >> 4, kcol = threadIdx.x & 15;
 #pragma unroll
@@ -2036,9 +2043,14 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io
                 return ((s_q[o] + s_q[ROWS * 17 + o]) + (s_q[2 * ROWS * 17 + o] + s_q[3 * ROWS * 17 + o])) + s_b3[a];
             };
             const unsigned long long grow = pio.row0 + (unsigned long long)(b0 * N + r);
-            const int act = select_action(qf, NA, pio.select, pio.epsilon, pio.seed, pio.step0 + (unsigned)s, grow);
+            const int er = r / N;   // the row's env within the block
+            const double eps = s_eps[er];
+            const int act = select_action(qf, NA, pio.select, (float)eps, pio.seed, pio.step0 + (unsigned)s, grow);
             s_act[r] = act;
-            if (r < rows_valid) pio.actions[((size_t)s * p.B + b0) * N + r] = act;
+            if (r < rows_valid) {
+                pio.actions[((size_t)s * p.B + b0) * N + r] = act;
+                if (pio.trace && r == er * N) pio.trace[(size_t)s * p.B + b0 + er] = eps;
+            }
         }
         __syncthreads();
         // ---- env.step with the chosen actions
@@ -2046,9 +2058,17 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io
         const int el = 4 * w + grp;
 #pragma unroll
         for (int i = 0; i < N; i++) act[i] = s_act[el * N + i];
+        // will this env execute the step?  (step_once: an env terminated on entry is reset first under CS_AUTO_RESET, left alone
+        // under CS_FREEZE_DONE): only executed steps anneal (the reference's episode loop has ended for a finished env)
+        const bool executed = live && !((e.target_find >= p.n_targets || e.time_step >= p.time_limit) &&
+                                        !(io.flags & CS_AUTO_RESET) && (io.flags & CS_FREEZE_DONE));
         if (wave_valid)
             step_once<N, 0>(p, T, io, tile, b, lane, (size_t)s * p.B + wave_b0, plan, live, act, win, s + 1 < io.T,
                             PIPE && s > 0, (size_t)(s - 1) * p.B + wave_b0, PIPE, e, no_tape, false, false);
+        if (pio.per_step && pio.eps_dev && executed && t == 0) {   // epsilon = epsilon - anneal if epsilon > min else epsilon
+            const double v = s_eps[el];
+            s_eps[el] = v > pio.min_eps ? v - pio.anneal : v;
+        }
     }
     if (PIPE && wave_valid) {  // rows of the last step
         FlushRegs<N> fr;
@@ -2057,6 +2077,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io
     }
     if (live) env_store<N>(p, b, t, e, false);
     __syncthreads();
+    if (pio.eps_dev && threadIdx.x < BLOCK / G && b0 + (int)threadIdx.x < p.B) pio.eps_dev[b0 + threadIdx.x] = s_eps[threadIdx.x];
 #pragma unroll
     for (int m = 0; m < N; m++) {
         const int r = 16 * m + srow;
@@ -2098,6 +2119,9 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io
 #ifndef CS_LANE_FROM
 #define CS_LANE_FROM 131072     /* default kernel of cs_rollout from this many envs: one env per lane (65536: octet 7.6e9
                                    against lane 7.1e9 env-steps/s at 3 agents, 5.0e9 against 4.8e9 at 5; 262144: 8.0 / 10.4) */
+#endif
+#ifndef CS_LANEV_DEFAULT
+#define CS_LANEV_DEFAULT 1      /* the lane-per-env kernel of teams of up to 5 is k_rollout_lanev (rollout_lanev.h) */
 #endif
 #ifndef CS_ODE_UPTO
 #define CS_ODE_UPTO 10240       /* ... up to this many envs with the third (emitting) wavefront: five 3-wavefront workgroups per CU x 256 CUs x 8 envs */
@@ -2835,6 +2859,35 @@ struct OctKin {   // one lane's agent during the kinematics of a step
     bool hit;            // wall flag of the position in (cx, cy) once the own stage has run
 };
 
+// (qx, qy) = (nx / den, ny / den), each quotient the correctly rounded IEEE one -- bit for bit what `/` gives -- with ONE reciprocal
+// for both (flight_env_easy.py:299-300 divides the two components of a repulsion term by the same squared distance).  The
+// compiler expands an fp64 division into v_div_scale x2, v_rcp_f64, two Newton steps on the reciprocal, the quotient and its
+// fused residual correction (v_div_fmas) and v_div_fixup: ~16 instructions, of which the reciprocal part depends on the
+// denominator alone.  For operands whose exponents are far from the ends of the range (here: squared distances below 9, terms
+// below 3) v_div_scale scales nothing and v_div_fixup changes nothing, so the sequence below IS that expansion with the
+// reciprocal shared; anything else (never seen: a squared distance below 1e-30) takes the plain divisions.
+#ifndef CS_SHARED_RCP_DIV
+#define CS_SHARED_RCP_DIV 1
+#endif
+__device__ __forceinline__ void div2_same_denominator(double nx, double ny, double den, double &qx, double &qy) {
+#if CS_SHARED_RCP_DIV
+    const double LO = 0x1p-100, HI = 0x1p100;
+    const double ax = fabs(nx), ay = fabs(ny);
+    const bool plain = (den >= LO) & (den <= HI) & ((ax == 0.0) | ((ax >= LO) & (ax <= HI))) & ((ay == 0.0) | ((ay >= LO) & (ay <= HI)));
+    if (__builtin_expect(__ballot(!plain) == 0ull, 1)) {
+        double r = __builtin_amdgcn_rcp(den);
+        r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+        r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+        const double mx = nx * r, my = ny * r;
+        qx = __builtin_fma(__builtin_fma(-den, mx, nx), r, mx);
+        qy = __builtin_fma(__builtin_fma(-den, my, ny), r, my);
+        return;
+    }
+#endif
+    qx = nx / den;
+    qy = ny / den;
+}
+
 // Stage I of the reference's sequential loop over agents (flight_env_easy.py:260-290, quirk Q7), for all 8 envs of the
 // wavefront at once: every OTHER agent J tests itself against agent I's pre-move position -- its own position being the
 // already-moved one if J < I -- and, if it is within force_dist, computes its term of I's repulsion (:293-301); the terms
@@ -2852,8 +2905,10 @@ struct OctStage {
             if (__ballot(inr)) {   // wave-uniform
                 const double ex = xi - k.cx, ey = yi - k.cy;
                 const double den = ex * ex + ey * ey;
-                const double tx = inr ? p.force_k * ex / den : 0.0;
-                const double ty = inr ? p.force_k * ey / den : 0.0;
+                double qx, qy;
+                div2_same_denominator(p.force_k * ex, p.force_k * ey, inr ? den : 1.0, qx, qy);   // force_k*(x-x_a)/den: product first
+                const double tx = inr ? qx : 0.0;
+                const double ty = inr ? qy : 0.0;
                 double fx = 0.0, fy = 0.0;
                 OctForceSum<N, I>::run(tx, ty, fx, fy);
                 const double x = (k.cx + p.velocity * k.c1) + fx;   // lane I: (x + v*cos) + f_x on its pre-move position
@@ -2888,7 +2943,25 @@ __device__ __forceinline__ unsigned oct_kinematics(const DevParams &p, const dou
     const double yw = yaw, yr = (yaw <= PI) ? PI - yaw : THREE_PI - yaw;
     double s1, c1, s2, c2;
     KIN_STAMP(3);
-    trig_heading_pair(T, yw, yr, s1, c1, s2, c2);
+#ifndef CS_OCT_TRIG_SPLIT
+#define CS_OCT_TRIG_SPLIT 1   /* teams of up to 4: the wall reflection's sin / cos come from the idle lane four places up */
+#endif
+    if constexpr (CS_OCT_TRIG_SPLIT && N <= 4) {
+        // Lanes 4..7 of an octet hold no agent.  Lane t + 4 evaluates agent t's REFLECTED heading while lane t evaluates the new
+        // one: one correctly rounded evaluation per lane instead of two interleaved ones -- the chain is as long, but a lone
+        // wavefront is bound by instruction issue (one per ~4.5 cycles), and the pair is ~100 instructions (same values: the
+        // pair IS two single evaluations).  Octets are aligned halves of the 16-lane DPP rows: row_shr:4 / row_shl:4 stay
+        // inside the octet for the lanes that use the result.
+        const double yr_up = dpp_f64<0x114>(yr);          // lane L receives lane L - 4's reflected heading
+        double sm, cm;
+        trig_heading(T, t >= 4 ? yr_up : yw, sm, cm);
+        s1 = sm;
+        c1 = cm;
+        s2 = dpp_f64<0x104>(sm);                          // lane L receives lane L + 4's result
+        c2 = dpp_f64<0x104>(cm);
+    } else {
+        trig_heading_pair(T, yw, yr, s1, c1, s2, c2);
+    }
     KIN_STAMP(4);
     // the move every agent makes unless a neighbour is within force_dist: (x + v*cos) + 0.0 -- the "+ 0.0" so that even
     // signed zeros agree with the reference's `x += force[0]`
@@ -4614,6 +4687,19 @@ __global__ void k_fill_prob(float *prob, size_t n4) {
     for (; i < n4; i += stride) reinterpret_cast<float4 *>(prob)[i] = make_float4(0.5f, 0.5f, 0.5f, 0.5f);
 }
 
+// One step of the exploration schedule for per-step callers (cs_epsilon_step): the envs the next cs_step(flags) will execute
+// anneal, the others keep their value; `trace` receives what this step's selection used.
+__global__ void k_eps_step(DevParams p, int flags, double *eps, double anneal, double min_eps, double *trace) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= p.B) return;
+    const int *h = p.hdr + (size_t)b * CS_H_WORDS;
+    const bool done = h[CS_H_TARGET_FIND] >= p.n_targets || h[CS_H_TIME_STEP] >= p.time_limit;
+    const bool executed = !(done && !(flags & CS_AUTO_RESET) && (flags & CS_FREEZE_DONE));
+    const double v = eps[b];
+    if (trace) trace[b] = v;
+    if (executed) eps[b] = v > min_eps ? v - anneal : v;   // common/rollout.py:75-76
+}
+
 __global__ void k_metrics(DevParams p, double *out4) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
@@ -4790,9 +4876,6 @@ void launch_lanev(const cs_config *cfg, const DevParams &p, StepIO io, hipStream
 }
 // Which lane-per-env kernel: k_rollout_lanev for teams of up to 5 (its in-loop MT19937 refresh tops up one env per wavefront
 // and step, which covers the draw rate of those teams), k_rollout_lane (+ the k_mt_advance pre-pass) for larger ones.
-#ifndef CS_LANEV_DEFAULT
-#define CS_LANEV_DEFAULT 1
-#endif
 inline bool use_lanev(const cs_config *c, int flags) {
     if (c->n_agents > CS_LANE_REFRESH_MAX_N) return false;
     if (flags & CS_KERNEL_LANEV) return true;
@@ -4847,7 +4930,16 @@ void launch_od(const cs_config *cfg, const DevParams &p, StepIO io, hipStream_t 
 // cs_rollout: the lane kernel's lower bound, by bench.py's protocol (tools/gpu_r3_z.sh): 3 agents 65536 envs octet 7.8e9 against
 // lane 7.3e9, 98304 8.0 / 8.2, 131072 8.2 / 10.4; 5 agents (the 250-VGPR lane variant) 262144 octet 5.6e9 against lane 4.9e9,
 // 524288 5.7 / 5.0, 2^20 5.8 / 6.4.
-inline long long lane_from(const cs_config *c) { return c->n_agents <= 4 ? CS_LANE_FROM : CS_LANE_FROM_LARGE_TEAMS; }
+// k_rollout_lanev (teams of up to 5) takes over from the octet kernel at 65536 envs -- one wavefront per SIMD -- (tools/gpu_r4_d.sh:
+// 3 agents 32768 envs octet 6.0e9 against lanev 4.4e9, 65536: 7.0 / 8.1, 131072: 7.8 / 11.2; 5 agents 32768: 4.2 / 3.0,
+// 65536: 4.8 / 5.7, 131072: 5.3 / 7.8)
+#ifndef CS_LANEV_FROM
+#define CS_LANEV_FROM 65536
+#endif
+inline long long lane_from(const cs_config *c) {
+    if (CS_LANEV_DEFAULT && c->n_agents <= CS_LANE_REFRESH_MAX_N) return CS_LANEV_FROM;
+    return c->n_agents <= 4 ? CS_LANE_FROM : CS_LANE_FROM_LARGE_TEAMS;
+}
 // Kernel choice for flight_easy: one env per 16-lane group (lowest latency, fills the chip from B = 4096) or one
 // env per lane (no replicated arithmetic; wins once the batch gives every SIMD a wavefront anyway).
 inline bool use_lane_kernel(const cs_config *c, int flags, bool rollout) {
@@ -5084,19 +5176,23 @@ int cs_rollout(const cs_config *cfg, void *state_dev, const void *actions_dev, i
 }
 
 int cs_rollout_policy(const cs_config *cfg, void *state_dev, const float *packed_dev, float *hidden_dev,
-                      const int64_t *last_dev, int T, int flags, float epsilon, uint64_t seed, uint32_t step0,
+                      const int64_t *last_dev, int T, int flags, const cs_epsilon *eps, uint64_t seed, uint32_t step0,
                       uint64_t row0, int select, int64_t *actions_dev, float *reward_dev, uint8_t *terminated_dev,
                       uint8_t *win_dev, float *obs_dev, float *state_out_dev, void *stream) {
     DevParams p;
     int rc = make_params(cfg, state_dev, &p);
     if (rc) return rc;
     if (cfg->variant != 0) return fail(CS_E_CONFIG, "cs_rollout_policy: flight_easy only");
+    const cs_epsilon greedy = {0.0, 0.0, 0.0, 0, 0, nullptr, nullptr};
+    if (!eps) eps = &greedy;
+    if (eps->trace_dev && !eps->eps_dev) return fail(CS_E_ARG, "cs_epsilon: trace_dev needs eps_dev");
     if (cfg->n_agents > 5) return fail(CS_E_CONFIG, "cs_rollout_policy: at most 5 agents");
     if (T < 1) return fail(CS_E_ARG, "T must be >= 1");
     if (!packed_dev || !hidden_dev || !last_dev || !actions_dev || !reward_dev || !terminated_dev || !win_dev)
         return fail(CS_E_ARG, "null rollout buffer");
     StepIO io{nullptr, reward_dev, terminated_dev, win_dev, obs_dev, state_out_dev, flags, T};
-    PolicyIO pio{packed_dev, hidden_dev, last_dev, actions_dev, epsilon, seed, step0, row0, select};
+    PolicyIO pio{packed_dev, hidden_dev, last_dev, actions_dev, eps->epsilon, eps->anneal, eps->min_epsilon, eps->per_step,
+                 eps->eps_dev, eps->trace_dev, seed, step0, row0, select};
     const size_t lds = (size_t)3 * 16 * cfg->n_agents * LDW * sizeof(float);
 #define CS_LAUNCH_RP(NN)                                                                                               \
     case NN: {                                                                                                         \
@@ -5116,12 +5212,15 @@ int cs_rollout_policy(const cs_config *cfg, void *state_dev, const float *packed
 int cs_rollout_policy_flight(const cs_config *cfg, void *state_dev, const float *packed_dev, const float *conv1_w_dev,
                              const float *conv1_b_dev, const float *conv2_w_dev, const float *conv2_b_dev,
                              const float *lin_w_dev, const float *lin_b_dev, float *hidden_dev, const int64_t *last_dev,
-                             float *scratch_dev, int T, int flags, float epsilon, uint64_t seed, uint32_t step0, uint64_t row0,
+                             float *scratch_dev, int T, int flags, const cs_epsilon *eps, uint64_t seed, uint32_t step0, uint64_t row0,
                              int select, int64_t *actions_dev, float *reward_dev, uint8_t *terminated_dev, uint8_t *win_dev,
                              float *obs_dev, float *state_out_dev, void *stream) {
     DevParams p;
     int rc = make_params(cfg, state_dev, &p);
     if (rc) return rc;
+    const cs_epsilon greedy = {0.0, 0.0, 0.0, 0, 0, nullptr, nullptr};
+    if (!eps) eps = &greedy;
+    if (eps->trace_dev && !eps->eps_dev) return fail(CS_E_ARG, "cs_epsilon: trace_dev needs eps_dev");
     if (cfg->variant != 1) return fail(CS_E_CONFIG, "cs_rollout_policy_flight: flight only");
     if (cfg->map_size != 50) return fail(CS_E_CONFIG, "cs_rollout_policy_flight: the conv front end is built for map_size 50");
     if (T < 1) return fail(CS_E_ARG, "T must be >= 1");
@@ -5149,8 +5248,12 @@ int cs_rollout_policy_flight(const cs_config *cfg, void *state_dev, const float 
         int64_t *act = actions_dev + (size_t)t * B * n;
         if (cs_policy_forward(packed_dev, own, prev_rows ? p.cells + 4 : 4, prev_rows ? p.cells : 0,
                               t == 0 ? last_dev : act - B * n, feat, cfg->n_agents, hidden_dev, nullptr, act, (int)(B * n),
-                              cfg->n_agents, NA, epsilon, seed, step0 + (uint32_t)t, row0, select, stream) != CS_OK)
+                              cfg->n_agents, NA, (float)eps->epsilon, eps->eps_dev, seed, step0 + (uint32_t)t, row0, select, stream) != CS_OK)
             return fail(CS_E_LAUNCH, cs_policy_last_error());
+        if (eps->eps_dev && (eps->per_step || eps->trace_dev))   // the schedule's step, before the env step it belongs to
+            hipLaunchKernelGGL(k_eps_step, dim3((unsigned)((p.B + 255) / 256)), dim3(256), 0, s, p, flags, eps->eps_dev,
+                               eps->per_step ? eps->anneal : 0.0, eps->per_step ? eps->min_epsilon : 1.0e300,
+                               eps->trace_dev ? eps->trace_dev + (size_t)t * B : nullptr);
         StepIO it{act, reward_dev + (size_t)t * B, terminated_dev + (size_t)t * B, win_dev + (size_t)t * B,
                   obs_dev ? obs_dev + (size_t)t * B * obs_w : tails,
                   state_out_dev ? state_out_dev + (size_t)t * B * W : nullptr, flags | CS_ACTIONS_I64, 1};
@@ -5164,6 +5267,17 @@ int cs_rollout_policy_flight(const cs_config *cfg, void *state_dev, const float 
         }
     }
     return launched("cs_rollout_policy_flight");
+}
+
+int cs_epsilon_step(const cs_config *cfg, void *state_dev, int flags, double *eps_dev, double anneal, double min_epsilon,
+                    double *trace_row_dev, void *stream) {
+    DevParams p;
+    int rc = make_params(cfg, state_dev, &p);
+    if (rc) return rc;
+    if (!eps_dev) return fail(CS_E_ARG, "null epsilon buffer");
+    hipLaunchKernelGGL(k_eps_step, dim3((unsigned)((p.B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, flags, eps_dev, anneal,
+                       min_epsilon, trace_row_dev);
+    return launched("cs_epsilon_step");
 }
 
 int cs_mt_advance(const cs_config *cfg, void *state_dev, int min_ahead, void *stream) {

@@ -34,6 +34,7 @@ namespace {
 struct PolicyParams {
     int rows, n_agents, n_actions, obs_stride, obs_offset;  // obs row r starts at obs + r*obs_stride + obs_offset (4 floats)
     float epsilon;
+    const double *eps_env;   // null, or [rows / n_agents]: per-env epsilon (cs_epsilon schedule) instead of `epsilon`
     unsigned long long seed;
     unsigned step;
     unsigned long long row0; // global index of row 0 (sharded batches: env_offset * n_agents)
@@ -207,7 +208,8 @@ __global__ __launch_bounds__(PBLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             };
             if (p.q && row < p.rows)
                 for (int a = 0; a < p.n_actions; a++) p.q[(size_t)row * p.n_actions + a] = qf(a);
-            const int act = select_action(qf, p.n_actions, p.select, p.epsilon, p.seed, p.step, p.row0 + (unsigned long long)row);
+            const float eps = p.eps_env ? (float)p.eps_env[(row < p.rows ? row : p.rows - 1) / p.n_agents] : p.epsilon;
+            const int act = select_action(qf, p.n_actions, p.select, eps, p.seed, p.step, p.row0 + (unsigned long long)row);
             if (row < p.rows) p.actions[row] = act;
         }
         POL_STAMP(6);
@@ -440,15 +442,15 @@ int cs_policy_pack(const float *fc1_w, const float *fc1_b, const float *w_ih, co
 // hidden_dev [rows][64] is updated in place; q_dev (nullable) [rows][n_actions]; actions_dev [rows] int64.
 int cs_policy_forward(const float *packed_dev, const float *obs_dev, int obs_stride, int obs_offset, const int64_t *last_dev,
                       const float *feat_dev, int rows_per_feat, float *hidden_dev, float *q_dev, int64_t *actions_dev,
-                      int rows, int n_agents, int n_actions, float epsilon, uint64_t seed, uint32_t step, uint64_t row0,
-                      int select, void *stream) {
+                      int rows, int n_agents, int n_actions, float epsilon, const double *eps_env_dev, uint64_t seed, uint32_t step,
+                      uint64_t row0, int select, void *stream) {
     const int in_dim = (feat_dev ? NFEAT : 0) + 4 + n_actions + n_agents;
     if (!packed_dev || !obs_dev || !hidden_dev || !actions_dev || rows < 1 || n_agents < 1 || n_actions < 1 ||
         in_dim > KIN_MAX || (feat_dev && rows_per_feat < 1)) {
         snprintf(g_perr, sizeof(g_perr), "cs_policy_forward: bad argument (input width %d, limit %d)", in_dim, KIN_MAX);
         return CS_E_ARG;
     }
-    PolicyParams p{rows, n_agents, n_actions, obs_stride, obs_offset, epsilon, seed, step, row0, select, packed_dev, obs_dev, last_dev,
+    PolicyParams p{rows, n_agents, n_actions, obs_stride, obs_offset, epsilon, eps_env_dev, seed, step, row0, select, packed_dev, obs_dev, last_dev,
                    feat_dev, rows_per_feat, hidden_dev, q_dev, actions_dev};
     const int tiles = (rows + 15) / 16;
     if (in_dim <= 16) {

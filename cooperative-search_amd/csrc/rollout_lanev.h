@@ -5,8 +5,11 @@
 // env-step against the octet kernels' 60 -- but sits at 210-250 VGPRs and 16.6 KB of LDS per wavefront (the 64 get_state rows
 // of a step staged as one tile), i.e. TWO wavefronts per SIMD, and the SQ counters show each of them waiting 43 % of its
 // cycles: the VALU pipe is idle half the time (profiles/r03_lane3_pmc.json).  This kernel keeps the layout and the per-env
-// arithmetic (same functions / same expression order: bit-identical results) and is built for THREE to FOUR wavefronts per
-// SIMD instead:
+// arithmetic (same functions / same expression order: bit-identical results) and was built for three to four wavefronts per
+// SIMD.  What it bought is something else (profiles/r04_lanev.md): occupancy turned out NOT to be the lever -- k_rollout_lane<5>
+// runs as fast with one wavefront per SIMD as with two, and this kernel capped at 168 VGPRs spills and loses -- but the
+// restructured step issues fewer instructions and waits less, at the same two wavefronts per SIMD (5 agents, 2^18 envs: 42.4 ->
+// 34.1 us per step).  The design points:
 //   * kinematics agent by agent, the reference's own order (flight_env_easy.py:255-301): the two headings of ONE agent
 //     (new heading, wall reflection) are evaluated together (trig_heading_pair), then its repulsion, move and wall rule --
 //     the 6 n doubles of all headings of a step are never live together (60 VGPRs at 5 agents); the instruction-level
@@ -27,11 +30,15 @@
 // variant is unconditional, so the wait for the actions never waits for a store (one in-order counter for loads and stores).
 #pragma once
 
+// Wavefronts per SIMD the register budget must allow.  Measured (profiles/r04_lanev.md): the kernel wants ~210 VGPRs at 3 agents
+// and ~240 at 5; capped at 168 (three wavefronts) the 3-agent variant spills 23 registers and runs 40.6 % of the HBM roofline at
+// 2^18 envs against 44.0 % uncapped (4096 wavefronts = 1.33 resident rounds instead of 2 full ones) but 49.3 % against 46.0 % at
+// 2^20; the 5-agent variant spills 670 and halves.  So: two.
 #ifndef CS_LV_WAVES_SMALL
-#define CS_LV_WAVES_SMALL 4   /* wavefronts per SIMD the register budget must allow, teams of up to 3 (128 VGPRs) */
+#define CS_LV_WAVES_SMALL 2   /* teams of up to 3 */
 #endif
 #ifndef CS_LV_WAVES_MID
-#define CS_LV_WAVES_MID 3     /* ... teams of 4 and 5 (168 VGPRs) */
+#define CS_LV_WAVES_MID 2     /* teams of 4 and 5 */
 #endif
 #ifndef CS_LV_WAVES_LARGE
 #define CS_LV_WAVES_LARGE 2   /* ... teams of 6 to 8 */
@@ -95,8 +102,10 @@ __device__ __forceinline__ void kinematics_v(const DevParams &p, const double *T
                 ya = q == j ? e.ay[q] : ya;
             }
             const double den = (x0 - xa) * (x0 - xa) + (y0 - ya) * (y0 - ya);
-            fx += p.force_k * (x0 - xa) / den;
-            fy += p.force_k * (y0 - ya) / den;
+            double qx, qy;
+            div2_same_denominator(p.force_k * (x0 - xa), p.force_k * (y0 - ya), den, qx, qy);   // one reciprocal for both quotients
+            fx += qx;
+            fy += qy;
         }
         const double x = (x0 + p.velocity * c1) + fx;
         const double y = (y0 + p.velocity * s1) + fy;
@@ -393,9 +402,9 @@ __global__ __launch_bounds__(BLOCK, lv_waves(N)) void k_rollout_lanev(DevParams 
         const bool stepping = live && !(done && freeze);
         LANE_STAMP(1);
         e.flags &= ~(FLAG_DIRTY | FLAG_RESET_PASS);
-        if (stepping) kinematics_v<N>(p, T, act, e);
-        // ---- in-loop refresh, first half: the row of the env running lowest on twisted words is requested now and twisted
-        //      after the draws of this step (each env comes round about every 64 steps)
+        // ---- in-loop refresh, first half: the row of the env running lowest on twisted words is requested now -- BEFORE the
+        //      kinematics: requested after them it had not arrived by the end of the draws (refresh 6200 cycles per step, the
+        //      wait included) -- and twisted after the draws of this step (each env comes round about every 64 steps)
         RowRegs rr;
         int cand;
         {
@@ -404,6 +413,7 @@ __global__ __launch_bounds__(BLOCK, lv_waves(N)) void k_rollout_lanev(DevParams 
             cand = urgent ? __ffsll((long long)urgent) - 1 : (normal ? __ffsll((long long)normal) - 1 : -1);
             if (cand >= 0) row_load(p.mt + (size_t)(b0 + cand) * MT_STRIDE, lane, rr);
         }
+        if (stepping) kinematics_v<N>(p, T, act, e);
         LANE_STAMP(2);
         // ---- the agents' floats (get_obs / get_state)
         float fx[N], fy[N];

@@ -197,7 +197,7 @@ int64_t policy_packed_floats() { return (int64_t)cs_policy_packed_floats(); }
 void policy_forward(const Tensor &packed, const Tensor &obs, int64_t obs_stride, int64_t obs_offset,
                     const c10::optional<Tensor> &last, const c10::optional<Tensor> &feat, int64_t rows_per_feat, Tensor hidden,
                     c10::optional<Tensor> q, Tensor actions, int64_t rows, int64_t n_agents, int64_t n_actions, double epsilon,
-                    int64_t seed, int64_t step, int64_t row0, int64_t select) {
+                    const c10::optional<Tensor> &eps_env, int64_t seed, int64_t step, int64_t row0, int64_t select) {
     check_f32(packed, "packed", (int64_t)cs_policy_packed_floats(), packed);
     check_f32(obs, "obs", -1, packed);
     TORCH_CHECK(rows >= 1 && obs_stride >= 4 && obs_offset >= 0 && obs.numel() >= (rows - 1) * obs_stride + obs_offset + 4,
@@ -210,11 +210,15 @@ void policy_forward(const Tensor &packed, const Tensor &obs, int64_t obs_stride,
     }
     if (last.has_value() && last->defined()) check_dev(*last, "last", at::kLong, rows, packed);
     check_dev(actions, "actions", at::kLong, rows, packed);
+    if (eps_env.has_value() && eps_env->defined()) {
+        TORCH_CHECK(n_agents >= 1 && rows % n_agents == 0, "coopsearch: eps_env needs rows = envs * n_agents");
+        check_dev(*eps_env, "eps_env", at::kDouble, rows / n_agents, packed);
+    }
     const int rc = cs_policy_forward(packed.data_ptr<float>(), obs.data_ptr<float>(), (int)obs_stride, (int)obs_offset,
                                      opt_ptr<const int64_t>(last), opt_ptr<const float>(feat), (int)rows_per_feat,
                                      hidden.data_ptr<float>(), opt_ptr<float>(q), actions.data_ptr<int64_t>(), (int)rows,
-                                     (int)n_agents, (int)n_actions, (float)epsilon, (uint64_t)seed, (uint32_t)step, (uint64_t)row0,
-                                     (int)select, stream_of(packed));
+                                     (int)n_agents, (int)n_actions, (float)epsilon, opt_ptr<const double>(eps_env), (uint64_t)seed,
+                                     (uint32_t)step, (uint64_t)row0, (int)select, stream_of(packed));
     TORCH_CHECK(rc == CS_OK, cs_policy_last_error());
 }
 
@@ -236,10 +240,40 @@ void policy_conv_features(const Tensor &c1w, const Tensor &c1b, const Tensor &c2
     TORCH_CHECK(rc == CS_OK, cs_policy_last_error());
 }
 
+// the exploration schedule of common/rollout.py:35-41,75-76,133-135 as a cs_epsilon: `eps_env` (float64 [B], in / out) carries
+// every env's own epsilon across calls; `eps_trace` (float64 [T, B], out) records what each step's selection used
+static cs_epsilon schedule_of(double epsilon, c10::optional<Tensor> &eps_env, double anneal, double min_epsilon, bool per_step,
+                              c10::optional<Tensor> &eps_trace, int64_t T, int64_t B, const Tensor &like) {
+    cs_epsilon e{epsilon, anneal, min_epsilon, per_step ? 1 : 0, 0, nullptr, nullptr};
+    if (eps_env.has_value() && eps_env->defined()) {
+        check_dev(*eps_env, "eps_env", at::kDouble, B, like);
+        e.eps_dev = eps_env->data_ptr<double>();
+    }
+    if (eps_trace.has_value() && eps_trace->defined()) {
+        TORCH_CHECK(e.eps_dev != nullptr, "coopsearch: eps_trace needs eps_env");
+        check_dev(*eps_trace, "eps_trace", at::kDouble, T * B, like);
+        e.trace_dev = eps_trace->data_ptr<double>();
+    }
+    return e;
+}
+
+// cs_epsilon_step: one step of the schedule for callers that drive policy_forward / env_step themselves
+void epsilon_step(const Tensor &cfg, const Tensor &state, int64_t flags, Tensor eps_env, double anneal, double min_epsilon,
+                  c10::optional<Tensor> trace_row) {
+    const cs_config &c = config_of(cfg);
+    check_state(c, state);
+    const Shapes s = shapes_of(c);
+    check_dev(eps_env, "eps_env", at::kDouble, s.B, state);
+    if (trace_row.has_value() && trace_row->defined()) check_dev(*trace_row, "trace_row", at::kDouble, s.B, state);
+    ok(cs_epsilon_step(&c, state.data_ptr(), (int)flags, eps_env.data_ptr<double>(), anneal, min_epsilon, opt_ptr<double>(trace_row),
+                       stream_of(state)));
+}
+
 // T x (cs_policy_forward -> cs_step) in one launch (cs_rollout_policy; flight_easy, n_agents <= 5)
 void rollout_policy(const Tensor &cfg, Tensor state, const Tensor &packed, Tensor hidden, const Tensor &last, int64_t T, int64_t flags,
-                    double epsilon, int64_t seed, int64_t step0, int64_t row0, int64_t select, Tensor actions, Tensor reward,
-                    Tensor terminated, Tensor win, c10::optional<Tensor> obs, c10::optional<Tensor> state_out) {
+                    double epsilon, c10::optional<Tensor> eps_env, double anneal, double min_epsilon, bool per_step,
+                    c10::optional<Tensor> eps_trace, int64_t seed, int64_t step0, int64_t row0, int64_t select, Tensor actions,
+                    Tensor reward, Tensor terminated, Tensor win, c10::optional<Tensor> obs, c10::optional<Tensor> state_out) {
     const cs_config &c = config_of(cfg);
     check_state(c, state);
     const Shapes s = shapes_of(c);
@@ -252,8 +286,9 @@ void rollout_policy(const Tensor &cfg, Tensor state, const Tensor &packed, Tenso
     check_dev(terminated, "terminated", at::kByte, T * s.B, state);
     check_dev(win, "win", at::kByte, T * s.B, state);
     check_outputs(c, state, T, obs, state_out);
+    const cs_epsilon sched = schedule_of(epsilon, eps_env, anneal, min_epsilon, per_step, eps_trace, T, s.B, state);
     ok(cs_rollout_policy(&c, state.data_ptr(), packed.data_ptr<float>(), hidden.data_ptr<float>(), last.data_ptr<int64_t>(), (int)T,
-                         (int)flags, (float)epsilon, (uint64_t)seed, (uint32_t)step0, (uint64_t)row0, (int)select,
+                         (int)flags, &sched, (uint64_t)seed, (uint32_t)step0, (uint64_t)row0, (int)select,
                          actions.data_ptr<int64_t>(), reward.data_ptr<float>(), terminated.data_ptr<uint8_t>(),
                          win.data_ptr<uint8_t>(), opt_ptr<float>(obs), opt_ptr<float>(state_out), stream_of(state)));
 }
@@ -261,9 +296,10 @@ void rollout_policy(const Tensor &cfg, Tensor state, const Tensor &packed, Tenso
 // flight: T x (conv features of the env's map -> policy forward -> env step) enqueued by one call (cs_rollout_policy_flight)
 void rollout_policy_flight(const Tensor &cfg, Tensor state, const Tensor &packed, const Tensor &c1w, const Tensor &c1b,
                            const Tensor &c2w, const Tensor &c2b, const Tensor &lw, const Tensor &lb, Tensor hidden, const Tensor &last,
-                           Tensor scratch, int64_t T, int64_t flags, double epsilon, int64_t seed, int64_t step0, int64_t row0,
-                           int64_t select, Tensor actions, Tensor reward, Tensor terminated, Tensor win, c10::optional<Tensor> obs,
-                           c10::optional<Tensor> state_out) {
+                           Tensor scratch, int64_t T, int64_t flags, double epsilon, c10::optional<Tensor> eps_env, double anneal,
+                           double min_epsilon, bool per_step, c10::optional<Tensor> eps_trace, int64_t seed, int64_t step0,
+                           int64_t row0, int64_t select, Tensor actions, Tensor reward, Tensor terminated, Tensor win,
+                           c10::optional<Tensor> obs, c10::optional<Tensor> state_out) {
     const cs_config &c = config_of(cfg);
     check_state(c, state);
     const Shapes s = shapes_of(c);
@@ -283,10 +319,11 @@ void rollout_policy_flight(const Tensor &cfg, Tensor state, const Tensor &packed
     check_dev(terminated, "terminated", at::kByte, T * s.B, state);
     check_dev(win, "win", at::kByte, T * s.B, state);
     check_outputs(c, state, T, obs, state_out);
+    const cs_epsilon sched = schedule_of(epsilon, eps_env, anneal, min_epsilon, per_step, eps_trace, T, s.B, state);
     ok(cs_rollout_policy_flight(&c, state.data_ptr(), packed.data_ptr<float>(), c1w.data_ptr<float>(), c1b.data_ptr<float>(),
                                 c2w.data_ptr<float>(), c2b.data_ptr<float>(), lw.data_ptr<float>(), lb.data_ptr<float>(),
                                 hidden.data_ptr<float>(), last.data_ptr<int64_t>(), scratch.data_ptr<float>(), (int)T, (int)flags,
-                                (float)epsilon, (uint64_t)seed, (uint32_t)step0, (uint64_t)row0, (int)select,
+                                &sched, (uint64_t)seed, (uint32_t)step0, (uint64_t)row0, (int)select,
                                 actions.data_ptr<int64_t>(), reward.data_ptr<float>(), terminated.data_ptr<uint8_t>(),
                                 win.data_ptr<uint8_t>(), opt_ptr<float>(obs), opt_ptr<float>(state_out), stream_of(state)));
 }
@@ -344,15 +381,19 @@ TORCH_LIBRARY(coopsearch, m) {
     m.def("mt_canonical(Tensor cfg, Tensor state, Tensor(a!) rows_out) -> ()", &mt_canonical);
     m.def("policy_packed_floats() -> int", &policy_packed_floats);
     m.def("policy_forward(Tensor packed, Tensor obs, int obs_stride, int obs_offset, Tensor? last, Tensor? feat, int rows_per_feat, "
-          "Tensor(a!) hidden, Tensor(b!)? q, Tensor(c!) actions, int rows, int n_agents, int n_actions, float epsilon, int seed, "
-          "int step, int row0, int select) -> ()", &policy_forward);
+          "Tensor(a!) hidden, Tensor(b!)? q, Tensor(c!) actions, int rows, int n_agents, int n_actions, float epsilon, Tensor? eps_env, "
+          "int seed, int step, int row0, int select) -> ()", &policy_forward);
+    m.def("epsilon_step(Tensor cfg, Tensor state, int flags, Tensor(a!) eps_env, float anneal, float min_epsilon, "
+          "Tensor(b!)? trace_row) -> ()", &epsilon_step);
     m.def("policy_conv_features(Tensor conv1_w, Tensor conv1_b, Tensor conv2_w, Tensor conv2_b, Tensor lin_w, Tensor lin_b, "
           "Tensor maps, int map_stride, int n_maps, Tensor(a!) feat) -> ()", &policy_conv_features);
     m.def("rollout_policy(Tensor cfg, Tensor(a!) state, Tensor packed, Tensor(b!) hidden, Tensor last, int T, int flags, "
-          "float epsilon, int seed, int step0, int row0, int select, Tensor(c!) actions, Tensor(d!) reward, Tensor(e!) terminated, "
+          "float epsilon, Tensor(j!)? eps_env, float anneal, float min_epsilon, bool per_step, Tensor(k!)? eps_trace, int seed, "
+          "int step0, int row0, int select, Tensor(c!) actions, Tensor(d!) reward, Tensor(e!) terminated, "
           "Tensor(f!) win, Tensor(g!)? obs, Tensor(h!)? state_out) -> ()", &rollout_policy);
     m.def("rollout_policy_flight(Tensor cfg, Tensor(a!) state, Tensor packed, Tensor c1w, Tensor c1b, Tensor c2w, Tensor c2b, "
-          "Tensor lw, Tensor lb, Tensor(b!) hidden, Tensor last, Tensor(i!) scratch, int T, int flags, float epsilon, int seed, "
+          "Tensor lw, Tensor lb, Tensor(b!) hidden, Tensor last, Tensor(i!) scratch, int T, int flags, float epsilon, "
+          "Tensor(j!)? eps_env, float anneal, float min_epsilon, bool per_step, Tensor(k!)? eps_trace, int seed, "
           "int step0, int row0, int select, Tensor(c!) actions, Tensor(d!) reward, Tensor(e!) terminated, Tensor(f!) win, "
           "Tensor(g!)? obs, Tensor(h!)? state_out) -> ()", &rollout_policy_flight);
     m.def("store_episodes(Tensor o_tab, Tensor s_tab, Tensor u_tab, Tensor r_tab, Tensor term_tab, Tensor? slots, int n_actions, "

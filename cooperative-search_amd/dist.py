@@ -28,6 +28,10 @@ def seeds_for(offset, count, base_seed=DEFAULT_BASE_SEED):
     return ((int(base_seed) + int(offset) + np.arange(count, dtype=np.int64)) % (1 << 32)).astype(np.uint32)
 
 
+def rank():
+    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
+
 def all_gather_sum(partial):
     """Sum of `partial` (any-shape tensor of partial sums) over all ranks via ONE all-gather; identity when
     torch.distributed is not initialised.  Works on CPU tensors (gloo) and GPU tensors (nccl = RCCL).  A process group

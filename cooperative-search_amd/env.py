@@ -346,14 +346,30 @@ class BatchedFlightEnv:
         out["win"] = win.view(torch.bool)
         return out
 
-    def rollout_policy(self, agents, T, epsilon=0.0, evaluate=True, emit=True, out=None, update_views=True):
+    def epsilon_step(self, eps_env, anneal, min_epsilon, trace_row=None):
+        """One step of the exploration schedule for a loop that calls choose_action / step itself (cs_epsilon_step): the envs
+        the NEXT step() will execute anneal -- eps = eps - anneal if eps > min_epsilon else eps, common/rollout.py:75-76 --;
+        trace_row (float64 [B]) receives the values before the anneal.  Call between choose_action and step."""
+        flags = (_lib.FREEZE_DONE if self.freeze_done else 0) | (_lib.AUTO_RESET if self.auto_reset else 0)
+        if self._ops is not None:
+            self._ops.epsilon_step(self._cfg_t, self._blob, flags, eps_env, float(anneal), float(min_epsilon), trace_row)
+            return
+        self._call(self._L.cs_epsilon_step, self._cfgp, self._blob.data_ptr(), flags, eps_env.data_ptr(), float(anneal),
+                   float(min_epsilon), trace_row.data_ptr() if trace_row is not None else None, self._stream())
+
+    def rollout_policy(self, agents, T, epsilon=0.0, evaluate=True, emit=True, out=None, update_views=True, eps_env=None,
+                       anneal=0.0, min_epsilon=0.0, per_step=False, eps_trace=None):
         """T closed-loop steps in ONE call: each step runs `agents`' network (a `FusedAgents`) on the current observation,
         picks the actions and steps the envs -- exactly what T x
         `env.step(agents.choose_action(env.get_obs(), epsilon, evaluate))` computes.  flight_easy (n <= 5): one launch,
         with the hidden state, the actions and the envs resident on chip in between.  flight: three kernels per step
         enqueued by one call (cs_rollout_policy_flight): the conv front end reads every env's map where it lives, and
         with emit=False the n observation copies of the map are never written.  Returns the `rollout` dict plus `actions`
-        (int64 [T, B, n]); `agents.hidden` / `agents.actions` / `agents.calls` advance as if the T calls had been made."""
+        (int64 [T, B, n]); `agents.hidden` / `agents.actions` / `agents.calls` advance as if the T calls had been made.
+        Exploration schedule (common/rollout.py:35-41, 75-76, 133-135; include/coopsearch.h cs_epsilon): eps_env (float64 [B],
+        in / out) gives every env its own epsilon, annealed ON THE DEVICE after every step the env executes when per_step
+        (`epsilon_anneal_scale == 'step'`: eps = eps - anneal if eps > min_epsilon else eps) and carried back in the same
+        tensor; eps_trace (float64 [T, B]) records what every step's selection used.  Ignored when evaluating."""
         T = int(T)
         B, n = self.batch, self.n_agents
         if agents.rows != B * n or bool(getattr(agents, "conv", False)) != self.flight:
@@ -373,32 +389,44 @@ class BatchedFlightEnv:
         has_obs = out.get("obs") is not None and out.get("state") is not None
         flags = (_lib.FREEZE_DONE if self.freeze_done else 0) | (_lib.AUTO_RESET if self.auto_reset else 0)
         sel_eps, sel_flags = agents.selection(epsilon, evaluate)
+        if evaluate and not agents.softmax:
+            eps_env = eps_trace = None   # epsilon = 0 if evaluate (rollout.py:35): no schedule
+        if eps_trace is not None and eps_env is None:
+            raise ValueError("rollout_policy: eps_trace needs eps_env")
+        for name, tns, numel in (("eps_env", eps_env, B), ("eps_trace", eps_trace, T * B)):
+            if tns is not None and (tns.dtype != torch.float64 or tns.numel() != numel or not tns.is_contiguous() or tns.device != dev):
+                raise ValueError(f"rollout_policy: {name} must be a contiguous float64 device tensor of {numel} elements")
+        sched_t = (sel_eps, eps_env, float(anneal), float(min_epsilon), bool(per_step), eps_trace)
+        if self._ops is None:
+            sched_c = _lib.CsEpsilon(sel_eps, float(anneal), float(min_epsilon), 1 if per_step else 0, 0,
+                                     eps_env.data_ptr() if eps_env is not None else None,
+                                     eps_trace.data_ptr() if eps_trace is not None else None)
         if self.flight:
             scratch = getattr(agents, "_flight_scratch", None)
             if scratch is None or scratch.numel() != B * (16 + 4 * n):
                 scratch = agents._flight_scratch = torch.empty(B, 16 + 4 * n, dtype=torch.float32, device=dev)
             if self._ops is not None:
                 self._ops.rollout_policy_flight(self._cfg_t, self._blob, agents.packed, *agents.conv_w, agents.hidden,
-                                                agents.actions, scratch, T, flags, sel_eps, agents.seed, agents.calls,
+                                                agents.actions, scratch, T, flags, *sched_t, agents.seed, agents.calls,
                                                 agents.row0, sel_flags, out["actions"], out["reward"],
                                                 out["terminated"].view(torch.uint8), out["win"].view(torch.uint8),
                                                 out["obs"] if has_obs else None, out["state"] if has_obs else None)
             else:
                 self._call(self._L.cs_rollout_policy_flight,
                     self._cfgp, self._blob.data_ptr(), agents.packed.data_ptr(), *[w.data_ptr() for w in agents.conv_w],
-                    agents.hidden.data_ptr(), agents.actions.data_ptr(), scratch.data_ptr(), T, flags, sel_eps, agents.seed,
+                    agents.hidden.data_ptr(), agents.actions.data_ptr(), scratch.data_ptr(), T, flags, C.byref(sched_c), agents.seed,
                     agents.calls, agents.row0, sel_flags, out["actions"].data_ptr(), out["reward"].data_ptr(),
                     out["terminated"].data_ptr(), out["win"].data_ptr(), out["obs"].data_ptr() if has_obs else None,
                     out["state"].data_ptr() if has_obs else None, self._stream())
         elif self._ops is not None:
-            self._ops.rollout_policy(self._cfg_t, self._blob, agents.packed, agents.hidden, agents.actions, T, flags, sel_eps,
+            self._ops.rollout_policy(self._cfg_t, self._blob, agents.packed, agents.hidden, agents.actions, T, flags, *sched_t,
                                      agents.seed, agents.calls, agents.row0, sel_flags, out["actions"], out["reward"],
                                      out["terminated"].view(torch.uint8), out["win"].view(torch.uint8),
                                      out["obs"] if has_obs else None, out["state"] if has_obs else None)
         else:
             self._call(self._L.cs_rollout_policy,
                 self._cfgp, self._blob.data_ptr(), agents.packed.data_ptr(), agents.hidden.data_ptr(),
-                agents.actions.data_ptr(), T, flags, sel_eps, agents.seed, agents.calls, agents.row0, sel_flags,
+                agents.actions.data_ptr(), T, flags, C.byref(sched_c), agents.seed, agents.calls, agents.row0, sel_flags,
                 out["actions"].data_ptr(), out["reward"].data_ptr(), out["terminated"].data_ptr(), out["win"].data_ptr(),
                 out["obs"].data_ptr() if has_obs else None, out["state"].data_ptr() if has_obs else None, self._stream())
         agents.calls += T

@@ -76,14 +76,22 @@ int main() {
     CS_OK_(cs_init(&cfg, state, stream));
     CS_OK_(cs_seed(&cfg, state, seeds, stream));
     double secs = 0;
-    for (int round = 0; round < 3; round++) {   // three batches of 4096 episodes, epsilon-greedy with eps = 0.1
+    // the reference's exploration schedule (common/arguments.py:78-82: epsilon 1 -> 0.05 over 10000 steps, scale 'step'), one
+    // epsilon per env, annealed on the device after every executed step and carried from batch to batch in eps_env
+    double *eps_env = dev_alloc<double>(B);
+    {
+        std::vector<double> one(B, 1.0);
+        HIP_OK(hipMemcpy(eps_env, one.data(), B * sizeof(double), hipMemcpyHostToDevice));
+    }
+    const cs_epsilon sched = {1.0, (1.0 - 0.05) / 10000, 0.05, /*per_step=*/1, 0, eps_env, nullptr};
+    for (int round = 0; round < 3; round++) {   // three batches of 4096 episodes, epsilon-greedy on the annealing schedule
         HIP_OK(hipMemsetAsync(hidden, 0, (size_t)B * n * 64 * sizeof(float), stream));      // init_hidden
         HIP_OK(hipMemsetAsync(last, 0xff, (size_t)B * n * sizeof(int64_t), stream));        // -1: no last action
         HIP_OK(hipMemsetAsync(metrics, 0, 4 * sizeof(double), stream));
         HIP_OK(hipStreamSynchronize(stream));
         const auto t0 = std::chrono::steady_clock::now();
         CS_OK_(cs_reset(&cfg, state, nullptr, 0, o_tab, s_tab, stream));                    // o[0], s[0]
-        CS_OK_(cs_rollout_policy(&cfg, state, packed_dev, hidden, last, T, CS_FREEZE_DONE, 0.1f, 99, (uint32_t)(round * T), /*row0=*/0, /*select=*/0,
+        CS_OK_(cs_rollout_policy(&cfg, state, packed_dev, hidden, last, T, CS_FREEZE_DONE, &sched, 99, (uint32_t)(round * T), /*row0=*/0, /*select=*/0,
                                  u_tab, r_tab, term_tab, win_tab, o_tab + (size_t)B * n * 4, s_tab + (size_t)B * W, stream));
         CS_OK_(cs_store_episodes(B, T, n, A, 4, W, o_tab, s_tab, u_tab, r_tab, term_tab, nullptr, &ep, stream));
         CS_OK_(cs_metrics(&cfg, state, metrics, stream));
@@ -98,6 +106,9 @@ int main() {
     double real = 0, hot = 0;
     for (float v : padded) real += 1.0 - v;
     for (float v : onehot) hot += v;
+    double h_eps[2];
+    HIP_OK(hipMemcpy(h_eps, eps_env, sizeof(h_eps), hipMemcpyDeviceToHost));
+    printf("epsilon of env 0 / env 1 after three episodes: %.6f / %.6f (1 - executed steps x 9.5e-5)\n", h_eps[0], h_eps[1]);
     printf("episodes %.0f  mean episode_reward %.2f  win rate %.4f  mean targets_find %.2f of %d\n", h_m[3], h_m[0] / h_m[3],
            h_m[1] / h_m[3], h_m[2] / h_m[3], m);
     printf("real steps %.0f  one-hot sum %.0f (= real steps x agents: %s)  batch time %.2f ms  %.3g env-step slots/s\n", real, hot,

@@ -32,8 +32,9 @@
 extern "C" {
 #endif
 
-#define CS_ABI_VERSION 5   /* 2: cs_layout.ahead_off (pre-twisted MT words), cs_mt_canonical; 3: cs_layout.job_off;
-                              4: cs_source_hash, CS_KERNEL_OCT; 5: CS_KERNEL_ODE */
+#define CS_ABI_VERSION 6   /* 2: cs_layout.ahead_off (pre-twisted MT words), cs_mt_canonical; 3: cs_layout.job_off;
+                              4: cs_source_hash, CS_KERNEL_OCT; 5: CS_KERNEL_ODE; 6: cs_epsilon (exploration schedule),
+                              cs_epsilon_step, CS_KERNEL_LANEV */
 #define CS_MAX_AGENTS 8
 #define CS_MAX_TARGETS 16
 #define CS_MAX_MAP 64
@@ -76,6 +77,25 @@ enum {
                             registers, half-wavefront staging of the get_state rows: three to four wavefronts per SIMD instead of
                             two; CS_KERNEL_LANE forces the first generation); same results */
 };
+
+/* Exploration schedule of RolloutWorker.generate_episode -- common/rollout.py:35-41 (episode / epoch scale: one anneal before
+ * the episode: the caller's), :75-76 (STEP scale, the QMIX and DOP default, common/arguments.py:78-82, 137-141: after every
+ * executed env step `epsilon = epsilon - anneal_epsilon if epsilon > min_epsilon else epsilon`), :133-135 (the value persists
+ * across episodes).  The reference has ONE worker and one scalar; a batch of B envs is B independent workers, each with its own
+ * epsilon annealed by its own executed steps (a frozen, finished env does not anneal -- its episode loop has ended).
+ *   eps_dev == NULL: every env uses `epsilon` for the whole call (no schedule).
+ *   eps_dev != NULL: double [B], env b's epsilon: read when the call starts, annealed on the device after every step env b
+ *                    executes (if per_step), written back when the call ends.
+ * All arithmetic is the reference's: IEEE doubles, one subtraction per executed step. */
+typedef struct cs_epsilon {
+    double epsilon;       /* value of every env when eps_dev is NULL */
+    double anneal;        /* args.anneal_epsilon */
+    double min_epsilon;   /* args.min_epsilon */
+    int32_t per_step;     /* != 0: args.epsilon_anneal_scale == 'step' */
+    int32_t reserved;
+    double *eps_dev;      /* NULL or double [B], in / out */
+    double *trace_dev;    /* NULL or double [T][B], out: the epsilon env b's action selection of step t used */
+} cs_epsilon;
 
 /* Environment constants: common/arguments.py:27-34 (map_size, target_num, target_mode, agent_mode, n_agents,
  * view_range) and :233-284 (get_flight_args / get_flight_easy_args), plus the parsed target file
@@ -237,8 +257,17 @@ int cs_policy_pack(const float *fc1_w, const float *fc1_b, const float *w_ih, co
  * identity; a caller with a real mask applies it to q_dev and selects on its side. */
 int cs_policy_forward(const float *packed_dev, const float *obs_dev, int obs_stride, int obs_offset,
                       const int64_t *last_dev, const float *feat_dev, int rows_per_feat, float *hidden_dev, float *q_dev,
-                      int64_t *actions_dev, int rows, int n_agents, int n_actions, float epsilon, uint64_t seed,
-                      uint32_t step, uint64_t row0, int select, void *stream);
+                      int64_t *actions_dev, int rows, int n_agents, int n_actions, float epsilon, const double *eps_env_dev,
+                      uint64_t seed, uint32_t step, uint64_t row0, int select, void *stream);
+/* (eps_env_dev: NULL, or double [rows / n_agents]: row r explores with epsilon eps_env_dev[r / n_agents] instead of `epsilon` --
+ * the per-env schedule of cs_epsilon for callers that drive the loop step by step; cs_epsilon_step anneals it.) */
+
+/* One step of the exploration schedule for a caller that drives the loop itself (cs_policy_forward -> cs_epsilon_step ->
+ * cs_step): for every env that the NEXT cs_step(flags) will execute (not: terminated on entry and frozen),
+ * eps_dev[b] = eps_dev[b] - anneal if eps_dev[b] > min_epsilon else eps_dev[b] (common/rollout.py:75-76); trace_row_dev (NULL or
+ * double [B]) receives the values BEFORE the anneal, i.e. what the action selection of this step used. */
+int cs_epsilon_step(const cs_config *cfg, void *state_dev, int flags, double *eps_dev, double anneal, double min_epsilon,
+                    double *trace_row_dev, void *stream);
 
 /* flight: the conv front end of base_net.py:9-18,31-36 with the reference's hyper-parameters (common/arguments.py:256-265:
  * Conv2d(1,4,k=4,s=2) -> ReLU -> Conv2d(4,1,k=3,s=1,p=1) -> ReLU -> Linear(576,16)) on n_maps 50x50 probability maps;
@@ -256,11 +285,14 @@ const char *cs_policy_last_error(void);
  * cs_policy_forward(..., step = step0 + s) and cs_step(flags) calls.
  *   packed_dev   cs_policy_pack output            hidden_dev  float [B*n][64], in/out
  *   last_dev     int64 [B][n] action before the first step (< 0 = none)
- *   actions_dev  int64 [T][B][n] chosen actions (out); the other outputs as in cs_rollout. */
+ *   actions_dev  int64 [T][B][n] chosen actions (out); the other outputs as in cs_rollout.
+ * Same results, bit for bit, as T triples cs_policy_forward(step0 + s, eps_env_dev) -> cs_epsilon_step -> cs_step. */
 int cs_rollout_policy(const cs_config *cfg, void *state_dev, const float *packed_dev, float *hidden_dev,
-                      const int64_t *last_dev, int T, int flags, float epsilon, uint64_t seed, uint32_t step0,
+                      const int64_t *last_dev, int T, int flags, const cs_epsilon *eps, uint64_t seed, uint32_t step0,
                       uint64_t row0, int select, int64_t *actions_dev, float *reward_dev, uint8_t *terminated_dev,
                       uint8_t *win_dev, float *obs_dev, float *state_out_dev, void *stream);
+/* (eps: the exploration schedule, see cs_epsilon; with eps->eps_dev the per-step anneal of rollout.py:75-76 runs INSIDE the
+ * launch, env by env, and the carried values come back in eps_dev.) */
 
 /* Closed loop for flight (the loop body of common/rollout.py:43-76 with the conv network of network/base_net.py:9-36):
  * T x (cs_policy_conv_features -> cs_policy_forward -> cs_step) enqueued by ONE call.  Bit for bit the results of the T
@@ -275,7 +307,7 @@ int cs_rollout_policy(const cs_config *cfg, void *state_dev, const float *packed
 int cs_rollout_policy_flight(const cs_config *cfg, void *state_dev, const float *packed_dev, const float *conv1_w_dev,
                              const float *conv1_b_dev, const float *conv2_w_dev, const float *conv2_b_dev,
                              const float *lin_w_dev, const float *lin_b_dev, float *hidden_dev, const int64_t *last_dev,
-                             float *scratch_dev, int T, int flags, float epsilon, uint64_t seed, uint32_t step0, uint64_t row0,
+                             float *scratch_dev, int T, int flags, const cs_epsilon *eps, uint64_t seed, uint32_t step0, uint64_t row0,
                              int select, int64_t *actions_dev, float *reward_dev, uint8_t *terminated_dev, uint8_t *win_dev,
                              float *obs_dev, float *state_out_dev, void *stream);
 

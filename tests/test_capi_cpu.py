@@ -33,7 +33,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert set(syms) == set(_lib.EXPORTS), (syms, _lib.EXPORTS)
     for s in syms:
         assert hasattr(L, s), s
-    assert L.cs_abi_version() == _lib.ABI_VERSION == 5
+    assert L.cs_abi_version() == _lib.ABI_VERSION == 6
 
 
 def test_staleness_is_decided_by_source_content_not_mtime(tmp_path, monkeypatch):
@@ -214,7 +214,7 @@ def test_torch_op_library_builds_loads_and_registers_every_op():
     ops = _lib.torch_ops()
     for name in ("abi_version", "state_bytes", "env_init", "env_seed", "env_reset", "env_step", "env_rollout", "env_emit",
                  "env_metrics", "mt_advance", "mt_canonical", "policy_packed_floats", "policy_forward", "policy_conv_features",
-                 "rollout_policy", "rollout_policy_flight", "store_episodes"):
+                 "rollout_policy", "rollout_policy_flight", "store_episodes", "epsilon_step"):
         assert hasattr(ops, name), name
     assert int(ops.abi_version()) == _lib.ABI_VERSION
     import torch
@@ -227,3 +227,20 @@ def test_torch_op_library_builds_loads_and_registers_every_op():
         ops.state_bytes(t[:-4].clone())
     with pytest.raises(RuntimeError, match="GPU"):   # no device here: a CPU state tensor must be refused, not dereferenced
         ops.env_init(t, torch.zeros(lay.total_bytes, dtype=torch.uint8))
+
+
+def test_committed_kernel_resources_describe_the_shipped_binary():
+    """profiles/r03_kernel_resources.txt had gone stale (a last commit changed a kernel after the measurement
+    set).  profiles/kernel_resources.txt is the CURRENT table -- VGPRs, spills, scratch, LDS of every kernel, read from the
+    code objects of the in-tree library -- and this test fails whenever the library was rebuilt from sources that change it:
+    regenerate with `python tools/kernel_resources.py > profiles/kernel_resources.txt`."""
+    import subprocess
+    import sys
+    _lib.load()   # (builds the library if the sources changed)
+    want = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py")], capture_output=True, text=True,
+                          check=True).stdout
+    path = os.path.join(ROOT, "profiles", "kernel_resources.txt")
+    assert os.path.exists(path), "python tools/kernel_resources.py > profiles/kernel_resources.txt"
+    have = open(path).read()
+    assert sorted(have.split("\n")) == sorted(want.split("\n")), \
+        "profiles/kernel_resources.txt is not of this binary: python tools/kernel_resources.py > profiles/kernel_resources.txt"

@@ -529,3 +529,120 @@ def test_trained_checkpoint_closed_loop_flight(tag):
         np.testing.assert_allclose(curve[IDX], z["shipped_curve"][IDX], rtol=0, atol=5.0 if tag == "flight3_qmix" else 7.0,
                                    err_msg=msg)
     np.testing.assert_allclose(curve[IDX], z["ref_curve"][IDX], rtol=0, atol=7.0 if tag == "flight3_qmix" else 9.0, err_msg=msg)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Exploration schedule: the epsilon the reference's OWN RolloutWorker hands to Agents.choose_action at every step
+# (tests/golden/epsilon_schedule.json, recorded by gen_epsilon.py with alg = 'qmix' and the shipped argument setters) against
+# the epsilon the HIP closed loop uses, env by env, step by step, as exact doubles.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _schedule_fixture(case):
+    import json
+    d = json.load(open(os.path.join(GOLD, "epsilon_schedule.json")))[case]
+    d["used_f"] = np.array([float(x) for x in d["used"]], dtype=np.float64)
+    return d
+
+
+def _schedule_args(n, d, flight=False):
+    a = _flight_args(n) if flight else _args(n)
+    a.epsilon, a.anneal_epsilon, a.min_epsilon = d["epsilon0"], float(d["anneal_epsilon"]), float(d["min_epsilon"])
+    a.epsilon_anneal_scale = d["scale"]
+    return a
+
+
+@pytest.mark.parametrize("case,one_launch,binding", [("default", True, None), ("default", False, None), ("fast", True, None),
+                                                     ("fast", False, None), ("fast", True, "ctypes")])
+def test_epsilon_step_schedule_equals_the_reference_worker(case, one_launch, binding):
+    """epsilon_anneal_scale == 'step' (the QMIX / DOP default): after every EXECUTED env step epsilon = epsilon - anneal if
+    epsilon > min_epsilon else epsilon (common/rollout.py:75-76), carried across episodes (:133-135).  The j-th step a worker
+    executes uses the j-th iterate of that rule, whatever the episode lengths: every env of the batch is its own worker, so
+    env b's step t of episode k must use used[steps b executed before + t] of the reference's recording -- bit for bit --
+    in the fused launch (the anneal runs inside k_rollout_policy) and in the per-step loop (cs_epsilon_step)."""
+    d = _schedule_fixture(case)
+    n, B, T = 3, 96, 200
+    a = _schedule_args(n, d)
+    torch.manual_seed(7)
+    env = cs.BatchedFlightEnv(a, batch=B, binding=binding)
+    cs.apply_env_info(a, env)
+    agents = FusedAgents(a, B, seed=5)
+    sched = cs.EpsilonSchedule(a, B)
+    col = cs.EpisodeCollector(env, schedule=sched)
+    done_before = np.zeros(B, dtype=np.int64)
+    used = d["used_f"]
+    for k in range(3):
+        trace = torch.full((T, B), -1.0, dtype=torch.float64, device="cuda")
+        ep, _r, _w, _f = col.generate_episodes(agents=agents, evaluate=False, one_launch=one_launch, episode_num=k, eps_trace=trace)
+        steps = (ep["padded"][:, :, 0] == 0).sum(1).cpu().numpy()   # executed steps of each env's episode
+        tr = trace.cpu().numpy()
+        for b in range(B):
+            want = used[done_before[b]:done_before[b] + steps[b]]
+            assert np.array_equal(tr[:steps[b], b], want), (case, k, b, steps[b])
+        done_before += steps
+        assert done_before.max() < len(used) - 1, "fixture too short for this run"
+        assert np.array_equal(sched.values.cpu().numpy(), used[done_before]), f"{case}: carried epsilon after episode {k}"
+    if case == "fast":   # the floor was crossed inside the run
+        assert (sched.values.cpu().numpy() <= float(d["min_epsilon"])).all()
+
+
+@pytest.mark.parametrize("case", ["episode", "epoch"])
+def test_epsilon_episode_and_epoch_scales_equal_the_reference_worker(case):
+    """'episode': one anneal before every episode (rollout.py:36-38); 'epoch': only before the episode with episode_num == 0
+    (:39-41).  The value of every step of episode k is the reference's (including its stepping below min_epsilon: the rule
+    tests `epsilon > min_epsilon` BEFORE subtracting)."""
+    d = _schedule_fixture(case)
+    n, B, T = 3, 16, 200
+    a = _schedule_args(n, d)
+    env = cs.BatchedFlightEnv(a, batch=B)
+    cs.apply_env_info(a, env)
+    agents = FusedAgents(a, B, seed=5)
+    sched = cs.EpsilonSchedule(a, B)
+    col = cs.EpisodeCollector(env, schedule=sched)
+    starts = np.concatenate([[0], np.cumsum(d["steps"])])
+    k = 0
+    for _epoch in range(d["epochs"]):
+        for num in range(d["episodes_per_epoch"]):
+            trace = torch.full((T, B), -1.0, dtype=torch.float64, device="cuda")
+            ep, *_ = col.generate_episodes(agents=agents, evaluate=False, episode_num=num, eps_trace=trace)
+            steps = (ep["padded"][:, :, 0] == 0).sum(1).cpu().numpy()
+            want = d["used_f"][starts[k]]   # constant over the reference's episode k
+            tr = trace.cpu().numpy()
+            for b in range(B):
+                assert np.array_equal(tr[:steps[b], b], np.full(steps[b], want)), (case, k, b)
+            assert np.array_equal(sched.values.cpu().numpy(), np.full(B, float(d["carried_after_episode"][k])))
+            k += 1
+
+
+def test_epsilon_schedule_in_the_flight_closed_loop():
+    """cs_rollout_policy_flight with a schedule: per step cs_policy_forward(eps_env) -> k_eps_step -> k_step, enqueued by the one
+    call; same iterates."""
+    d = _schedule_fixture("fast")
+    n, B, T = 3, 8, 200
+    a = _schedule_args(n, d, flight=True)
+    env = cs.BatchedFlightEnv(a, batch=B)
+    cs.apply_env_info(a, env)
+    agents = FusedAgents(a, B, seed=3)
+    sched = cs.EpsilonSchedule(a, B)
+    col = cs.EpisodeCollector(env, schedule=sched)
+    trace = torch.full((T, B), -1.0, dtype=torch.float64, device="cuda")
+    ep, *_ = col.generate_episodes(agents=agents, evaluate=False, eps_trace=trace, init=True)
+    steps = (ep["padded"][:, :, 0] == 0).sum(1).cpu().numpy()
+    tr = trace.cpu().numpy()
+    for b in range(B):
+        assert np.array_equal(tr[:steps[b], b], d["used_f"][:steps[b]]), b
+    assert np.array_equal(sched.values.cpu().numpy(), d["used_f"][steps])
+
+
+def test_evaluation_ignores_the_schedule():
+    """epsilon = 0 if evaluate (rollout.py:35) and self.epsilon is left alone (:133-134)."""
+    d = _schedule_fixture("default")
+    a = _schedule_args(3, d)
+    env = cs.BatchedFlightEnv(a, batch=32)
+    cs.apply_env_info(a, env)
+    agents = FusedAgents(a, 32, seed=5)
+    sched = cs.EpsilonSchedule(a, 32)
+    col = cs.EpisodeCollector(env, schedule=sched)
+    ep1, *_ = col.generate_episodes(agents=agents, evaluate=True)
+    assert (sched.values == 1.0).all()
+    env2 = cs.BatchedFlightEnv(a, batch=32)
+    ep2, *_ = cs.EpisodeCollector(env2).generate_episodes(agents=FusedAgents(a, 32, seed=5), evaluate=True)
+    assert torch.equal(ep1["u"], ep2["u"])
