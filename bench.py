@@ -535,11 +535,15 @@ def closed_loop_measurement(cs, dev, n, B, K, W, env_name="flight_easy"):
                                "the n observation copies of the map are not written)"),
            "mode": "closed-loop", "value": B * K / dt, "unit": "env-steps/s", "ms_per_step": dt * 1e3 / K,
            "policy_kernels_us": pol_us}
-    if env_name == "flight_easy":   # one kernel, GEMM-shaped: price it against the fp32 matrix peak
-        in_dim = 4 + 3 + n          # useful FLOPs only (the kernel pads fc1's input to 16 and fc2's output to 16)
+    if env_name == "flight_easy":   # one kernel, GEMM-shaped: price it against the matrix pipe it runs on
+        in_dim = 4 + 3 + n          # useful FLOPs only (the kernel pads fc1's input to 32 and fc2's output to 16)
         flops = 2.0 * B * n * (in_dim * 64 + 2 * 192 * 64 + 64 * 64 + 64 * 3)
-        out["policy_roofline"] = {"bound": "mfma", "achieved": flops / pol_us / 1e6, "peak": 157.3, "unit": "TFLOP/s",
-                                  "frac": flops / pol_us / 1e6 / 157.3, "dtype": "f32"}
+        # csrc/policy_dev.h: every fp32 product runs as THREE v_mfma_f32_16x16x32_f16 (split-fp16 operands, 22 bits), so the
+        # useful-FLOP peak of this path is a third of the dense 16-bit matrix peak (2.5 PFLOP/s, MI355X_MICROARCH.md)
+        peak = 2500.0 / 3.0
+        out["policy_roofline"] = {"bound": "mfma", "achieved": flops / pol_us / 1e6, "peak": peak, "unit": "TFLOP/s",
+                                  "frac": flops / pol_us / 1e6 / peak, "dtype": "f16x2 (fp32 operands split into two fp16, fp32 accumulate)",
+                                  "note": "useful fp32-equivalent FLOPs; the fp32 matrix pipe's peak is 157.3 TFLOP/s"}
     return out
 
 

@@ -1880,10 +1880,22 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io
     __shared__ int s_act[16 * N];          // last / chosen action per row (row = env_in_block * N + agent)
     __shared__ float s_b3[16];
     __shared__ double s_eps[BLOCK / G];    // the block's 16 envs' epsilon (cs_epsilon: annealed env by env, rollout.py:75-76)
-    extern __shared__ float pol_lds[];     // s_a | s_b | s_h, each [16N][LDW]; the partial q of fc2 aliases s_a
+    extern __shared__ __attribute__((aligned(16))) float pol_lds[];
     constexpr int ROWS = 16 * N, NA = 3;   // the env has three actions (flight_env_easy.py:32)
+#if CS_POLICY_F16
+    // split-fp16 activations (policy_dev.h): a | b | hs as (hi, lo) plane pairs of [ROWS][HST] halves, then s_h [ROWS][LDW] fp32
+    // (the GRU blend needs the previous hidden state itself); the partial q of fc2 aliases the a planes
+    _Float16 *a_hi = reinterpret_cast<_Float16 *>(pol_lds), *a_lo = a_hi + ROWS * HST;
+    _Float16 *b_hi = a_lo + ROWS * HST, *b_lo = b_hi + ROWS * HST;
+    _Float16 *hs_hi = b_lo + ROWS * HST, *hs_lo = hs_hi + ROWS * HST;
+    float *s_h = reinterpret_cast<float *>(hs_lo + ROWS * HST);
+    float *s_q = pol_lds;                  // [4][ROWS * 17] floats = ROWS * 272 B <= the a planes' ROWS * 288 B
+    static_assert(4 * 17 * 4 <= 2 * HST * 2, "s_q must fit the a planes");
+#else
+    // s_a | s_b | s_h, each [16N][LDW]; the partial q of fc2 aliases s_a
     float *s_a = pol_lds, *s_b = pol_lds + ROWS * LDW, *s_h = pol_lds + 2 * ROWS * LDW;
     float *s_q = s_a;                      // [4][ROWS * 17] <= ROWS * LDW floats
+#endif
     const int gid = blockIdx.x * BLOCK + threadIdx.x;
     const int b = gid / G, t = gid % G;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1904,6 +1916,23 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io
     // ---- policy: weight fragments and biases of this wavefront's column tile, once (k_policy)
     const int crow = (lane >> 4) * 4, ccol = lane & 15, col = 16 * w + ccol;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#if CS_POLICY_F16
+    const unsigned ulane = lane;
+    const BFrag b1 = load_bfrag(pio.w, HOFF_W1, w, ulane);
+    BFrag bg[6][2];
+#pragma unroll
+    for (int g = 0; g < 3; g++)
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            bg[2 * g][ks] = load_bfrag(pio.w, HOFF_WIH, (w + 4 * g) * 2 + ks, ulane);
+            bg[2 * g + 1][ks] = load_bfrag(pio.w, HOFF_WHH, (w + 4 * g) * 2 + ks, ulane);
+        }
+    BFrag b2[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) b2[ks] = load_bfrag(pio.w, HOFF_W2, w * 2 + ks, ulane);
+    const BFrag b3 = load_bfrag(pio.w, HOFF_W3, w, ulane);
+    constexpr int PO_B1 = HOFF_B1, PO_BIH = HOFF_BIH, PO_BHH = HOFF_BHH, PO_B2 = HOFF_B2, PO_B3 = HOFF_B3;
+#else
     float b1[4], bg[6][16], b2[16], b3f[4];
     {
         const unsigned ulane = lane;
@@ -1921,10 +1950,12 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) b3f[kk] = (pio.w + OFF_W3 + (4 * w + kk) * FR)[ulane];
     }
-    const float bias1 = pio.w[OFF_B1 + col], bias2 = pio.w[OFF_B2 + col];
-    const float bir = pio.w[OFF_BIH + col], biz = pio.w[OFF_BIH + 64 + col], bin = pio.w[OFF_BIH + 128 + col];
-    const float bhr = pio.w[OFF_BHH + col], bhz = pio.w[OFF_BHH + 64 + col], bhn = pio.w[OFF_BHH + 128 + col];
-    if (threadIdx.x < 16) s_b3[threadIdx.x] = pio.w[OFF_B3 + threadIdx.x];
+    constexpr int PO_B1 = OFF_B1, PO_BIH = OFF_BIH, PO_BHH = OFF_BHH, PO_B2 = OFF_B2, PO_B3 = OFF_B3;
+#endif
+    const float bias1 = pio.w[PO_B1 + col], bias2 = pio.w[PO_B2 + col];
+    const float bir = pio.w[PO_BIH + col], biz = pio.w[PO_BIH + 64 + col], bin = pio.w[PO_BIH + 128 + col];
+    const float bhr = pio.w[PO_BHH + col], bhz = pio.w[PO_BHH + 64 + col], bhn = pio.w[PO_BHH + 128 + col];
+    if (threadIdx.x < 16) s_b3[threadIdx.x] = pio.w[PO_B3 + threadIdx.x];
     if (threadIdx.x < BLOCK / G)
         s_eps[threadIdx.x] = (pio.eps_dev && b0 + (int)threadIdx.x < p.B) ? pio.eps_dev[b0 + threadIdx.x] : pio.epsilon;
     // hidden state and last actions of the block's rows -> LDS
@@ -1933,8 +1964,14 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io
     for (int m = 0; m < N; m++) {
         const int r = 16 * m + srow;
         const size_t grow = (size_t)b0 * N + (r < rows_valid ? r : 0);
-        *reinterpret_cast<float4 *>(s_h + r * LDW + 4 * kcol) =
-            *reinterpret_cast<const float4 *>(pio.hidden + grow * H + 4 * kcol);
+        const float4 hv = *reinterpret_cast<const float4 *>(pio.hidden + grow * H + 4 * kcol);
+        *reinterpret_cast<float4 *>(s_h + r * LDW + 4 * kcol) = hv;
+#if CS_POLICY_F16
+        split_store(hs_hi, hs_lo, r * HST + 4 * kcol + 0, hv.x);
+        split_store(hs_hi, hs_lo, r * HST + 4 * kcol + 1, hv.y);
+        split_store(hs_hi, hs_lo, r * HST + 4 * kcol + 2, hv.z);
+        split_store(hs_hi, hs_lo, r * HST + 4 * kcol + 3, hv.w);
+#endif
     }
     for (int r = threadIdx.x; r < ROWS; r += BLOCK) s_act[r] = r < rows_valid ? (int)pio.last[(size_t)b0 * N + r] : -1;
     // the current observation of every env goes into its wavefront's tile (what get_obs would return now)
@@ -1947,6 +1984,99 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io
 
     for (int s = 0; s < io.T; s++) {
         __syncthreads();   // tiles / s_act of the previous step are complete; s_q (= s_a) has been consumed
+#if CS_POLICY_F16
+        // ---- x = obs(4) | one_hot(last action) | one_hot(agent id) per row (agent.py:41-52), zero up to column 32 (one k-step):
+        //      two columns per thread, split into (hi, lo) halves
+#pragma unroll
+        for (int m = 0; m < N; m++) {
+            const int r = 16 * m + srow, el = r / N, ag = r - el * N;
+            float v = 0.0f;
+            if (kcol < 4) v = tiles[el >> 2].row[el & 3][4 * ag + kcol];
+            else if (kcol < 4 + NA) v = (kcol - 4 == s_act[r]) ? 1.0f : 0.0f;
+            else if (kcol < in_dim) v = (kcol - 4 - NA == ag) ? 1.0f : 0.0f;
+            split_store(a_hi, a_lo, r * HST + kcol, r < rows_valid ? v : 0.0f);
+            split_store(a_hi, a_lo, r * HST + kcol + 16, 0.0f);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < N; m++) {   // h1 = relu(W1 x + b1), columns 16w..16w+15 of every row tile
+            f32x4 hi = zero, lo = zero;
+            h8 ah, al;
+            load_afrag(a_hi, a_lo, 16 * m, 0, lane, ah, al);
+            mfma_split(ah, al, b1, hi, lo);
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                split_store(b_hi, b_lo, (16 * m + crow + r) * HST + col, fmaxf(split_sum(hi[r], lo[r]) + bias1, 0.0f));
+        }
+        __syncthreads();
+        {   // GRUCell: per row tile the six chains in k_policy_h's order
+            f32x4 hnew[N];
+#pragma unroll
+            for (int m = 0; m < N; m++) {
+                f32x4 hi[6], lo[6];
+#pragma unroll
+                for (int c = 0; c < 6; c++) hi[c] = lo[c] = zero;
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) {
+                    h8 xh, xl, hh, hl;
+                    load_afrag(b_hi, b_lo, 16 * m, ks, lane, xh, xl);
+                    load_afrag(hs_hi, hs_lo, 16 * m, ks, lane, hh, hl);
+#pragma unroll
+                    for (int g = 0; g < 3; g++) {
+                        mfma_split(xh, xl, bg[2 * g][ks], hi[2 * g], lo[2 * g]);
+                        mfma_split(hh, hl, bg[2 * g + 1][ks], hi[2 * g + 1], lo[2 * g + 1]);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float ir = split_sum(hi[0][r], lo[0][r]), hr = split_sum(hi[1][r], lo[1][r]);
+                    const float iz = split_sum(hi[2][r], lo[2][r]), hz = split_sum(hi[3][r], lo[3][r]);
+                    const float in_ = split_sum(hi[4][r], lo[4][r]), hn_ = split_sum(hi[5][r], lo[5][r]);
+                    const float rg = sigmoidf_((ir + bir) + (hr + bhr));
+                    const float zg = sigmoidf_((iz + biz) + (hz + bhz));
+                    const float ng = tanhf_((in_ + bin) + rg * (hn_ + bhn));
+                    hnew[m][r] = (1.0f - zg) * ng + zg * s_h[(16 * m + crow + r) * LDW + col];
+                    split_store(a_hi, a_lo, (16 * m + crow + r) * HST + col, hnew[m][r]);
+                }
+            }
+            __syncthreads();   // every wavefront has finished reading s_h / hs
+#pragma unroll
+            for (int m = 0; m < N; m++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    s_h[(16 * m + crow + r) * LDW + col] = hnew[m][r];
+                    split_store(hs_hi, hs_lo, (16 * m + crow + r) * HST + col, hnew[m][r]);
+                }
+        }
+#pragma unroll
+        for (int m = 0; m < N; m++) {   // f = relu(W2 h' + b2)
+            f32x4 hi = zero, lo = zero;
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                h8 ah, al;
+                load_afrag(a_hi, a_lo, 16 * m, ks, lane, ah, al);
+                mfma_split(ah, al, b2[ks], hi, lo);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                split_store(b_hi, b_lo, (16 * m + crow + r) * HST + col, fmaxf(split_sum(hi[r], lo[r]) + bias2, 0.0f));
+        }
+        __syncthreads();   // f complete; the a planes (h') are no longer needed: their space now takes the partial q
+#pragma unroll
+        for (int m = 0; m < N; m++) {   // partial q over this wavefront's 16 of the 64 k (k-blocks 0, 1; the other lanes add zeros)
+            f32x4 hi = zero, lo = zero;
+            h8 ah = {0, 0, 0, 0, 0, 0, 0, 0}, al = {0, 0, 0, 0, 0, 0, 0, 0};
+            if ((lane >> 4) < 2) {
+                const int idx = (16 * m + (lane & 15)) * HST + 16 * w + 8 * (lane >> 4);
+                ah = *reinterpret_cast<const h8 *>(b_hi + idx);
+                al = *reinterpret_cast<const h8 *>(b_lo + idx);
+            }
+            mfma_split(ah, al, b3, hi, lo);
+#pragma unroll
+            for (int r = 0; r < 4; r++) s_q[w * (ROWS * 17) + (16 * m + crow + r) * 17 + ccol] = split_sum(hi[r], lo[r]);
+        }
+        __syncthreads();
+#else
         // ---- x = obs(4) | one_hot(last action) | one_hot(agent id) per row (agent.py:41-52), one column per thread
 #pragma unroll
         for (int m = 0; m < N; m++) {
@@ -2037,6 +2167,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io
                 for (int r = 0; r < 4; r++) s_q[w * (ROWS * 17) + (16 * m + crow + r) * 17 + ccol] = acc[m][r];
         }
         __syncthreads();
+#endif
         for (int r = threadIdx.x; r < ROWS; r += BLOCK) {   // argmax / epsilon-greedy, one thread per row
             auto qf = [&](int a) {
                 const int o = r * 17 + a;
@@ -2893,7 +3024,7 @@ __device__ __forceinline__ void div2_same_denominator(double nx, double ny, doub
 // already-moved one if J < I -- and, if it is within force_dist, computes its term of I's repulsion (:293-301); the terms
 // meet in lane I (ordered DPP sum); lane I moves its agent, applies the wall rule and becomes "already moved" for the
 // later stages.  The two fp64 divisions run only if SOME env of the wavefront has such a neighbour in this stage.
-template <int N, int I>
+template <int N, int I, bool SHARED_DIV>
 struct OctStage {
     static __device__ __forceinline__ void run(const DevParams &p, const double2 (*pos)[OCT_PAD], int o, int t, bool act_lane,
                                                OctKin &k) {
@@ -2905,8 +3036,13 @@ struct OctStage {
             if (__ballot(inr)) {   // wave-uniform
                 const double ex = xi - k.cx, ey = yi - k.cy;
                 const double den = ex * ex + ey * ey;
-                double qx, qy;
-                div2_same_denominator(p.force_k * ex, p.force_k * ey, inr ? den : 1.0, qx, qy);   // force_k*(x-x_a)/den: product first
+                double qx, qy;   // force_k*(x-x_a)/den: product first, then the division
+                if constexpr (SHARED_DIV) {
+                    div2_same_denominator(p.force_k * ex, p.force_k * ey, inr ? den : 1.0, qx, qy);
+                } else {
+                    qx = p.force_k * ex / den;
+                    qy = p.force_k * ey / den;
+                }
                 const double tx = inr ? qx : 0.0;
                 const double ty = inr ? qy : 0.0;
                 double fx = 0.0, fy = 0.0;
@@ -2924,14 +3060,18 @@ struct OctStage {
                 k.cy = k.yf;
                 k.hit = k.hitf;
             }
-            OctStage<N, I + 1>::run(p, pos, o, t, act_lane, k);
+            OctStage<N, I + 1, SHARED_DIV>::run(p, pos, o, t, act_lane, k);
         }
     }
 };
 
 // Kinematics of one step for the octet's env (flight_env_easy.py:255-301); `act` = this lane's agent's action.
 // Returns the octet's out_flag bits.  Lanes t >= N hold no agent and take no part in any decision.
-template <int N>
+// SHARED_DIV: the two components of a repulsion term share one reciprocal (div2_same_denominator: same quotients, ~19 instructions
+// fewer per stage that runs).  Measured (tools/gpu_r4_f.sh, 3 agents): the one-wavefront octet kernel at 32768 envs +8 %, the pair
+// kernel at 8192 / 16384 envs +2 %, but the c2 pair (4096 envs, K alone on its SIMD and bound by its dependent chain) -1.9 %: the
+// range check in front of the shared sequence lengthens the chain.  So: the one-wavefront kernel only.
+template <int N, bool SHARED_DIV = false>
 __device__ __forceinline__ unsigned oct_kinematics(const DevParams &p, const double *T, const double2 (*pos)[OCT_PAD], int o, int t,
                                                    int sh8, bool stepping, int act, EnvO<N> &e, int tl_step = -1) {
     const double PI = 3.141592653589793, TWO_PI = 2.0 * 3.141592653589793, THREE_PI = 3.0 * 3.141592653589793;
@@ -2988,7 +3128,7 @@ __device__ __forceinline__ unsigned oct_kinematics(const DevParams &p, const dou
         any_pair = any_pair | ((t != I) & (dx * dx + dy * dy < p.force_d2) & ((qx != pi.x) | (qy != pi.y)));
     }
     if (__ballot(any_pair & upd)) {
-        OctStage<N, 0>::run(p, pos, o, t, upd, k);
+        OctStage<N, 0, SHARED_DIV>::run(p, pos, o, t, upd, k);
     } else {
         k.cx = k.xf;
         k.cy = k.yf;
@@ -3455,7 +3595,7 @@ __global__ __launch_bounds__(OCT_BLOCK, CS_OCT_WAVES) void k_rollout_oct(DevPara
         const bool stepping = live && !(done && freeze);
         OCT_STAMP(1);
         // ---- kinematics -> positions, obs floats, out flags
-        const unsigned out = oct_kinematics<N>(p, T, sh.pos, o, t, sh8, stepping, act, e);
+        const unsigned out = oct_kinematics<N, CS_SHARED_RCP_DIV != 0>(p, T, sh.pos, o, t, sh8, stepping, act, e);
         OCT_STAMP(2);
         if (stepping) e.flags = (e.flags & ~0xff00) | (int)(out << 8);
         sh.pos[o][t] = make_double2(e.x, e.y);
@@ -3664,6 +3804,20 @@ struct __attribute__((aligned(16))) OdOut {
     int term[OCT_ENVS], win[OCT_ENVS];
     unsigned found[OCT_ENVS];
 };
+// -DCS_JITTER (test builds only, tests/test_gpu_jitter.py): a pseudo-random pause of 0..1800 cycles -- up to two thirds of a step --
+// in each role at every hand-shake of the pair's protocol (before a counter is read, before it is posted, around a fix request and
+// its acknowledgement).  The K / D / E hand-shakes rest on LDS ordering with hand-placed ds instructions and no fence; the parity
+// suite exercises the protocol's LOGIC (mispredictions every other step) but at the kernel's natural timing only.  With the pauses
+// every interleaving of the three wavefronts that the counters allow actually happens; results must not move by a bit.
+#ifdef CS_JITTER
+#define OD_JITTER(salt) do { \
+        unsigned jh_ = (unsigned)blockIdx.x * 2654435761u ^ (unsigned)(s + 1) * 40503u ^ (unsigned)(salt) * 2246822519u ^ (unsigned)role * 3266489917u; \
+        jh_ ^= jh_ >> 15; jh_ *= 2246822519u; jh_ ^= jh_ >> 13; \
+        for (unsigned jq_ = __builtin_amdgcn_readfirstlane(jh_ & 7u); jq_ > 0u; jq_--) __builtin_amdgcn_s_sleep(4); \
+    } while (0)
+#else
+#define OD_JITTER(salt) do {} while (0)
+#endif
 template <int N, bool VEC, bool EMIT, bool E3>
 __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams p, StepIO io) {
     static_assert(!E3 || (VEC && EMIT), "the emitting wavefront has the full-wavefront, obs + state stores only");
@@ -3829,6 +3983,7 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
             asm volatile("" : "+v"(t));
             ag = t < N;
             DUO_STAMP(0);
+            OD_JITTER(1);
             const int act_after = ap[0];
             if (s + 3 < io.T) ap += astep;
             // flow control: slot s % OD_RING is free once D has finished step s - OD_RING (E3: ... once E has written step
@@ -3849,6 +4004,7 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
             DUO_STAMP(2);
             produce(s, act, true);
             DUO_STAMP(1);
+            OD_JITTER(2);
             post(&sh.k_steps, s + 1);
             act = act_next;
             act_next = act_after;
@@ -3900,7 +4056,9 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
         for (int s = 0; s < io.T; s++) {
             asm volatile("" : "+v"(t));
             ag = t < N;
+            OD_JITTER(3);
             while (peek(&sh.d_steps) <= s) { SPIN_TICK; __builtin_amdgcn_s_sleep(1); }   // D has judged step s: its record and K's slot are final
+            OD_JITTER(4);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const OdRing &r = sh.ring[s & (OD_RING - 1)];
             const OdOut &d = outs[s & (OD_RING - 1)];
@@ -3944,6 +4102,7 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
             for (int q = 0; q < Q; q++) __builtin_nontemporal_store(o_st[q], p_st + chunk[q]);
             p_st += (size_t)p.B * W / 4;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (the tile reads above are complete: their values are in registers)
+            OD_JITTER(5);
             if (lane == 0) lds_post(&e_steps, s + 1);
         }
         SPIN_STORE(2);
@@ -4126,8 +4285,10 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
         }
         const bool stepping = live && !(done && freeze);
         DUO_STAMP(9);
+        OD_JITTER(6);
         // ---- K's step s (normally produced long ago): out flags, the agents' four floats (get_obs / get_state), positions
         while (peek(&sh.k_steps) <= s) { SPIN_TICK; __builtin_amdgcn_s_sleep(1); }
+        OD_JITTER(7);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #ifdef CS_OD_ABL_NODET   /* experiment: what K alone sustains */
         post(&sh.d_steps, s + 1);
@@ -4158,6 +4319,7 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
 #pragma unroll
             for (int q = 0; q < OCT_ENVS; q++) m8 |= (unsigned)((mb >> (OG * q)) & 1ull) << q;
             if (lane == 0) sh.fix_mask = m8;
+            OD_JITTER(8);
             post(&sh.fix_req, s + 1);
         }
         if (E3) {   // this step's record for E (published with d_steps below)
@@ -4262,6 +4424,7 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
         if (__builtin_expect(mb != 0ull, 0)) {   // slot s stays ours until K has restored the flagged envs from it
             while (peek(&sh.fix_ack) != s + 1) __builtin_amdgcn_s_sleep(1);
         }
+        OD_JITTER(9);
         post(&sh.d_steps, s + 1);
         DUO_STAMP(12);
     }
@@ -4927,7 +5090,7 @@ void launch_od(const cs_config *cfg, const DevParams &p, StepIO io, hipStream_t 
         hipLaunchKernelGGL((k_rollout_od<N, false, false, false>), dim3((unsigned)((p.B - full + OCT_ENVS - 1) / OCT_ENVS)), dim3(OD_BLOCK), 0, s, p, io);
     }
 }
-// cs_rollout: the lane kernel's lower bound, by bench.py's protocol (tools/gpu_r3_z.sh): 3 agents 65536 envs octet 7.8e9 against
+// cs_rollout: the first-generation lane kernel's lower bound, by bench.py's protocol (round 3): 3 agents 65536 envs octet 7.8e9 against
 // lane 7.3e9, 98304 8.0 / 8.2, 131072 8.2 / 10.4; 5 agents (the 250-VGPR lane variant) 262144 octet 5.6e9 against lane 4.9e9,
 // 524288 5.7 / 5.0, 2^20 5.8 / 6.4.
 // k_rollout_lanev (teams of up to 5) takes over from the octet kernel at 65536 envs -- one wavefront per SIMD -- (tools/gpu_r4_d.sh:
@@ -5193,12 +5356,17 @@ int cs_rollout_policy(const cs_config *cfg, void *state_dev, const float *packed
     StepIO io{nullptr, reward_dev, terminated_dev, win_dev, obs_dev, state_out_dev, flags, T};
     PolicyIO pio{packed_dev, hidden_dev, last_dev, actions_dev, eps->epsilon, eps->anneal, eps->min_epsilon, eps->per_step,
                  eps->eps_dev, eps->trace_dev, seed, step0, row0, select};
-    const size_t lds = (size_t)3 * 16 * cfg->n_agents * LDW * sizeof(float);
+#if CS_POLICY_F16
+#define CS_RP_LDS(NN) ((size_t)16 * (NN) * (6 * HST * 2 + LDW * 4))   /* six split planes of halves + s_h fp32, per row */
+#else
+#define CS_RP_LDS(NN) ((size_t)3 * 16 * (NN) * LDW * 4)
+#endif
+    const size_t lds = CS_RP_LDS(cfg->n_agents);
 #define CS_LAUNCH_RP(NN)                                                                                               \
     case NN: {                                                                                                         \
         static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(k_rollout_policy<NN>),           \
                                                        hipFuncAttributeMaxDynamicSharedMemorySize,                     \
-                                                       3 * 16 * NN * LDW * 4) == hipSuccess;                           \
+                                                       (int)CS_RP_LDS(NN)) == hipSuccess;                              \
         if (!lds_ok) return fail(CS_E_LAUNCH, "cs_rollout_policy: cannot reserve the LDS tile");                       \
         hipLaunchKernelGGL(k_rollout_policy<NN>, dim3(env_blocks(p)), dim3(BLOCK), lds, (hipStream_t)stream, p, io, pio); \
     } break;

@@ -217,6 +217,186 @@ __global__ __launch_bounds__(PBLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 }
 
 
+#if CS_POLICY_F16
+// k_policy on the 16-bit matrix pipe with split-fp16 operands (policy_dev.h): same decomposition -- a block of 4 wavefronts owns a
+// 16-row tile, wavefront w the hidden columns 16w..16w+15 of every layer, weights resident in registers (32 B fragments: 128
+// VGPRs), activations through LDS as (hi, lo) plane pairs, one barrier per layer, the next tile's inputs prefetched -- with 48
+// matrix instructions of ~17 cycles per tile and wavefront instead of 120 of 32.  The fc1 input is padded to 32 columns (one k-step)
+// whether or not the conv features are present.
+__global__ __launch_bounds__(PBLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_policy_h(PolicyParams p) {
+    __shared__ __attribute__((aligned(16))) _Float16 s_a[2][16 * HST];   // x, then h'      (hi, lo planes)
+    __shared__ __attribute__((aligned(16))) _Float16 s_b[2][16 * HST];   // h1, then f
+    __shared__ __attribute__((aligned(16))) _Float16 s_hs[2][16 * HST];  // previous hidden state, split
+    __shared__ float s_h[16 * LDW];      // previous hidden state, fp32 (the GRU blend)
+    __shared__ float s_q[4][16 * 17];    // partial q of the four wavefronts
+    __shared__ float s_b3[16];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // w is wave-uniform
+    const int crow = (lane >> 4) * 4, ccol = lane & 15;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const unsigned ulane = lane;
+
+    // every weight fragment this wavefront will use and its biases, once
+    const BFrag b1 = load_bfrag(p.w, HOFF_W1, w, ulane);
+    BFrag bg[6][2];
+#pragma unroll
+    for (int g = 0; g < 3; g++)   // torch.nn.GRUCell: gates ordered r, z, n in weight_ih / weight_hh
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            bg[2 * g][ks] = load_bfrag(p.w, HOFF_WIH, (w + 4 * g) * 2 + ks, ulane);
+            bg[2 * g + 1][ks] = load_bfrag(p.w, HOFF_WHH, (w + 4 * g) * 2 + ks, ulane);
+        }
+    BFrag b2[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) b2[ks] = load_bfrag(p.w, HOFF_W2, w * 2 + ks, ulane);
+    const BFrag b3 = load_bfrag(p.w, HOFF_W3, w, ulane);
+    if (threadIdx.x < 16) s_b3[threadIdx.x] = p.w[HOFF_B3 + threadIdx.x];  // visible after the first barrier
+    const int col = 16 * w + ccol;
+    const float bias1 = p.w[HOFF_B1 + col], bias2 = p.w[HOFF_B2 + col];
+    const float bir = p.w[HOFF_BIH + col], biz = p.w[HOFF_BIH + 64 + col], bin = p.w[HOFF_BIH + 128 + col];
+    const float bhr = p.w[HOFF_BHH + col], bhz = p.w[HOFF_BHH + 64 + col], bhn = p.w[HOFF_BHH + 128 + col];
+
+    // staging: 16 threads per row, two input columns (k, k + 16) and four hidden values each.  Input row (agent.py:41-52,
+    // base_net.py:31-39): [16 conv features |] obs(4) | one_hot(last action) | one_hot(agent id), zero up to column 32; raw mode
+    // (no `last`): [16 conv features |] the caller's own columns.
+    constexpr int NCOL = 2;
+    const int tiles = (p.rows + 15) / 16;
+    const int fbase = p.feat ? NFEAT : 0, in_dim = fbase + 4 + p.n_actions + p.n_agents;
+    const int srow = threadIdx.x >> 4, kcol = threadIdx.x & 15;
+    enum { ZERO, OBS, FEAT, LAST, AGENT };
+    int kind[NCOL], kidx[NCOL];
+#pragma unroll
+    for (int j = 0; j < NCOL; j++) {
+        const int k = kcol + 16 * j, ko = k - fbase;
+        kind[j] = k >= in_dim ? ZERO : k < fbase ? FEAT : (!p.last || ko < 4) ? OBS : ko < 4 + p.n_actions ? LAST : AGENT;
+        kidx[j] = kind[j] == FEAT ? k : kind[j] == OBS ? ko : kind[j] == LAST ? ko - 4 : ko - 4 - p.n_actions;
+    }
+    float xv[NCOL];
+    int lav[NCOL];
+    float4 hv;
+    auto fetch = [&](int tile) {   // loads only: nothing here waits for memory
+        const int row = 16 * tile + srow < p.rows ? 16 * tile + srow : p.rows - 1;
+#pragma unroll
+        for (int j = 0; j < NCOL; j++) {
+            xv[j] = kind[j] == OBS ? p.obs[(size_t)row * p.obs_stride + p.obs_offset + kidx[j]]
+                  : kind[j] == FEAT ? p.feat[(size_t)(row / p.rows_per_feat) * NFEAT + kidx[j]] : 0.0f;
+            lav[j] = kind[j] == LAST ? (int)p.last[row] : -1;
+        }
+        hv = *reinterpret_cast<const float4 *>(p.hidden + (size_t)row * H + 4 * kcol);
+    };
+    auto input_value = [&](int j, int row) {
+        if (kind[j] == OBS || kind[j] == FEAT) return xv[j];
+        if (kind[j] == LAST) return kidx[j] == lav[j] ? 1.0f : 0.0f;
+        return (kind[j] == AGENT && kidx[j] == row % p.n_agents) ? 1.0f : 0.0f;
+    };
+
+    int tile = blockIdx.x;
+    if (tile < tiles) fetch(tile);
+    for (int iter = 0; tile < tiles; tile += gridDim.x, iter++) {
+        const int row0 = 16 * tile;
+        POL_STAMP(0);
+#pragma unroll
+        for (int j = 0; j < NCOL; j++)
+            split_store(s_a[0], s_a[1], srow * HST + kcol + 16 * j, input_value(j, row0 + srow < p.rows ? row0 + srow : p.rows - 1));
+        *reinterpret_cast<float4 *>(s_h + srow * LDW + 4 * kcol) = hv;
+        split_store(s_hs[0], s_hs[1], srow * HST + 4 * kcol + 0, hv.x);
+        split_store(s_hs[0], s_hs[1], srow * HST + 4 * kcol + 1, hv.y);
+        split_store(s_hs[0], s_hs[1], srow * HST + 4 * kcol + 2, hv.z);
+        split_store(s_hs[0], s_hs[1], srow * HST + 4 * kcol + 3, hv.w);
+        if (tile + (int)gridDim.x < tiles) fetch(tile + gridDim.x);
+        __syncthreads();
+        POL_STAMP(1);
+
+        {   // h1 = relu(W1 x + b1), columns 16w..16w+15
+            f32x4 hi = zero, lo = zero;
+            h8 ah, al;
+            load_afrag(s_a[0], s_a[1], 0, 0, lane, ah, al);
+            mfma_split(ah, al, b1, hi, lo);
+#pragma unroll
+            for (int r = 0; r < 4; r++) split_store(s_b[0], s_b[1], (crow + r) * HST + col, fmaxf(split_sum(hi[r], lo[r]) + bias1, 0.0f));
+        }
+        __syncthreads();
+        POL_STAMP(2);
+
+        {   // GRUCell, columns 16w..16w+15: six independent chains (an accumulator pair each), interleaved
+            f32x4 hi[6], lo[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) hi[c] = lo[c] = zero;
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                h8 xh, xl, hh, hl;
+                load_afrag(s_b[0], s_b[1], 0, ks, lane, xh, xl);
+                load_afrag(s_hs[0], s_hs[1], 0, ks, lane, hh, hl);
+#pragma unroll
+                for (int g = 0; g < 3; g++) {
+                    mfma_split(xh, xl, bg[2 * g][ks], hi[2 * g], lo[2 * g]);
+                    mfma_split(hh, hl, bg[2 * g + 1][ks], hi[2 * g + 1], lo[2 * g + 1]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float ir = split_sum(hi[0][r], lo[0][r]), hr = split_sum(hi[1][r], lo[1][r]);
+                const float iz = split_sum(hi[2][r], lo[2][r]), hz = split_sum(hi[3][r], lo[3][r]);
+                const float in_ = split_sum(hi[4][r], lo[4][r]), hn_ = split_sum(hi[5][r], lo[5][r]);
+                const float rg = sigmoidf_((ir + bir) + (hr + bhr));
+                const float zg = sigmoidf_((iz + biz) + (hz + bhz));
+                const float ng = tanhf_((in_ + bin) + rg * (hn_ + bhn));
+                const float hnew = (1.0f - zg) * ng + zg * s_h[(crow + r) * LDW + col];
+                split_store(s_a[0], s_a[1], (crow + r) * HST + col, hnew);  // s_a (x) was last read before the previous barrier
+                if (row0 + crow + r < p.rows) p.hidden[(size_t)(row0 + crow + r) * H + col] = hnew;
+            }
+        }
+        __syncthreads();
+        POL_STAMP(3);
+
+        {   // f = relu(W2 h' + b2), columns 16w..16w+15
+            f32x4 hi = zero, lo = zero;
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                h8 ah, al;
+                load_afrag(s_a[0], s_a[1], 0, ks, lane, ah, al);
+                mfma_split(ah, al, b2[ks], hi, lo);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) split_store(s_b[0], s_b[1], (crow + r) * HST + col, fmaxf(split_sum(hi[r], lo[r]) + bias2, 0.0f));
+        }
+        __syncthreads();
+        POL_STAMP(4);
+
+        {   // q = W3 f + b3: the 64-long reduction is split four ways over the wavefronts (columns 16w..16w+15 of f: k-blocks 0, 1 of
+            // this wavefront's fragment; the lanes of k-blocks 2, 3 contribute zeros)
+            f32x4 hi = zero, lo = zero;
+            h8 ah = {0, 0, 0, 0, 0, 0, 0, 0}, al = {0, 0, 0, 0, 0, 0, 0, 0};
+            if ((lane >> 4) < 2) {
+                const int idx = (lane & 15) * HST + 16 * w + 8 * (lane >> 4);
+                ah = *reinterpret_cast<const h8 *>(s_b[0] + idx);
+                al = *reinterpret_cast<const h8 *>(s_b[1] + idx);
+            }
+            mfma_split(ah, al, b3, hi, lo);
+#pragma unroll
+            for (int r = 0; r < 4; r++) s_q[w][(crow + r) * 17 + ccol] = split_sum(hi[r], lo[r]);
+        }
+        __syncthreads();
+        POL_STAMP(5);
+
+        // final sum, argmax and epsilon-greedy: one thread per row (wavefront 0 only; the others run ahead to the
+        // next tile's staging)
+        if (threadIdx.x < 16) {
+            const int row = row0 + threadIdx.x;
+            auto qf = [&](int a) {
+                const int o = threadIdx.x * 17 + a;
+                return ((s_q[0][o] + s_q[1][o]) + (s_q[2][o] + s_q[3][o])) + s_b3[a];
+            };
+            if (p.q && row < p.rows)
+                for (int a = 0; a < p.n_actions; a++) p.q[(size_t)row * p.n_actions + a] = qf(a);
+            const float eps = p.eps_env ? (float)p.eps_env[(row < p.rows ? row : p.rows - 1) / p.n_agents] : p.epsilon;
+            const int act = select_action(qf, p.n_actions, p.select, eps, p.seed, p.step, p.row0 + (unsigned long long)row);
+            if (row < p.rows) p.actions[row] = act;
+        }
+        POL_STAMP(6);
+    }
+}
+#endif   // CS_POLICY_F16
+
 // ---- flight: conv front end of the agent network (network/base_net.py:9-18,31-36) ---------------------------------
 // Conv2d(1, 4, k=4, s=2) -> ReLU -> Conv2d(4, 1, k=3, s=1, p=1) -> ReLU -> Linear(576, 16) on the 50 x 50 probability
 // map (the reference's flight hyper-parameters, common/arguments.py:256-265; anything else stays on the torch path).
@@ -415,6 +595,34 @@ int cs_policy_pack(const float *fc1_w, const float *fc1_b, const float *w_ih, co
         return CS_E_ARG;
     }
     for (int i = 0; i < PACKED_FLOATS; i++) packed[i] = 0.0f;
+#if CS_POLICY_F16
+    // split-fp16 fragments (policy_dev.h): fragment (column tile nt, k-step ks of 32) = hi plane | lo plane, each [64 lanes][8 halves];
+    // lane l, j: W[16 nt + (l & 15)][k0 + 32 ks + 8 (l >> 4) + j] for k-blocks (l >> 4) < kblocks, zero beyond
+    auto hfrag = [&](int off, int frag, const float *w, int n_out, int k_in, int nt, int k0, int kblocks) {
+        _Float16 *hi = reinterpret_cast<_Float16 *>(packed + off + (size_t)frag * FRAG_DW), *lo = hi + 64 * 8;
+        for (int l = 0; l < 64; l++)
+            for (int j = 0; j < 8; j++) {
+                const int n = 16 * nt + (l & 15), k = k0 + 8 * (l >> 4) + j;
+                const float v = (n < n_out && k < k_in && (l >> 4) < kblocks) ? w[(size_t)n * k_in + k] : 0.0f;
+                split_f16(v, hi[l * 8 + j], lo[l * 8 + j]);
+            }
+    };
+    for (int nt = 0; nt < 4; nt++) hfrag(HOFF_W1, nt, fc1_w, 64, in_dim, nt, 0, 4);
+    for (int nt = 0; nt < 12; nt++)
+        for (int ks = 0; ks < 2; ks++) {
+            hfrag(HOFF_WIH, nt * 2 + ks, w_ih, 192, 64, nt, 32 * ks, 4);
+            hfrag(HOFF_WHH, nt * 2 + ks, w_hh, 192, 64, nt, 32 * ks, 4);
+        }
+    for (int nt = 0; nt < 4; nt++)
+        for (int ks = 0; ks < 2; ks++) hfrag(HOFF_W2, nt * 2 + ks, fc2a_w, 64, 64, nt, 32 * ks, 4);
+    for (int wv = 0; wv < 4; wv++) hfrag(HOFF_W3, wv, fc2b_w, n_actions, 64, 0, 16 * wv, 2);   // wavefront wv's 16 of the 64 k
+    for (int i = 0; i < 64; i++) packed[HOFF_B1 + i] = fc1_b[i];
+    for (int i = 0; i < 192; i++) packed[HOFF_BIH + i] = b_ih[i];
+    for (int i = 0; i < 192; i++) packed[HOFF_BHH + i] = b_hh[i];
+    for (int i = 0; i < 64; i++) packed[HOFF_B2 + i] = fc2a_b[i];
+    for (int i = 0; i < n_actions; i++) packed[HOFF_B3 + i] = fc2b_b[i];
+    return CS_OK;
+#endif
     auto frag = [&](int off, int tiles, int ksteps, const float *w, int n_out, int k_in) {
         for (int nt = 0; nt < tiles; nt++)
             for (int kk = 0; kk < ksteps; kk++)
@@ -453,6 +661,17 @@ int cs_policy_forward(const float *packed_dev, const float *obs_dev, int obs_str
     PolicyParams p{rows, n_agents, n_actions, obs_stride, obs_offset, epsilon, eps_env_dev, seed, step, row0, select, packed_dev, obs_dev, last_dev,
                    feat_dev, rows_per_feat, hidden_dev, q_dev, actions_dev};
     const int tiles = (rows + 15) / 16;
+#if CS_POLICY_F16
+    {
+        static const int resident = resident_blocks(k_policy_h);   // persistent grid: what the device holds at once
+        hipLaunchKernelGGL(k_policy_h, dim3(tiles < resident ? tiles : resident), dim3(PBLOCK), 0, (hipStream_t)stream, p);
+        if (hipGetLastError() != hipSuccess) {
+            snprintf(g_perr, sizeof(g_perr), "cs_policy_forward: kernel launch failed");
+            return CS_E_LAUNCH;
+        }
+        return CS_OK;
+    }
+#endif
     if (in_dim <= 16) {
         static const int resident = resident_blocks(k_policy<4>);   // persistent grid: what the device holds at once
         hipLaunchKernelGGL(k_policy<4>, dim3(tiles < resident ? tiles : resident), dim3(PBLOCK), 0, (hipStream_t)stream, p);

@@ -24,7 +24,82 @@ constexpr int OFF_BIH = OFF_B1 + 64;                // 192
 constexpr int OFF_BHH = OFF_BIH + 192;              // 192
 constexpr int OFF_B2 = OFF_BHH + 192;               // 64
 constexpr int OFF_B3 = OFF_B2 + 64;                 // 16
-constexpr int PACKED_FLOATS = OFF_B3 + 16;
+constexpr int PACKED_FLOATS_F32 = OFF_B3 + 16;
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Split-fp16 matrix path (default).  The fp32 matrix pipe (v_mfma_f32_16x16x4_f32) runs at the vector rate, 1/16 of the 16-bit
+// rate, and at 92 kFLOP per env-step it caps the closed loop at ~1.7e9 env-steps/s however fast the env is.  Here every fp32
+// operand v is carried as TWO fp16 numbers, v = hi + lo / 2048 with hi = fp16(v) and lo = fp16((v - hi) * 2048) -- 22 significant
+// bits, the low part pre-scaled so that it never falls into fp16's subnormal range -- and a product a*b is evaluated as
+//     a_hi*b_hi + (a_lo*b_hi + a_hi*b_lo) / 2048
+// with three v_mfma_f32_16x16x32_f16 (exact fp16 products, fp32 accumulation; the dropped a_lo*b_lo term is 2^-22 relative):
+// three matrix instructions per K = 32 instead of eight fp32 ones per K = 32, each ~17 instead of 32 cycles -- 5x the rate at
+// an error of ~2.4e-7 per product, two orders below the 2e-5 parity bar with the reference network (network/base_net.py:31-46).
+// Values below fp16's normal range (6.1e-5) go entirely to the scaled low part, so no subnormal is ever handed to the matrix pipe.
+// ---------------------------------------------------------------------------------------------------------------------------
+#ifndef CS_POLICY_F16
+#define CS_POLICY_F16 1
+#endif
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+constexpr int HST = 72;                 // halves per LDS row of a split activation plane: rows 144 B apart, conflict-free 16-byte reads
+constexpr float LO_SCALE = 2048.0f, LO_INV = 1.0f / 2048.0f;
+constexpr float F16_MIN_NORMAL = 6.2e-5f;
+// packed weights, in dwords: fragment f = 2 planes (hi, lo) x 64 lanes x 4 dwords (8 halves): lane l of fragment (column tile nt,
+// k-step ks of 32) holds W[16 nt + (l & 15)][32 ks + 8 (l >> 4) + j], j = 0..7 -- the B operand of one 16x16x32 MFMA
+constexpr int FRAG_DW = 2 * 64 * 4;
+constexpr int HOFF_W1 = 0;                               // [4 col tiles][1 k-step]   (inputs padded to 32 columns)
+constexpr int HOFF_WIH = HOFF_W1 + 4 * 1 * FRAG_DW;      // [12][2]
+constexpr int HOFF_WHH = HOFF_WIH + 12 * 2 * FRAG_DW;    // [12][2]
+constexpr int HOFF_W2 = HOFF_WHH + 12 * 2 * FRAG_DW;     // [4][2]
+constexpr int HOFF_W3 = HOFF_W2 + 4 * 2 * FRAG_DW;       // [4 K-slices of 16, one per wavefront][1]: lanes 32..63 (k >= 16) are zero
+constexpr int HOFF_B1 = HOFF_W3 + 4 * FRAG_DW;           // biases, fp32
+constexpr int HOFF_BIH = HOFF_B1 + 64;
+constexpr int HOFF_BHH = HOFF_BIH + 192;
+constexpr int HOFF_B2 = HOFF_BHH + 192;
+constexpr int HOFF_B3 = HOFF_B2 + 64;
+constexpr int PACKED_FLOATS_F16 = HOFF_B3 + 16;
+constexpr int PACKED_FLOATS = CS_POLICY_F16 ? PACKED_FLOATS_F16 : PACKED_FLOATS_F32;
+
+// v -> (hi, lo) of the split representation (same code on the host for the weights, cs_policy_pack)
+__host__ __device__ __forceinline__ void split_f16(float v, _Float16 &hi, _Float16 &lo) {
+    const float a = v < 0.0f ? -v : v;
+    hi = a < F16_MIN_NORMAL ? (_Float16)0.0f : (_Float16)v;
+    lo = (_Float16)((v - (float)hi) * LO_SCALE);
+}
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+// one element of a split activation plane pair in LDS (planes: [rows][HST] halves)
+__device__ __forceinline__ void split_store(_Float16 *hi, _Float16 *lo, int idx, float v) {
+    _Float16 h, l;
+    split_f16(v, h, l);
+    hi[idx] = h;
+    lo[idx] = l;
+}
+// B fragment (hi, lo) of one (column tile, k-step) for this lane
+struct BFrag {
+    h8 hi, lo;
+};
+__device__ __forceinline__ BFrag load_bfrag(const float *packed, int off_dw, int frag, unsigned lane) {
+    const uint4 *base = reinterpret_cast<const uint4 *>(packed + off_dw + (size_t)frag * FRAG_DW);
+    const uint4 a = base[lane], b = base[64 + lane];
+    BFrag f;
+    __builtin_memcpy(&f.hi, &a, 16);
+    __builtin_memcpy(&f.lo, &b, 16);
+    return f;
+}
+// A fragment of k-step ks from a split plane pair (16 rows of one tile starting at `row0` of the planes)
+__device__ __forceinline__ void load_afrag(const _Float16 *hi, const _Float16 *lo, int row0, int ks, int lane, h8 &ah, h8 &al) {
+    const int idx = (row0 + (lane & 15)) * HST + 32 * ks + 8 * (lane >> 4);
+    ah = *reinterpret_cast<const h8 *>(hi + idx);
+    al = *reinterpret_cast<const h8 *>(lo + idx);
+}
+// one k-step of the split product into the (hi, lo) accumulator pair: ALWAYS in this order, in every kernel
+__device__ __forceinline__ void mfma_split(const h8 ah, const h8 al, const BFrag &b, f32x4 &hi, f32x4 &lo) {
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b.hi, lo, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.lo, lo, 0, 0, 0);
+    hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.hi, hi, 0, 0, 0);
+}
+__device__ __forceinline__ float split_sum(float hi, float lo) { return hi + lo * LO_INV; }
+#endif
 
 
 // Gate nonlinearities on the hardware exp2 / rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each): absolute error ~1e-7 on

@@ -22,7 +22,9 @@
 //     copy the piece out as float4 chunks, non-temporal; then the other half.  The wavefront's MT19937 row buffer of the
 //     in-loop refresh ALIASES the piece (the row is twisted between two write-outs);
 //   * the refresh row is requested after the kinematics and consumed after the draws of the SAME step (ten dwords per lane
-//     live across the sensor tests only, where the register pressure is lowest), not held across a step;
+//     live across the sensor tests only, where the register pressure is lowest), not held across a step; the hit tapes sit
+//     in LDS with a per-lane cursor instead of ten barrel-shifted registers, and a step walks the MISSES among its draws
+//     (0.3 per env-step) instead of the in-range pairs;
 //   * resets take the lean path only (one attempt batch from twisted words, LDS tables, scalar kernarg loads, host start
 //     poses); everything unusual -- batch not sufficient, words not twisted, a target within view of a start pose (the
 //     reset-time detection pass then draws, quirk Q3) -- goes through the generic 16-lane code on a temporary Env<N>.
@@ -402,18 +404,23 @@ __global__ __launch_bounds__(BLOCK, lv_waves(N)) void k_rollout_lanev(DevParams 
         const bool stepping = live && !(done && freeze);
         LANE_STAMP(1);
         e.flags &= ~(FLAG_DIRTY | FLAG_RESET_PASS);
-        // ---- in-loop refresh, first half: the row of the env running lowest on twisted words is requested now -- BEFORE the
-        //      kinematics: requested after them it had not arrived by the end of the draws (refresh 6200 cycles per step, the
-        //      wait included) -- and twisted after the draws of this step (each env comes round about every 64 steps)
+        // ---- in-loop refresh, first half: the row of the env running lowest on twisted words is requested after the kinematics
+        //      and twisted after the draws of this step (each env comes round about every 64 steps)
+#ifndef CS_LV_REFRESH_EARLY
+#define CS_LV_REFRESH_EARLY 0   /* request the refresh row BEFORE the kinematics instead of after them: measured on one box, two
+                                   runs each (tools/gpu_r4_g.sh): 5 agents no difference, 3 agents -2..-3 % */
+#endif
         RowRegs rr;
         int cand;
-        {
+        auto request_row = [&]() __attribute__((always_inline)) {
             constexpr int URGENT = LOW + 64, NORMAL = 352 > LOW + 128 ? 352 : LOW + 128;
             const unsigned long long urgent = __ballot(e.ahead < URGENT), normal = __ballot(e.ahead < NORMAL);
             cand = urgent ? __ffsll((long long)urgent) - 1 : (normal ? __ffsll((long long)normal) - 1 : -1);
             if (cand >= 0) row_load(p.mt + (size_t)(b0 + cand) * MT_STRIDE, lane, rr);
-        }
+        };
+        if (CS_LV_REFRESH_EARLY) request_row();
         if (stepping) kinematics_v<N>(p, T, act, e);
+        if (!CS_LV_REFRESH_EARLY) request_row();
         LANE_STAMP(2);
         // ---- the agents' floats (get_obs / get_state)
         float fx[N], fy[N];

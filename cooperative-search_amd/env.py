@@ -394,7 +394,8 @@ class BatchedFlightEnv:
         if eps_trace is not None and eps_env is None:
             raise ValueError("rollout_policy: eps_trace needs eps_env")
         for name, tns, numel in (("eps_env", eps_env, B), ("eps_trace", eps_trace, T * B)):
-            if tns is not None and (tns.dtype != torch.float64 or tns.numel() != numel or not tns.is_contiguous() or tns.device != dev):
+            if tns is not None and (tns.dtype != torch.float64 or tns.numel() != numel or not tns.is_contiguous() or not tns.is_cuda
+                                    or (tns.device.index or 0) != (dev.index or 0)):
                 raise ValueError(f"rollout_policy: {name} must be a contiguous float64 device tensor of {numel} elements")
         sched_t = (sel_eps, eps_env, float(anneal), float(min_epsilon), bool(per_step), eps_trace)
         if self._ops is None:

@@ -174,32 +174,57 @@ def test_c_example_compiles_and_links_against_the_abi(tmp_path, example):
 
 
 def test_policy_pack_layout_host_only():
-    """cs_policy_pack is pure host code: fragment (column tile nt, k-step kk) holds W[16nt + (l & 15)][4kk + (l >> 4)]
-    for lane l (the B operand of one 16x16x4 MFMA), zero padded; biases follow."""
+    """cs_policy_pack is pure host code.  Split-fp16 layout (csrc/policy_dev.h): every weight w travels as hi = fp16(w) (0 below
+    fp16's normal range) and lo = fp16((w - hi) * 2048); fragment (column tile nt, k-step ks of 32) is the hi plane then the lo
+    plane, each [64 lanes][8 halves] with lane l, j holding W[16 nt + (l & 15)][32 ks + 8 (l >> 4) + j] -- the B operand of one
+    16x16x32 MFMA --, zero padded; fc2's second layer as four K-slices of 16 (one per wavefront, k-blocks 2 and 3 zero); fp32 biases
+    follow.  hi + lo / 2048 reproduces the weight to 22 bits."""
     import ctypes as C
     L = _lib.load()
     rng = np.random.default_rng(3)
     in_dim, nA = 10, 3
     ws = [rng.standard_normal(s).astype(np.float32) for s in
           ((64, in_dim), (64,), (192, 64), (192,), (192, 64), (192,), (64, 64), (64,), (nA, 64), (nA,))]
+    ws[2][0, :4] = [1e-6, -3e-5, 6.0e-5, 6.3e-5]   # around fp16's smallest normal number
     n = L.cs_policy_packed_floats()
     packed = np.full(n, np.nan, dtype=np.float32)
     rc = L.cs_policy_pack(*[C.c_void_p(w.ctypes.data) for w in ws], in_dim, nA, C.c_void_p(packed.ctypes.data))
-    assert rc == 0 and not np.isnan(packed).any()
+    assert rc == 0
+    halves = packed.view(np.float16)
     lanes = np.arange(64)
 
-    def frag(off, nt, kk, ksteps):
-        return packed[off + (nt * ksteps + kk) * 64: off + (nt * ksteps + kk) * 64 + 64]
+    def split(w):
+        hi = np.where(np.abs(w) < np.float32(6.2e-5), np.float16(0), w.astype(np.float16))
+        lo = ((w - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+        return hi, lo
 
-    off = 0
-    for w, tiles, ksteps in ((ws[0], 4, 8), (ws[2], 12, 16), (ws[4], 12, 16), (ws[6], 4, 16), (ws[8], 1, 16)):
-        for nt in range(tiles):
-            for kk in range(ksteps):
-                rows, ks = 16 * nt + (lanes & 15), 4 * kk + (lanes >> 4)
-                want = np.where((rows < w.shape[0]) & (ks < w.shape[1]),
-                                w[np.minimum(rows, w.shape[0] - 1), np.minimum(ks, w.shape[1] - 1)], 0.0)
-                assert np.array_equal(frag(off, nt, kk, ksteps), want.astype(np.float32))
-        off += tiles * ksteps * 64
+    def want_frag(w, nt, k0, kblocks):
+        rows = 16 * nt + (lanes & 15)[:, None]
+        ks = k0 + 8 * (lanes >> 4)[:, None] + np.arange(8)[None, :]
+        ok = (rows < w.shape[0]) & (ks < w.shape[1]) & ((lanes >> 4)[:, None] < kblocks)
+        v = np.where(ok, w[np.minimum(rows, w.shape[0] - 1), np.minimum(ks, w.shape[1] - 1)], np.float32(0)).astype(np.float32)
+        return split(v)
+
+    off = 0   # in dwords
+    frags = ([(ws[0], nt, 0, 4) for nt in range(4)] +
+             [(ws[2], nt, 32 * ks, 4) for nt in range(12) for ks in range(2)] +
+             [(ws[4], nt, 32 * ks, 4) for nt in range(12) for ks in range(2)] +
+             [(ws[6], nt, 32 * ks, 4) for nt in range(4) for ks in range(2)] +
+             [(ws[8], 0, 16 * wv, 2) for wv in range(4)])
+    for w, nt, k0, kb in frags:
+        hi, lo = want_frag(w, nt, k0, kb)
+        got_hi = halves[2 * off: 2 * off + 512].reshape(64, 8)
+        got_lo = halves[2 * off + 512: 2 * off + 1024].reshape(64, 8)
+        assert np.array_equal(got_hi.view(np.uint16), hi.view(np.uint16)) and np.array_equal(got_lo.view(np.uint16), lo.view(np.uint16))
+        back = got_hi.astype(np.float64) + got_lo.astype(np.float64) / 2048.0
+        ref = want_frag(w, nt, k0, kb)
+        full = ref[0].astype(np.float64) + ref[1].astype(np.float64) / 2048.0
+        assert np.array_equal(back, full)
+        off += 512
+    # the split keeps 22 bits of every weight (11 bits, i.e. an absolute error below 3.1e-8, of one below fp16's normal range)
+    hi, lo = split(ws[2])
+    err = np.abs(hi.astype(np.float64) + lo.astype(np.float64) / 2048.0 - ws[2].astype(np.float64))
+    assert (err <= np.maximum(np.abs(ws[2]) * 2.0 ** -21, 3.1e-8)).all()
     for b, width in ((ws[1], 64), (ws[3], 192), (ws[5], 192), (ws[7], 64), (ws[9], 16)):
         assert np.array_equal(packed[off:off + len(b)], b) and not packed[off + len(b):off + width].any()
         off += width

@@ -128,10 +128,17 @@ def test_caller_side_ops_agree_with_ctypes_and_check_their_tensors(monkeypatch):
     ops = _lib.torch_ops()
     with pytest.raises(RuntimeError, match="hidden"):
         ops.policy_forward(ag_t.packed, env_t.get_obs(), 4, 0, ag_t.actions, None, n, ag_t.hidden[:-1].contiguous(), None, ag_t.actions,
-                           B * n, n, 3, 0.0, 0, 0, 0, 0)
+                           B * n, n, 3, 0.0, None, 0, 0, 0, 0)
     with pytest.raises(RuntimeError, match="actions"):
         ops.policy_forward(ag_t.packed, env_t.get_obs(), 4, 0, ag_t.actions, None, n, ag_t.hidden, None, ag_t.actions.int(),
-                           B * n, n, 3, 0.0, 0, 0, 0, 0)
+                           B * n, n, 3, 0.0, None, 0, 0, 0, 0)
+    with pytest.raises(RuntimeError, match="eps_env must be"):   # the per-env exploration schedule: float64 [B]
+        ops.policy_forward(ag_t.packed, env_t.get_obs(), 4, 0, ag_t.actions, None, n, ag_t.hidden, None, ag_t.actions,
+                           B * n, n, 3, 0.0, torch.zeros(B, device="cuda"), 0, 0, 0, 0)
+    with pytest.raises(RuntimeError, match="eps_trace needs eps_env"):
+        ops.rollout_policy(env_t._cfg_t, env_t._blob, ag_t.packed, ag_t.hidden, ag_t.actions, T, 0, 0.0, None, 0.0, 0.0, True,
+                           torch.zeros(T, B, dtype=torch.float64, device="cuda"), 0, 0, 0, 0, out_t["actions"], out_t["reward"],
+                           out_t["terminated"].view(torch.uint8), out_t["win"].view(torch.uint8), None, None)
     with pytest.raises(RuntimeError, match="11 destination"):
         ops.store_episodes(out_t["obs"], out_t["state"], out_t["actions"][:-1].contiguous(), out_t["reward"][:-1].contiguous(),
                            out_t["terminated"][:-1].contiguous().view(torch.uint8), None, 3, [])
@@ -162,12 +169,12 @@ def test_flight_closed_loop_call_agrees_between_bindings(monkeypatch, emit):
     assert torch.equal(ag_t.hidden, ag_c.hidden) and torch.equal(env_t.raw()["prob"], env_c.raw()["prob"])
     assert torch.equal(env_t.get_obs(), env_c.get_obs())
     ops = _lib.torch_ops()
-    with pytest.raises(RuntimeError, match="scratch"):
+    with pytest.raises(RuntimeError, match="scratch must"):
         ops.rollout_policy_flight(env_t._cfg_t, env_t._blob, ag_t.packed, *ag_t.conv_w, ag_t.hidden, ag_t.actions,
-                                  torch.empty(B, 16, device="cuda"), T, 0, 0.0, 0, 0, 0, 0, out_t["actions"], out_t["reward"],
+                                  torch.empty(B, 16, device="cuda"), T, 0, 0.0, None, 0.0, 0.0, False, None, 0, 0, 0, 0, out_t["actions"], out_t["reward"],
                                   out_t["terminated"].view(torch.uint8), out_t["win"].view(torch.uint8), None, None)
     easy = cs.BatchedFlightEnv(cs.make_env_args("flight_easy", n_agents=n), batch=B)
     with pytest.raises(RuntimeError, match="flight only"):
         ops.rollout_policy_flight(easy._cfg_t, easy._blob, ag_t.packed, *ag_t.conv_w, ag_t.hidden, ag_t.actions,
-                                  torch.empty(B, 16 + 4 * n, device="cuda"), T, 0, 0.0, 0, 0, 0, 0, out_t["actions"], out_t["reward"],
+                                  torch.empty(B, 16 + 4 * n, device="cuda"), T, 0, 0.0, None, 0.0, 0.0, False, None, 0, 0, 0, 0, out_t["actions"], out_t["reward"],
                                   out_t["terminated"].view(torch.uint8), out_t["win"].view(torch.uint8), None, None)

@@ -644,5 +644,5 @@ def test_evaluation_ignores_the_schedule():
     ep1, *_ = col.generate_episodes(agents=agents, evaluate=True)
     assert (sched.values == 1.0).all()
     env2 = cs.BatchedFlightEnv(a, batch=32)
-    ep2, *_ = cs.EpisodeCollector(env2).generate_episodes(agents=FusedAgents(a, 32, seed=5), evaluate=True)
+    ep2, *_ = cs.EpisodeCollector(env2).generate_episodes(agents=FusedAgents(a, 32, net=agents.net, seed=5), evaluate=True)
     assert torch.equal(ep1["u"], ep2["u"])
