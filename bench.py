@@ -208,6 +208,26 @@ def physical_cores():
     return max(1, len(cores)), max(1, round(len(cpus) / max(1, len(cores))))
 
 
+STEADY_SPAN = 1.25   # p90 / p10 of the per-region rates below which a thread count counts as a repeatable baseline
+
+
+def cpu_quota():
+    """CPUs' worth of time the container's cgroup grants (cpu.max of cgroup v2, cfs_quota_us / cfs_period_us of v1), or None
+    when unlimited / unreadable.  A gpurun box shows 256 logical CPUs and a quota of 16: a team of more threads than that runs
+    until the quota of the 100 ms period is spent and is then stopped for the rest of it -- regions 4x slower than the median."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        quota = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if quota <= 0 else quota / period
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(env_name, n, batch, budget_s=10.0):
     """The CPU baseline in a CHILD process with a pinned OpenMP team: OMP_PROC_BIND=close and OMP_PLACES=cores have to be in
     the environment before libgomp initialises, and the parent has long loaded its OpenMP runtimes (torch's, numpy's) and
@@ -215,7 +235,7 @@ def cpu_baseline(env_name, n, batch, budget_s=10.0):
     Unpinned, the same measurement was bimodal (p10 / p90 of the per-region rates 8x apart: threads migrating between
     cores and SMT siblings in the middle of a region)."""
     env = dict(os.environ)
-    env.update({"OMP_PROC_BIND": "close", "OMP_PLACES": "cores", "OMP_DYNAMIC": "false", "OMP_WAIT_POLICY": "active"})
+    env.update({"OMP_PROC_BIND": "close", "OMP_PLACES": "cores", "OMP_DYNAMIC": "false"})
     env.pop("OMP_NUM_THREADS", None)
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", f"{env_name},{n},{batch},{budget_s}"]
     out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
@@ -230,14 +250,16 @@ def cpu_baseline_inproc(env_name, n, batch, budget_s=10.0):
     bounded sample of the same workload: same batch, auto-reset, obs+state emission, x*x squares (its fast mode).
     flight_easy: orc_batch_rollout_rep -- ONE OpenMP region per 400 steps (the 100-step action table walked four times),
     env-major, so the fork/join cost is paid once per 400 steps and an env stays in its core's cache.  The team is pinned
-    (see cpu_baseline): one thread per PHYSICAL core at most -- SMT siblings are never used -- and thread counts from 1 to
-    the number of physical cores are calibrated first (median of three regions each); the two best share the time budget and
-    `value` is the MEDIAN per-region rate of the better one (`cores` = that thread count); the others are listed in
-    `thread_scaling_env_steps_per_s`."""
+    (see cpu_baseline): one thread per PHYSICAL core at most -- SMT siblings are never used -- and never more threads than the
+    cgroup's CPU quota (cpu_quota); thread counts from 1 to that limit are calibrated first (median of three regions each); the three best share the time budget
+    and `value` is the MEDIAN per-region rate of the fastest one whose regions span less than STEADY_SPAN between p10 and p90
+    (`cores` = that thread count); every measured point is listed with its p10 / median / p90.  The envs of a region are handed
+    out dynamically, four at a time, so one descheduled thread costs its current chunk and not the whole region."""
     import numpy as np
     from oracle import oracle as orc
     n_cores, smt = physical_cores()
-    max_threads = max(1, min(orc.OracleBatch.max_threads(), n_cores))
+    quota = cpu_quota()
+    max_threads = max(1, min(orc.OracleBatch.max_threads(), n_cores, int(quota) if quota and quota >= 1 else n_cores))
     flight = env_name == "flight"
     B = batch if not flight else min(batch, 256)
     T, R = (100, 4) if not flight else (10, 1)
@@ -246,9 +268,10 @@ def cpu_baseline_inproc(env_name, n, batch, budget_s=10.0):
     orc.set_exact_pow(False)
     try:
         ob = orc.OracleBatch(cfg, B, seeds)
-        ob.reset(init=True, threads=max_threads)
+        warm = min(max_threads, 16)   # warm-up on a small team: the full one would leave its idle threads behind in the pool
+        ob.reset(init=True, threads=warm)
         acts = np.random.RandomState(1).randint(0, 3, size=(T, B, n)).astype(np.int32)
-        out = ob.rollout(acts, auto_reset=True, freeze_done=False, threads=max_threads)   # warm-up + buffers
+        out = ob.rollout(acts, auto_reset=True, freeze_done=False, threads=warm)   # warm-up + buffers
 
         def regions(th, reps, rep=R):
             """`reps` OpenMP regions of T * rep steps on `th` threads, each timed on its own: env-steps/s per region."""
@@ -261,36 +284,46 @@ def cpu_baseline_inproc(env_name, n, batch, budget_s=10.0):
 
         cands = sorted({1, 2, 4, 8, 16, 32, 64, 128, max_threads // 2, max_threads} & set(range(1, max_threads + 1)))
         scaling = {}
-        for th in cands:   # calibration: the MEDIAN of three regions per thread count (single regions are noisy at high
-            #                thread counts: SMT siblings, 4096 envs over 128 threads); the slow single thread runs quarter regions
+        for th in cands:   # calibration: the MEDIAN of three regions per thread count; the slow single thread runs quarter regions
             scaling[str(th)] = statistics.median(regions(th, 3, rep=1 if th == 1 else R))
-        # the two best calibration points share the budget; the reported value is the MEDIAN region rate of the better one
-        # (repeatable to a few percent, where a mean over one noisy burst was not)
-        top = sorted(cands, key=lambda th: scaling[str(th)], reverse=True)[:2]
-        value, dt, best, reps, spread = 0.0, 0.0, top[0], 0, None
+        # the three best calibration points share the budget.  `value` is the MEDIAN region rate of the fastest point whose
+        # regions hold together (p90 / p10 < 1.25); a faster point that does not is listed under `measured_points` with its
+        # spread and is not the baseline: GPU boxes are slices of a shared 8-GPU host, and above ~16-32 threads the regions
+        # of the same pinned team were 4x apart while the per-thread rate up to 16 threads repeats to 2 % box after box
+        top = sorted(cands, key=lambda th: scaling[str(th)], reverse=True)[:3]
+        points = {}
         for th in top:
             per = B * T * R / scaling[str(th)]
-            n_rep = int(max(5, min(5000, 0.5 * budget_s / max(per, 1e-6))))
+            n_rep = int(max(10, min(5000, budget_s / len(top) / max(per, 1e-6))))
             t0 = time.perf_counter()
             rates = regions(th, n_rep)
             d = time.perf_counter() - t0
+            q = statistics.quantiles(rates, n=10)
             v = statistics.median(rates)
             scaling[str(th)] = v
-            if v > value:
-                q = statistics.quantiles(rates, n=10) if len(rates) >= 10 else [min(rates)] * 9
-                value, dt, best, reps, spread = v, d, th, n_rep, [q[0], v, q[-1]]
+            points[th] = {"p10": q[0], "median": v, "p90": q[-1], "span": q[-1] / q[0] if q[0] > 0 else float("inf"),
+                          "regions": n_rep, "wall_s": d}
+        steady = [th for th in top if points[th]["span"] < STEADY_SPAN]
+        best = max(steady, key=lambda th: points[th]["median"]) if steady else min(top, key=lambda th: points[th]["span"])
     finally:
         orc.set_exact_pow(True)
-    single = scaling["1"]
+    pt = points[best]
+    value, single = pt["median"], scaling["1"]
+    faster = {str(th): [points[th]["p10"], points[th]["median"], points[th]["p90"]] for th in top
+              if th != best and points[th]["median"] > value}
     return {"value": value, "unit": "env-steps/s", "cores": best, "kind": "port",
             "sample": f"C oracle (oracle/flight_oracle.c orc_batch_rollout_rep: one OpenMP region per {T * R} steps, "
-                      f"env-major), {B} envs x {T * R * reps} steps on {best} threads (best of {cands}), auto-reset, "
-                      f"obs+state emitted, {dt:.1f} s wall on {cpu_model()} ({os.cpu_count()} logical CPUs, {n_cores} physical cores)",
-            "region_rate_p10_median_p90": spread, "statistic": "median over the timed regions",
-            "p90_over_p10": (spread[2] / spread[0]) if spread and spread[0] > 0 else None,
+                      f"env-major, dynamic schedule), {B} envs x {T * R * pt['regions']} steps on {best} threads (fastest of "
+                      f"{top} whose regions span < {STEADY_SPAN}x; calibrated over {cands}), auto-reset, "
+                      f"obs+state emitted, {pt['wall_s']:.1f} s wall on {cpu_model()} ({os.cpu_count()} logical CPUs, {n_cores} physical cores)",
+            "region_rate_p10_median_p90": [pt["p10"], pt["median"], pt["p90"]], "statistic": "median over the timed regions",
+            "p90_over_p10": pt["span"], "steady": bool(steady),
+            "measured_points": {str(th): [points[th]["p10"], points[th]["median"], points[th]["p90"]] for th in top},
+            "faster_but_unsteady": faster or None,
             "pinning": {"OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES"),
-                        "physical_cores": n_cores, "threads_per_core": smt,
-                        "note": "own process, one thread per physical core at most (no SMT siblings)"},
+                        "physical_cores": n_cores, "threads_per_core": smt, "cgroup_cpu_quota": quota,
+                        "note": "own process, one thread per physical core at most (no SMT siblings), never more threads than "
+                                "the cgroup's CPU quota"},
             "single_thread_value": single, "speedup_vs_single_thread": value / single,
             "thread_scaling_env_steps_per_s": scaling}
 
@@ -311,31 +344,72 @@ def gpu_local_cpus(local_rank, sysfs="/sys"):
     """(numa node, CPUs) next to the GPU this rank will use, from sysfs alone -- NO GPU call: the binding has to be in place
     before the HIP runtime starts its helper threads.  GPUs = the KFD topology nodes this process may read that have SIMDs,
     in node order (the order HIP enumerates them in); the node's drm_render_minor leads to the PCI device's local_cpulist.
-    None when sysfs does not tell (no KFD, fewer GPUs than local_rank, a device filter in the environment)."""
-    if any(os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL")):
-        return None   # the runtime's numbering is no longer the topology's
+    None when sysfs does not tell (no KFD, fewer GPUs than local_rank, a device filter that is not a list of indices)."""
     base = os.path.join(sysfs, "class/kfd/kfd/topology/nodes")
     try:
         nodes = sorted((int(d) for d in os.listdir(base) if d.isdigit()))
     except OSError:
         return None
-    minors = []
+    gpus, cpu_nodes = [], set()
     for nd in nodes:
         try:
             props = dict(ln.split()[:2] for ln in open(os.path.join(base, str(nd), "properties")) if len(ln.split()) >= 2)
         except OSError:
             continue   # another container's GPU: not ours to read, not ours to enumerate
         if int(props.get("simd_count", "0")) > 0:
-            minors.append(int(props.get("drm_render_minor", "-1")))
-    if local_rank >= len(minors) or minors[local_rank] < 0:
+            gpus.append((nd, props))
+        elif int(props.get("cpu_cores_count", "0")) > 0:
+            cpu_nodes.add(nd)
+    # device filters in the environment renumber what the runtime shows: ROCR_VISIBLE_DEVICES picks from the topology's GPUs,
+    # HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES (and GPU_DEVICE_ORDINAL) from what is left.  (A gpurun box sets the first two to "0".)
+    order = list(range(len(gpus)))
+    for names in (("ROCR_VISIBLE_DEVICES",), ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"), ("GPU_DEVICE_ORDINAL",)):
+        val = next((os.environ[k] for k in names if os.environ.get(k)), None)
+        if val is None:
+            continue
+        try:
+            pick = [int(x) for x in val.split(",") if x.strip() != ""]
+            order = [order[i] for i in pick]
+        except (ValueError, IndexError):
+            return None   # UUIDs or indices past what this process may read: no guess
+    if local_rank >= len(order):
         return None
-    dev = os.path.join(sysfs, f"class/drm/renderD{minors[local_rank]}/device")
-    try:
-        cpus = parse_cpulist(open(os.path.join(dev, "local_cpulist")).read())
-        node = int(open(os.path.join(dev, "numa_node")).read().strip() or -1)
-    except (OSError, ValueError):
-        return None
-    return (node, cpus) if cpus else None
+    nd, props = gpus[order[local_rank]]
+
+    def read_dev(dev):
+        try:
+            cpus = parse_cpulist(open(os.path.join(dev, "local_cpulist")).read())
+            node = int(open(os.path.join(dev, "numa_node")).read().strip() or -1)
+        except (OSError, ValueError):
+            return None
+        return (node, cpus) if cpus else None
+
+    # 1. the render node's PCI device; 2. the same device by its PCI address (a container's /sys/class/drm may not list the
+    #    minor it was handed); 3. the KFD io_link from the GPU to a CPU node, whose number is the NUMA node's
+    minor = int(props.get("drm_render_minor", "-1"))
+    found = read_dev(os.path.join(sysfs, f"class/drm/renderD{minor}/device")) if minor >= 0 else None
+    if not found and "location_id" in props:
+        loc, dom = int(props["location_id"]), int(props.get("domain", "0"))
+        bdf = f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7:x}"
+        found = read_dev(os.path.join(sysfs, "bus/pci/devices", bdf))
+    if not found:
+        links = os.path.join(base, str(nd), "io_links")
+        try:
+            names = sorted(os.listdir(links))
+        except OSError:
+            names = []
+        for ln in names:
+            try:
+                lp = dict(x.split()[:2] for x in open(os.path.join(links, ln, "properties")) if len(x.split()) >= 2)
+                to = int(lp.get("node_to", "-1"))
+                if to in cpu_nodes:
+                    cpus = parse_cpulist(open(os.path.join(sysfs, f"devices/system/node/node{to}/cpulist")).read())
+                    if cpus:
+                        found = (to, cpus)
+                        break
+            except (OSError, ValueError):
+                continue
+    return found
 
 
 def bind_rank_to_gpu_node(local_rank, sysfs="/sys"):

@@ -1873,8 +1873,15 @@ struct PolicyIO {
     int select;              // CS_SELECT_*
 };
 
+#ifndef CS_RP_WAVES
+#define CS_RP_WAVES 1   /* wavefronts per SIMD the fused closed-loop kernel is compiled for at N <= 3 (2: 256 registers) */
+#endif
+#ifndef CS_RP_TAPE
+#define CS_RP_TAPE 1    /* teams of up to 3 read their draws from the hit tape (10 KB of row buffers per workgroup) */
+#endif
 template <int N>
-__global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io, PolicyIO pio) {
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((N <= 3 ? CS_RP_WAVES : 1), (N <= 3 ? CS_RP_WAVES : 1))))
+void k_rollout_policy(DevParams p, StepIO io, PolicyIO pio) {
     __shared__ double T[TRIG_ROWS * TRIG_COLS];
     __shared__ WaveTile tiles[BLOCK / 64];
     __shared__ int s_act[16 * N];          // last / chosen action per row (row = env_in_block * N + agent)
@@ -1883,14 +1890,19 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io
     extern __shared__ __attribute__((aligned(16))) float pol_lds[];
     constexpr int ROWS = 16 * N, NA = 3;   // the env has three actions (flight_env_easy.py:32)
 #if CS_POLICY_F16
-    // split-fp16 activations (policy_dev.h): a | b | hs as (hi, lo) plane pairs of [ROWS][HST] halves, then s_h [ROWS][LDW] fp32
-    // (the GRU blend needs the previous hidden state itself); the partial q of fc2 aliases the a planes
-    _Float16 *a_hi = reinterpret_cast<_Float16 *>(pol_lds), *a_lo = a_hi + ROWS * HST;
-    _Float16 *b_hi = a_lo + ROWS * HST, *b_lo = b_hi + ROWS * HST;
-    _Float16 *hs_hi = b_lo + ROWS * HST, *hs_lo = hs_hi + ROWS * HST;
-    float *s_h = reinterpret_cast<float *>(hs_lo + ROWS * HST);
-    float *s_q = pol_lds;                  // [4][ROWS * 17] floats = ROWS * 272 B <= the a planes' ROWS * 288 B
-    static_assert(4 * 17 * 4 <= 2 * HST * 2, "s_q must fit the a planes");
+    // split-fp16 activations (policy_dev.h), all as (hi, lo) plane pairs of halves:
+    //   x  [ROWS][HXS]   the network input of the NEXT forward, kept current in place: the env lanes write the four observation
+    //                    columns after every step, the selecting lanes the one-hot of the chosen action; the agent-id columns and
+    //                    the zero padding never change (no assembly phase, no barrier for it)
+    //   b  [ROWS][HST]   h1, then f (scratch of one forward)
+    //   hs [2][...]      the hidden state as A-operand planes, PING-PONG by step parity: the GRU of step s reads hs[s & 1] (every
+    //                    wavefront reads all rows) and writes hs[(s + 1) & 1] -- no barrier between its reads and its writes; fc2 reads
+    //                    h' from there too, and the q values of step s take the space of hs[s & 1] once the GRU has consumed it
+    //   s_h [ROWS][LDW]  the hidden state in fp32 (the GRU blend): element (row, col) is read and written by ONE thread only
+    _Float16 *x_hi = reinterpret_cast<_Float16 *>(pol_lds), *x_lo = x_hi + ROWS * HXS;
+    _Float16 *b_hi = x_lo + ROWS * HXS, *b_lo = b_hi + ROWS * HST;
+    _Float16 *hs_base = b_lo + ROWS * HST;                 // [2][2 planes][ROWS][HST]
+    float *s_h = reinterpret_cast<float *>(hs_base + 4 * ROWS * HST);
 #else
     // s_a | s_b | s_h, each [16N][LDW]; the partial q of fc2 aliases s_a
     float *s_a = pol_lds, *s_b = pol_lds + ROWS * LDW, *s_h = pol_lds + 2 * ROWS * LDW;
@@ -1930,7 +1942,9 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io
     BFrag b2[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) b2[ks] = load_bfrag(pio.w, HOFF_W2, w * 2 + ks, ulane);
-    const BFrag b3 = load_bfrag(pio.w, HOFF_W3, w, ulane);
+    BFrag b3[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) b3[ks] = load_bfrag(pio.w, HOFF_W3, ks, ulane);
     constexpr int PO_B1 = HOFF_B1, PO_BIH = HOFF_BIH, PO_BHH = HOFF_BHH, PO_B2 = HOFF_B2, PO_B3 = HOFF_B3;
 #else
     float b1[4], bg[6][16], b2[16], b3f[4];
@@ -1967,116 +1981,168 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io
         const float4 hv = *reinterpret_cast<const float4 *>(pio.hidden + grow * H + 4 * kcol);
         *reinterpret_cast<float4 *>(s_h + r * LDW + 4 * kcol) = hv;
 #if CS_POLICY_F16
-        split_store(hs_hi, hs_lo, r * HST + 4 * kcol + 0, hv.x);
-        split_store(hs_hi, hs_lo, r * HST + 4 * kcol + 1, hv.y);
-        split_store(hs_hi, hs_lo, r * HST + 4 * kcol + 2, hv.z);
-        split_store(hs_hi, hs_lo, r * HST + 4 * kcol + 3, hv.w);
+        split_store(hs_base, hs_base + ROWS * HST, r * HST + 4 * kcol + 0, hv.x);   // hs[0]: what step 0 reads
+        split_store(hs_base, hs_base + ROWS * HST, r * HST + 4 * kcol + 1, hv.y);
+        split_store(hs_base, hs_base + ROWS * HST, r * HST + 4 * kcol + 2, hv.z);
+        split_store(hs_base, hs_base + ROWS * HST, r * HST + 4 * kcol + 3, hv.w);
 #endif
     }
     for (int r = threadIdx.x; r < ROWS; r += BLOCK) s_act[r] = r < rows_valid ? (int)pio.last[(size_t)b0 * N + r] : -1;
     // the current observation of every env goes into its wavefront's tile (what get_obs would return now)
     if (live) env_trig<N>(T, e);
     emit_deposit<N>(p, tile, t, grp, live, e, 0, false);
+    // Draws: teams of up to 3 read them from the env's hit tape like the open-loop kernels (rows topped up here, once per launch; an env
+    // that outlives its row falls back to twisting on demand inside detect_pass_tape); larger teams have no registers left for the
+    // ten tape words and twist on demand throughout.
+    constexpr bool USE_TAPE = N <= 3 && CS_RP_TAPE;
+    __shared__ unsigned rowbufs[USE_TAPE ? BLOCK / 64 : 1][USE_TAPE ? MT_N : 1];
     MtWin win = {0u, 0u};
-    if (live) win = mt_prefetch(p.mt + (size_t)b * MT_STRIDE, e.mt_pos, t);
-    unsigned no_tape[TAPE_DW];   // the closed loop twists its words on demand
-    const int in_dim = 4 + NA + N;
+    unsigned tape[TAPE_DW];
+    bool tape_ok = false;
+    if (USE_TAPE) {
+        if (live) tape_ok = tape_load(p, b, e, tape);
+        if (wave_valid) group_wave_advance<N>(p, wave_b0, nvalid, lane, io.min_ahead, rowbufs[USE_TAPE ? w : 0], e, tape, tape_ok);
+    } else if (live) {
+        win = mt_prefetch(p.mt + (size_t)b * MT_STRIDE, e.mt_pos, t);
+    }
 
-    for (int s = 0; s < io.T; s++) {
-        __syncthreads();   // tiles / s_act of the previous step are complete; s_q (= s_a) has been consumed
+    const int in_dim = 4 + NA + N;
 #if CS_POLICY_F16
-        // ---- x = obs(4) | one_hot(last action) | one_hot(agent id) per row (agent.py:41-52), zero up to column 32 (one k-step):
-        //      two columns per thread, split into (hi, lo) halves
+    // the env lane of agent t of env (w, grp) keeps row r's four observation columns of x current (tile.row is what emit_deposit left)
+    auto put_obs_columns = [&]() __attribute__((always_inline)) {
+        if (live && t < N) {
+            const int r = (4 * w + grp) * N + t;
+#pragma unroll
+            for (int k = 0; k < 4; k++) split_store(x_hi, x_lo, r * HXS + k, tile.row[grp][4 * t + k]);
+        }
+    };
+    {   // x once: agent-id one-hot, zero padding, the last action on entry; the observation columns as after every step
+        __syncthreads();   // s_act and the tiles are complete
 #pragma unroll
         for (int m = 0; m < N; m++) {
             const int r = 16 * m + srow, el = r / N, ag = r - el * N;
             float v = 0.0f;
-            if (kcol < 4) v = tiles[el >> 2].row[el & 3][4 * ag + kcol];
-            else if (kcol < 4 + NA) v = (kcol - 4 == s_act[r]) ? 1.0f : 0.0f;
-            else if (kcol < in_dim) v = (kcol - 4 - NA == ag) ? 1.0f : 0.0f;
-            split_store(a_hi, a_lo, r * HST + kcol, r < rows_valid ? v : 0.0f);
-            split_store(a_hi, a_lo, r * HST + kcol + 16, 0.0f);
+            if (kcol >= 4 && kcol < 4 + NA) v = (kcol - 4 == s_act[r]) ? 1.0f : 0.0f;
+            else if (kcol >= 4 + NA && kcol < in_dim) v = (kcol - 4 - NA == ag) ? 1.0f : 0.0f;
+            split_store(x_hi, x_lo, r * HXS + kcol, r < rows_valid ? v : 0.0f);
+            split_store(x_hi, x_lo, r * HXS + kcol + 16, 0.0f);
         }
-        __syncthreads();
+        __syncthreads();   // (the observation columns below overwrite the zeros of columns 0..3)
+        put_obs_columns();
+    }
+#endif
+    for (int s = 0; s < io.T; s++) {
+        LANE_STAMP(6);
+        __syncthreads();   // x is complete (observation after the previous step, last action); the previous s_q has been consumed
+        LANE_STAMP(7);
+#if CS_POLICY_F16
+        _Float16 *hc_hi = hs_base + (size_t)(s & 1) * 2 * ROWS * HST, *hc_lo = hc_hi + ROWS * HST;          // hidden state in
+        _Float16 *hn_hi = hs_base + (size_t)((s + 1) & 1) * 2 * ROWS * HST, *hn_lo = hn_hi + ROWS * HST;    // hidden state out
+        float *s_q = reinterpret_cast<float *>(hc_hi);   // [ROWS][17] floats (68 B per row <= a plane's 144 B), written after the GRU
 #pragma unroll
         for (int m = 0; m < N; m++) {   // h1 = relu(W1 x + b1), columns 16w..16w+15 of every row tile
             f32x4 hi = zero, lo = zero;
             h8 ah, al;
-            load_afrag(a_hi, a_lo, 16 * m, 0, lane, ah, al);
+            load_afrag<HXS>(x_hi, x_lo, 16 * m, 0, lane, ah, al);
             mfma_split(ah, al, b1, hi, lo);
 #pragma unroll
             for (int r = 0; r < 4; r++)
                 split_store(b_hi, b_lo, (16 * m + crow + r) * HST + col, fmaxf(split_sum(hi[r], lo[r]) + bias1, 0.0f));
         }
+        LANE_STAMP(8);
         __syncthreads();
-        {   // GRUCell: per row tile the six chains in k_policy_h's order
-            f32x4 hnew[N];
+        LANE_STAMP(9);
 #pragma unroll
-            for (int m = 0; m < N; m++) {
-                f32x4 hi[6], lo[6];
+        for (int m = 0; m < N; m++) {   // GRUCell: per row tile the six chains in k_policy_h's order
+            f32x4 hi[6], lo[6];
 #pragma unroll
-                for (int c = 0; c < 6; c++) hi[c] = lo[c] = zero;
+            for (int c = 0; c < 6; c++) hi[c] = lo[c] = zero;
+            // gate by gate (r, z, n), both k-steps of a gate's two chains together: the r and z chains are complete while the matrix
+            // pipe still works on n, and their sigmoids issue in its shadow (each chain's own summation order is unchanged)
+            h8 xh[2], xl[2], hh[2], hl[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                load_afrag(b_hi, b_lo, 16 * m, ks, lane, xh[ks], xl[ks]);
+                load_afrag(hc_hi, hc_lo, 16 * m, ks, lane, hh[ks], hl[ks]);
+            }
+#pragma unroll
+            for (int g = 0; g < 3; g++)
 #pragma unroll
                 for (int ks = 0; ks < 2; ks++) {
-                    h8 xh, xl, hh, hl;
-                    load_afrag(b_hi, b_lo, 16 * m, ks, lane, xh, xl);
-                    load_afrag(hs_hi, hs_lo, 16 * m, ks, lane, hh, hl);
-#pragma unroll
-                    for (int g = 0; g < 3; g++) {
-                        mfma_split(xh, xl, bg[2 * g][ks], hi[2 * g], lo[2 * g]);
-                        mfma_split(hh, hl, bg[2 * g + 1][ks], hi[2 * g + 1], lo[2 * g + 1]);
-                    }
+                    mfma_split(xh[ks], xl[ks], bg[2 * g][ks], hi[2 * g], lo[2 * g]);
+                    mfma_split(hh[ks], hl[ks], bg[2 * g + 1][ks], hi[2 * g + 1], lo[2 * g + 1]);
                 }
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const float ir = split_sum(hi[0][r], lo[0][r]), hr = split_sum(hi[1][r], lo[1][r]);
-                    const float iz = split_sum(hi[2][r], lo[2][r]), hz = split_sum(hi[3][r], lo[3][r]);
-                    const float in_ = split_sum(hi[4][r], lo[4][r]), hn_ = split_sum(hi[5][r], lo[5][r]);
-                    const float rg = sigmoidf_((ir + bir) + (hr + bhr));
-                    const float zg = sigmoidf_((iz + biz) + (hz + bhz));
-                    const float ng = tanhf_((in_ + bin) + rg * (hn_ + bhn));
-                    hnew[m][r] = (1.0f - zg) * ng + zg * s_h[(16 * m + crow + r) * LDW + col];
-                    split_store(a_hi, a_lo, (16 * m + crow + r) * HST + col, hnew[m][r]);
-                }
+            for (int r = 0; r < 4; r++) {
+                const float ir = split_sum(hi[0][r], lo[0][r]), hr = split_sum(hi[1][r], lo[1][r]);
+                const float iz = split_sum(hi[2][r], lo[2][r]), hz = split_sum(hi[3][r], lo[3][r]);
+                const float in_ = split_sum(hi[4][r], lo[4][r]), hn_ = split_sum(hi[5][r], lo[5][r]);
+                const float rg = sigmoidf_((ir + bir) + (hr + bhr));
+                const float zg = sigmoidf_((iz + biz) + (hz + bhz));
+                const float ng = tanhf_((in_ + bin) + rg * (hn_ + bhn));
+                const int o = 16 * m + crow + r;
+                const float hnew = (1.0f - zg) * ng + zg * s_h[o * LDW + col];
+                s_h[o * LDW + col] = hnew;                          // (this thread's own element)
+                split_store(hn_hi, hn_lo, o * HST + col, hnew);     // h' for fc2 and for the next step's GRU
             }
-            __syncthreads();   // every wavefront has finished reading s_h / hs
-#pragma unroll
-            for (int m = 0; m < N; m++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    s_h[(16 * m + crow + r) * LDW + col] = hnew[m][r];
-                    split_store(hs_hi, hs_lo, (16 * m + crow + r) * HST + col, hnew[m][r]);
-                }
         }
+        LANE_STAMP(10);
+        __syncthreads();
+        LANE_STAMP(11);
 #pragma unroll
         for (int m = 0; m < N; m++) {   // f = relu(W2 h' + b2)
             f32x4 hi = zero, lo = zero;
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
                 h8 ah, al;
-                load_afrag(a_hi, a_lo, 16 * m, ks, lane, ah, al);
+                load_afrag(hn_hi, hn_lo, 16 * m, ks, lane, ah, al);
                 mfma_split(ah, al, b2[ks], hi, lo);
             }
 #pragma unroll
             for (int r = 0; r < 4; r++)
                 split_store(b_hi, b_lo, (16 * m + crow + r) * HST + col, fmaxf(split_sum(hi[r], lo[r]) + bias2, 0.0f));
         }
-        __syncthreads();   // f complete; the a planes (h') are no longer needed: their space now takes the partial q
+        LANE_STAMP(12);
+        __syncthreads();   // f complete
+        LANE_STAMP(13);
+        // q = W3 f + b3 and the choice of row tile m, by wavefront m % 4 alone (as in k_policy_h: no K split, no exchange of
+        // partial sums, no barrier between the product and the selection)
 #pragma unroll
-        for (int m = 0; m < N; m++) {   // partial q over this wavefront's 16 of the 64 k (k-blocks 0, 1; the other lanes add zeros)
+        for (int m = 0; m < N; m++) {
+            if ((m & 3) != w) continue;   // wave-uniform
             f32x4 hi = zero, lo = zero;
-            h8 ah = {0, 0, 0, 0, 0, 0, 0, 0}, al = {0, 0, 0, 0, 0, 0, 0, 0};
-            if ((lane >> 4) < 2) {
-                const int idx = (16 * m + (lane & 15)) * HST + 16 * w + 8 * (lane >> 4);
-                ah = *reinterpret_cast<const h8 *>(b_hi + idx);
-                al = *reinterpret_cast<const h8 *>(b_lo + idx);
-            }
-            mfma_split(ah, al, b3, hi, lo);
 #pragma unroll
-            for (int r = 0; r < 4; r++) s_q[w * (ROWS * 17) + (16 * m + crow + r) * 17 + ccol] = split_sum(hi[r], lo[r]);
+            for (int ks = 0; ks < 2; ks++) {
+                h8 ah, al;
+                load_afrag(b_hi, b_lo, 16 * m, ks, lane, ah, al);
+                mfma_split(ah, al, b3[ks], hi, lo);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) s_q[(16 * m + crow + r) * 17 + ccol] = split_sum(hi[r], lo[r]) + s_b3[ccol];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane < 16) {   // argmax / epsilon-greedy, one lane per row
+                const int r = 16 * m + lane;
+                auto qf = [&](int a) { return s_q[r * 17 + a]; };
+                const unsigned long long grow = pio.row0 + (unsigned long long)(b0 * N + r);
+                const int er = r / N;   // the row's env within the block
+                const double eps = s_eps[er < BLOCK / G ? er : 0];
+                const int act = select_action(qf, NA, pio.select, (float)eps, pio.seed, pio.step0 + (unsigned)s, grow);
+                s_act[r] = act;
+#pragma unroll
+                for (int a = 0; a < NA; a++) split_store(x_hi, x_lo, r * HXS + 4 + a, (r < rows_valid && a == act) ? 1.0f : 0.0f);
+                if (r < rows_valid) {
+                    pio.actions[((size_t)s * p.B + b0) * N + r] = act;
+                    if (pio.trace && r == er * N) pio.trace[(size_t)s * p.B + b0 + er] = eps;
+                }
+            }
         }
-        __syncthreads();
+        LANE_STAMP(14);
+        __syncthreads();   // s_act is complete
+        LANE_STAMP(15);
 #else
+        // (fp32 matrix path: the loop-top barrier above also covers the tiles / s_act of the previous step)
         // ---- x = obs(4) | one_hot(last action) | one_hot(agent id) per row (agent.py:41-52), one column per thread
 #pragma unroll
         for (int m = 0; m < N; m++) {
@@ -2167,7 +2233,6 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io
                 for (int r = 0; r < 4; r++) s_q[w * (ROWS * 17) + (16 * m + crow + r) * 17 + ccol] = acc[m][r];
         }
         __syncthreads();
-#endif
         for (int r = threadIdx.x; r < ROWS; r += BLOCK) {   // argmax / epsilon-greedy, one thread per row
             auto qf = [&](int a) {
                 const int o = r * 17 + a;
@@ -2184,6 +2249,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io
             }
         }
         __syncthreads();
+#endif
         // ---- env.step with the chosen actions
         int act[N];
         const int el = 4 * w + grp;
@@ -2195,18 +2261,24 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_policy(DevParams p, StepIO io
                                         !(io.flags & CS_AUTO_RESET) && (io.flags & CS_FREEZE_DONE));
         if (wave_valid)
             step_once<N, 0>(p, T, io, tile, b, lane, (size_t)s * p.B + wave_b0, plan, live, act, win, s + 1 < io.T,
-                            PIPE && s > 0, (size_t)(s - 1) * p.B + wave_b0, PIPE, e, no_tape, false, false);
+                            PIPE && s > 0, (size_t)(s - 1) * p.B + wave_b0, PIPE, e, tape, USE_TAPE, tape_ok);
         if (pio.per_step && pio.eps_dev && executed && t == 0) {   // epsilon = epsilon - anneal if epsilon > min else epsilon
             const double v = s_eps[el];
             s_eps[el] = v > pio.min_eps ? v - pio.anneal : v;
         }
+#if CS_POLICY_F16
+        if (wave_valid) put_obs_columns();   // the next forward's observation columns (emit_deposit has left them in the tile)
+#endif
     }
     if (PIPE && wave_valid) {  // rows of the last step
         FlushRegs<N> fr;
         emit_flush_load<N>(tile, plan, fr);
         emit_flush_store<N>(p, io, plan, fr, (size_t)(io.T - 1) * p.B + wave_b0);
     }
-    if (live) env_store<N>(p, b, t, e, false);
+    if (live) {
+        env_store<N>(p, b, t, e, false);
+        if (USE_TAPE && tape_ok) group_tape_store<N>(p, b, t, e, tape);
+    }
     __syncthreads();
     if (pio.eps_dev && threadIdx.x < BLOCK / G && b0 + (int)threadIdx.x < p.B) pio.eps_dev[b0 + threadIdx.x] = s_eps[threadIdx.x];
 #pragma unroll
@@ -5022,19 +5094,19 @@ inline size_t lane_smem(const cs_config *c) {
 template <int N>
 void launch_lanev(const cs_config *cfg, const DevParams &p, StepIO io, hipStream_t s) {
     const size_t W = 4 * (size_t)cfg->n_agents + 3 * (size_t)cfg->n_targets;
-    const size_t smem = LV_HEAD_BYTES + (BLOCK / 64) * lv_wave_bytes((int)W);
+    const size_t smem = LV_HEAD_BYTES + (LV_BLOCK / 64) * lv_wave_bytes((int)W);
     const bool aligned = io.state && io.obs && (reinterpret_cast<size_t>(io.state) & 15) == 0 &&
                          (reinterpret_cast<size_t>(io.obs) & 15) == 0 && ((size_t)p.B * W) % 4 == 0;
     const int full = aligned ? (p.B / 64) * 64 : 0;
     if (full > 0) {
         io.env0 = 0;
         io.env_n = full;
-        hipLaunchKernelGGL((k_rollout_lanev<N, true>), dim3((unsigned)((full + BLOCK - 1) / BLOCK)), dim3(BLOCK), smem, s, p, io);
+        hipLaunchKernelGGL((k_rollout_lanev<N, true>), dim3((unsigned)((full + LV_BLOCK - 1) / LV_BLOCK)), dim3(LV_BLOCK), smem, s, p, io);
     }
     if (p.B - full > 0) {
         io.env0 = full;
         io.env_n = p.B - full;
-        hipLaunchKernelGGL((k_rollout_lanev<N, false>), dim3((unsigned)((p.B - full + BLOCK - 1) / BLOCK)), dim3(BLOCK), smem, s, p, io);
+        hipLaunchKernelGGL((k_rollout_lanev<N, false>), dim3((unsigned)((p.B - full + LV_BLOCK - 1) / LV_BLOCK)), dim3(LV_BLOCK), smem, s, p, io);
     }
 }
 // Which lane-per-env kernel: k_rollout_lanev for teams of up to 5 (its in-loop MT19937 refresh tops up one env per wavefront
@@ -5354,10 +5426,11 @@ int cs_rollout_policy(const cs_config *cfg, void *state_dev, const float *packed
     if (!packed_dev || !hidden_dev || !last_dev || !actions_dev || !reward_dev || !terminated_dev || !win_dev)
         return fail(CS_E_ARG, "null rollout buffer");
     StepIO io{nullptr, reward_dev, terminated_dev, win_dev, obs_dev, state_out_dev, flags, T};
+    io.min_ahead = prepass_min_ahead(cfg, T);   // rows with fewer twisted words are topped up in the kernel's prologue
     PolicyIO pio{packed_dev, hidden_dev, last_dev, actions_dev, eps->epsilon, eps->anneal, eps->min_epsilon, eps->per_step,
                  eps->eps_dev, eps->trace_dev, seed, step0, row0, select};
 #if CS_POLICY_F16
-#define CS_RP_LDS(NN) ((size_t)16 * (NN) * (6 * HST * 2 + LDW * 4))   /* six split planes of halves + s_h fp32, per row */
+#define CS_RP_LDS(NN) ((size_t)16 * (NN) * (2 * HXS * 2 + 6 * HST * 2 + LDW * 4))   /* x, b, hs[2] plane pairs of halves + s_h fp32, per row */
 #else
 #define CS_RP_LDS(NN) ((size_t)3 * 16 * (NN) * LDW * 4)
 #endif

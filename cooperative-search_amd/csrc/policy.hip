@@ -248,7 +248,9 @@ __global__ __launch_bounds__(PBLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     BFrag b2[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) b2[ks] = load_bfrag(p.w, HOFF_W2, w * 2 + ks, ulane);
-    const BFrag b3 = load_bfrag(p.w, HOFF_W3, w, ulane);
+    BFrag b3[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) b3[ks] = load_bfrag(p.w, HOFF_W3, ks, ulane);
     if (threadIdx.x < 16) s_b3[threadIdx.x] = p.w[HOFF_B3 + threadIdx.x];  // visible after the first barrier
     const int col = 16 * w + ccol;
     const float bias1 = p.w[HOFF_B1 + col], bias2 = p.w[HOFF_B2 + col];
@@ -362,35 +364,34 @@ __global__ __launch_bounds__(PBLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         __syncthreads();
         POL_STAMP(4);
 
-        {   // q = W3 f + b3: the 64-long reduction is split four ways over the wavefronts (columns 16w..16w+15 of f: k-blocks 0, 1 of
-            // this wavefront's fragment; the lanes of k-blocks 2, 3 contribute zeros)
+        // q = W3 f + b3 and the choice, by ONE wavefront (no K split, no exchange of partial sums, no barrier: the other wavefronts go
+        // on to the next tile's staging, which touches neither s_b nor s_q; wavefront 0 joins the next barrier when it is done)
+        if (w == 0) {
             f32x4 hi = zero, lo = zero;
-            h8 ah = {0, 0, 0, 0, 0, 0, 0, 0}, al = {0, 0, 0, 0, 0, 0, 0, 0};
-            if ((lane >> 4) < 2) {
-                const int idx = (lane & 15) * HST + 16 * w + 8 * (lane >> 4);
-                ah = *reinterpret_cast<const h8 *>(s_b[0] + idx);
-                al = *reinterpret_cast<const h8 *>(s_b[1] + idx);
-            }
-            mfma_split(ah, al, b3, hi, lo);
 #pragma unroll
-            for (int r = 0; r < 4; r++) s_q[w][(crow + r) * 17 + ccol] = split_sum(hi[r], lo[r]);
-        }
-        __syncthreads();
-        POL_STAMP(5);
-
-        // final sum, argmax and epsilon-greedy: one thread per row (wavefront 0 only; the others run ahead to the
-        // next tile's staging)
-        if (threadIdx.x < 16) {
-            const int row = row0 + threadIdx.x;
-            auto qf = [&](int a) {
-                const int o = threadIdx.x * 17 + a;
-                return ((s_q[0][o] + s_q[1][o]) + (s_q[2][o] + s_q[3][o])) + s_b3[a];
-            };
-            if (p.q && row < p.rows)
-                for (int a = 0; a < p.n_actions; a++) p.q[(size_t)row * p.n_actions + a] = qf(a);
-            const float eps = p.eps_env ? (float)p.eps_env[(row < p.rows ? row : p.rows - 1) / p.n_agents] : p.epsilon;
-            const int act = select_action(qf, p.n_actions, p.select, eps, p.seed, p.step, p.row0 + (unsigned long long)row);
-            if (row < p.rows) p.actions[row] = act;
+            for (int ks = 0; ks < 2; ks++) {
+                h8 ah, al;
+                load_afrag(s_b[0], s_b[1], 0, ks, lane, ah, al);
+                mfma_split(ah, al, b3[ks], hi, lo);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) s_q[0][(crow + r) * 17 + ccol] = split_sum(hi[r], lo[r]) + s_b3[ccol];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            POL_STAMP(5);
+            // argmax and epsilon-greedy: one lane per row
+            if (lane < 16) {
+                const int row = row0 + lane;
+                auto qf = [&](int a) { return s_q[0][lane * 17 + a]; };
+                if (p.q && row < p.rows)
+                    for (int a = 0; a < p.n_actions; a++) p.q[(size_t)row * p.n_actions + a] = qf(a);
+                const float eps = p.eps_env ? (float)p.eps_env[(row < p.rows ? row : p.rows - 1) / p.n_agents] : p.epsilon;
+                const int act = select_action(qf, p.n_actions, p.select, eps, p.seed, p.step, p.row0 + (unsigned long long)row);
+                if (row < p.rows) p.actions[row] = act;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();   // s_q[0] is free again (this wavefront's next tile)
         }
         POL_STAMP(6);
     }
@@ -615,7 +616,7 @@ int cs_policy_pack(const float *fc1_w, const float *fc1_b, const float *w_ih, co
         }
     for (int nt = 0; nt < 4; nt++)
         for (int ks = 0; ks < 2; ks++) hfrag(HOFF_W2, nt * 2 + ks, fc2a_w, 64, 64, nt, 32 * ks, 4);
-    for (int wv = 0; wv < 4; wv++) hfrag(HOFF_W3, wv, fc2b_w, n_actions, 64, 0, 16 * wv, 2);   // wavefront wv's 16 of the 64 k
+    for (int ks = 0; ks < 2; ks++) hfrag(HOFF_W3, ks, fc2b_w, n_actions, 64, 0, 32 * ks, 4);
     for (int i = 0; i < 64; i++) packed[HOFF_B1 + i] = fc1_b[i];
     for (int i = 0; i < 192; i++) packed[HOFF_BIH + i] = b_ih[i];
     for (int i = 0; i < 192; i++) packed[HOFF_BHH + i] = b_hh[i];

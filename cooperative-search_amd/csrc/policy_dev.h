@@ -42,6 +42,7 @@ constexpr int PACKED_FLOATS_F32 = OFF_B3 + 16;
 #endif
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 constexpr int HST = 72;                 // halves per LDS row of a split activation plane: rows 144 B apart, conflict-free 16-byte reads
+constexpr int HXS = 40;                 // ... of the 32-column input planes of the fused closed loop: rows 80 B apart, conflict-free too
 constexpr float LO_SCALE = 2048.0f, LO_INV = 1.0f / 2048.0f;
 constexpr float F16_MIN_NORMAL = 6.2e-5f;
 // packed weights, in dwords: fragment f = 2 planes (hi, lo) x 64 lanes x 4 dwords (8 halves): lane l of fragment (column tile nt,
@@ -51,8 +52,8 @@ constexpr int HOFF_W1 = 0;                               // [4 col tiles][1 k-st
 constexpr int HOFF_WIH = HOFF_W1 + 4 * 1 * FRAG_DW;      // [12][2]
 constexpr int HOFF_WHH = HOFF_WIH + 12 * 2 * FRAG_DW;    // [12][2]
 constexpr int HOFF_W2 = HOFF_WHH + 12 * 2 * FRAG_DW;     // [4][2]
-constexpr int HOFF_W3 = HOFF_W2 + 4 * 2 * FRAG_DW;       // [4 K-slices of 16, one per wavefront][1]: lanes 32..63 (k >= 16) are zero
-constexpr int HOFF_B1 = HOFF_W3 + 4 * FRAG_DW;           // biases, fp32
+constexpr int HOFF_W3 = HOFF_W2 + 4 * 2 * FRAG_DW;       // [1 col tile][2]: the whole K = 64 (one wavefront computes a tile's q and selects)
+constexpr int HOFF_B1 = HOFF_W3 + 2 * FRAG_DW;           // biases, fp32
 constexpr int HOFF_BIH = HOFF_B1 + 64;
 constexpr int HOFF_BHH = HOFF_BIH + 192;
 constexpr int HOFF_B2 = HOFF_BHH + 192;
@@ -86,9 +87,10 @@ __device__ __forceinline__ BFrag load_bfrag(const float *packed, int off_dw, int
     __builtin_memcpy(&f.lo, &b, 16);
     return f;
 }
-// A fragment of k-step ks from a split plane pair (16 rows of one tile starting at `row0` of the planes)
+// A fragment of k-step ks from a split plane pair (16 rows of one tile starting at `row0` of the planes; row pitch ST halves)
+template <int ST = HST>
 __device__ __forceinline__ void load_afrag(const _Float16 *hi, const _Float16 *lo, int row0, int ks, int lane, h8 &ah, h8 &al) {
-    const int idx = (row0 + (lane & 15)) * HST + 32 * ks + 8 * (lane >> 4);
+    const int idx = (row0 + (lane & 15)) * ST + 32 * ks + 8 * (lane >> 4);
     ah = *reinterpret_cast<const h8 *>(hi + idx);
     al = *reinterpret_cast<const h8 *>(lo + idx);
 }
@@ -98,7 +100,9 @@ __device__ __forceinline__ void mfma_split(const h8 ah, const h8 al, const BFrag
     lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.lo, lo, 0, 0, 0);
     hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b.hi, hi, 0, 0, 0);
 }
-__device__ __forceinline__ float split_sum(float hi, float lo) { return hi + lo * LO_INV; }
+// hi + lo / 2048 in ONE instruction: the scaling by a power of two is exact, so the fused form rounds exactly like the product followed
+// by the sum (the translation unit is compiled with -ffp-contract=off: written as a sum it stays two instructions)
+__device__ __forceinline__ float split_sum(float hi, float lo) { return __builtin_fmaf(lo, LO_INV, hi); }
 #endif
 
 

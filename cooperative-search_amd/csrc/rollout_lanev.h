@@ -45,6 +45,10 @@
 #ifndef CS_LV_WAVES_LARGE
 #define CS_LV_WAVES_LARGE 2   /* ... teams of 6 to 8 */
 #endif
+#ifndef CS_LV_BLOCK
+#define CS_LV_BLOCK 256   /* threads per workgroup of k_rollout_lanev (>= 128: load_trig_to_lds) */
+#endif
+constexpr int LV_BLOCK = CS_LV_BLOCK;
 constexpr int lv_waves(int n) { return n <= 3 ? CS_LV_WAVES_SMALL : (n <= 5 ? CS_LV_WAVES_MID : CS_LV_WAVES_LARGE); }
 constexpr int LV_PIECE = 32;           // get_state rows per staging piece: half a wavefront
 constexpr int LV_SLOT_FLOATS = 4 * G * 2;   // reset hand-over: four rows of 16 (ntx, nty) pairs
@@ -162,7 +166,7 @@ __device__ __forceinline__ void lv_advance_now(const DevParams &p, int b0, int l
 }
 
 template <int N, bool VEC>
-__global__ __launch_bounds__(BLOCK, lv_waves(N)) void k_rollout_lanev(DevParams p, StepIO io) {
+__global__ __launch_bounds__(LV_BLOCK, lv_waves(N)) void k_rollout_lanev(DevParams p, StepIO io) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *T = reinterpret_cast<double *>(smem);                                   // trig table (2072 B)
     double *rtab = reinterpret_cast<double *>(smem + LV_HEAD_BYTES - 4 * G * sizeof(double));   // the reset's target tables
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(BLOCK, lv_waves(N)) void k_rollout_lanev(DevParams 
     unsigned *rowbuf = reinterpret_cast<unsigned *>(wbase);         // ... or one MT19937 row (in-loop refresh): never live together
     unsigned *tl = reinterpret_cast<unsigned *>(wbase + lv_wave_bytes(W) - LV_TAPE_ROWS * 64 * sizeof(unsigned));   // hit tapes, [dword][lane]
     float2 *slots = reinterpret_cast<float2 *>(reinterpret_cast<char *>(tl) - LV_SLOT_FLOATS * sizeof(float));      // [4][G] reset hand-over
-    const int b = io.env0 + blockIdx.x * BLOCK + threadIdx.x;
+    const int b = io.env0 + blockIdx.x * LV_BLOCK + threadIdx.x;
     const int b0 = b - lane;  // first env of this wavefront
     const int b_end = io.env0 + io.env_n;
     const bool live = VEC || b < b_end;   // a VEC launch has only full wavefronts

@@ -14,8 +14,9 @@
  *     data_ptr()); `stream` is a hipStream_t passed as void* (NULL = the legacy default stream);
  *   - nothing allocates, synchronises or copies on the step path; all work is enqueued on `stream`;
  *   - return value: 0 = OK, negative = CS_E_*; cs_last_error() gives a thread-local message;
- *   - one environment = 16 lanes of a wavefront: lane t owns target t, the <= 8 agents are replicated
- *     in every lane's registers.  Hence n_targets <= 16 and n_agents <= 8.
+ *   - n_targets <= 16 and n_agents <= 8: every kernel layout (16 lanes per env with lane t owning target t; 8 lanes per env
+ *     with lane t owning agent t and targets t, t + 8; one env per lane) is built on these bounds.  Which layout a call runs
+ *     on is chosen by batch size: the dispatch table is in DESIGN.md section 4; all of them give the same results.
  *
  * Numerics contract: agent positions and yaw are fp64 and follow the reference's
  * float operations one for one (same order, no FMA contraction, correctly rounded sin/cos of the
@@ -61,8 +62,9 @@ enum {
                             flag clear to reproduce that, as the B = 1 adapter does.) */
     CS_AUTO_RESET = 2,   /* an env that was terminated on entry is reset(init=False) first, then stepped */
     CS_ACTIONS_I64 = 4,  /* actions_dev holds int64 (torch.long) instead of int32 */
-    CS_KERNEL_GROUP = 8, /* flight_easy: force the 16-lanes-per-env kernels (default for batch < 32768) */
-    CS_KERNEL_LANE = 16, /* flight_easy: force the lane-per-env kernel   (default for batch >= 32768); same results */
+    CS_KERNEL_GROUP = 8, /* flight_easy: force the 16-lanes-per-env kernels (the default of cs_step up to the lane kernels' range) */
+    CS_KERNEL_LANE = 16, /* flight_easy: force the first-generation lane-per-env kernel (the default for teams of 6 to 8 at very
+                            large batches; smaller teams get CS_KERNEL_LANEV's kernel); same results */
     CS_KERNEL_SOLO = 32, /* cs_rollout, 16-lanes-per-env path: one wavefront per four envs does the whole step */
     CS_KERNEL_DUO = 64,  /* ... a kinematics wavefront and a detection wavefront per four envs (default up to 4096 envs
                             of at most 6 agents, where the batch leaves a wave slot per SIMD empty); same results */

@@ -574,7 +574,11 @@ void orc_batch_rollout_rep(orc_batch *b, const int32_t *actions, int T, int repe
     const size_t obs_w = (size_t)n * (b->c.variant == 0 ? 4 : b->c.map_size * b->c.map_size + 4);
     const size_t st_w = (size_t)(4 * n + 3 * m);
     const size_t B = (size_t)b->n;
-#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
+    /* dynamic, 64 envs at a time: the envs are independent, so the schedule cannot change a result.  64 envs = whole cache lines
+     * of every per-step output (64 terminated / win bytes, 256 reward bytes), so no two threads write one line -- chunks of 4
+     * were a third slower than a static split for that reason -- and a thread the host deschedules costs the region its
+     * current chunk instead of its whole static share */
+#pragma omp parallel for schedule(dynamic, 64) num_threads(threads > 0 ? threads : 1)
     for (int64_t i = 0; i < b->n; i++) {
         orc_env *e = b->envs[i];
         for (int rs = 0; rs < repeat * T; rs++) {

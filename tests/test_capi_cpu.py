@@ -177,8 +177,7 @@ def test_policy_pack_layout_host_only():
     """cs_policy_pack is pure host code.  Split-fp16 layout (csrc/policy_dev.h): every weight w travels as hi = fp16(w) (0 below
     fp16's normal range) and lo = fp16((w - hi) * 2048); fragment (column tile nt, k-step ks of 32) is the hi plane then the lo
     plane, each [64 lanes][8 halves] with lane l, j holding W[16 nt + (l & 15)][32 ks + 8 (l >> 4) + j] -- the B operand of one
-    16x16x32 MFMA --, zero padded; fc2's second layer as four K-slices of 16 (one per wavefront, k-blocks 2 and 3 zero); fp32 biases
-    follow.  hi + lo / 2048 reproduces the weight to 22 bits."""
+    16x16x32 MFMA --, zero padded; fp32 biases follow.  hi + lo / 2048 reproduces the weight to 22 bits."""
     import ctypes as C
     L = _lib.load()
     rng = np.random.default_rng(3)
@@ -210,7 +209,7 @@ def test_policy_pack_layout_host_only():
              [(ws[2], nt, 32 * ks, 4) for nt in range(12) for ks in range(2)] +
              [(ws[4], nt, 32 * ks, 4) for nt in range(12) for ks in range(2)] +
              [(ws[6], nt, 32 * ks, 4) for nt in range(4) for ks in range(2)] +
-             [(ws[8], 0, 16 * wv, 2) for wv in range(4)])
+             [(ws[8], 0, 32 * ks, 4) for ks in range(2)])
     for w, nt, k0, kb in frags:
         hi, lo = want_frag(w, nt, k0, kb)
         got_hi = halves[2 * off: 2 * off + 512].reshape(64, 8)
@@ -269,3 +268,30 @@ def test_committed_kernel_resources_describe_the_shipped_binary():
     have = open(path).read()
     assert sorted(have.split("\n")) == sorted(want.split("\n")), \
         "profiles/kernel_resources.txt is not of this binary: python tools/kernel_resources.py > profiles/kernel_resources.txt"
+
+
+def test_dispatch_table_matches_the_code():
+    """the kernel-dispatch thresholds disagreed between README, DESIGN, INTEGRATION, the header and the code.  ONE
+    table now (between the dispatch markers); this test reads its macros and values and compares them with the
+    defaults in csrc/coopsearch.hip and with bench.py's kernel_label at every boundary; the other documents must not carry
+    thresholds of their own that disagree (the old 131072 / 32768 rollout switches)."""
+    import importlib.util
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    table = design[design.index("<!-- dispatch:begin -->"):design.index("<!-- dispatch:end -->")]
+    doc = {m.group(1): int(m.group(2)) for m in re.finditer(r"`(CS_[A-Z_]+)` = (\d+)", table)}
+    assert set(doc) == {"CS_ODE_UPTO", "CS_OD_UPTO", "CS_OCT_FROM", "CS_LANEV_FROM", "CS_LANE_FROM_LARGE_TEAMS"}
+    src = open(os.path.join(ROOT, "cooperative-search_amd", "csrc", "coopsearch.hip")).read()
+    for name, value in doc.items():
+        m = re.search(r"#ifndef " + name + r"\s*\n#define " + name + r"\s+(\d+)", src)
+        assert m and int(m.group(1)) == value, (name, value, m and m.group(1))
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    lab = lambda n, B: bench.kernel_label("flight_easy", n, B, "rollout", "auto")
+    assert lab(3, doc["CS_ODE_UPTO"]) == "k_rollout_od<3,E>" and lab(3, doc["CS_ODE_UPTO"] + 1) == "k_rollout_od<3>"
+    assert lab(5, doc["CS_OD_UPTO"]) == "k_rollout_od<5>" and lab(5, doc["CS_OD_UPTO"] + 1) == "k_rollout_oct<5>"
+    assert lab(5, doc["CS_LANEV_FROM"] - 1) == "k_rollout_oct<5>" and lab(5, doc["CS_LANEV_FROM"]) == "k_rollout_lanev<5>"
+    assert lab(6, doc["CS_LANEV_FROM"]) == "k_rollout_oct<6>" and lab(6, doc["CS_LANE_FROM_LARGE_TEAMS"]) == "k_rollout_lane<6>"
+    for fn in ("README.md", "INTEGRATION.md", os.path.join("include", "coopsearch.h")):
+        txt = open(os.path.join(ROOT, fn)).read()
+        assert "131072" not in txt, fn + " still names the old lane-kernel threshold; refer to DESIGN.md section 4 instead"

@@ -143,6 +143,20 @@ def test_rank_binding_reads_the_gpu_numa_node_from_sysfs(tmp_path):
     assert bench.gpu_local_cpus(1, str(tmp_path)) == (1, {4, 5, 6, 7, 12, 13, 14, 15})
     assert bench.gpu_local_cpus(2, str(tmp_path)) is None          # fewer GPUs than ranks: no binding, no error
     assert bench.gpu_local_cpus(0, str(tmp_path / "nowhere")) is None
+    # device filters renumber (a gpurun box exports ROCR_VISIBLE_DEVICES=0 and HIP_VISIBLE_DEVICES=0)
+    try:
+        os.environ["ROCR_VISIBLE_DEVICES"] = "0"
+        os.environ["HIP_VISIBLE_DEVICES"] = "0"
+        assert bench.gpu_local_cpus(0, str(tmp_path))[0] == 0 and bench.gpu_local_cpus(1, str(tmp_path)) is None
+        os.environ["ROCR_VISIBLE_DEVICES"] = "1,0"
+        assert bench.gpu_local_cpus(0, str(tmp_path))[0] == 1
+        os.environ["HIP_VISIBLE_DEVICES"] = "1"
+        assert bench.gpu_local_cpus(0, str(tmp_path))[0] == 0
+        os.environ["HIP_VISIBLE_DEVICES"] = "GPU-1234abcd"
+        assert bench.gpu_local_cpus(0, str(tmp_path)) is None      # not a list of indices: no guess
+    finally:
+        for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+            os.environ.pop(k, None)
     before = os.sched_getaffinity(0)
     try:
         got = bench.bind_rank_to_gpu_node(0, str(tmp_path))
@@ -153,6 +167,85 @@ def test_rank_binding_reads_the_gpu_numa_node_from_sysfs(tmp_path):
             assert got is None
     finally:
         os.sched_setaffinity(0, before)
+
+
+def test_rank_binding_falls_back_to_the_pci_address_and_the_kfd_io_link(tmp_path):
+    """What a gpurun box shows (gpurun_out/a_topology.txt): the container's GPU is KFD node 3 with render minor 136, but
+    /sys/class/drm lists renderD128..135 only -- the lookup by minor finds nothing.  Second source: the PCI device by the
+    node's domain / location_id; third: the GPU's io_link to a CPU node, whose number is the NUMA node's."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL"):
+        os.environ.pop(k, None)
+
+    def tree(base, with_pci, with_link):
+        nodes = base / "class/kfd/kfd/topology/nodes"
+        for k in (0, 1):
+            (nodes / str(k)).mkdir(parents=True)
+            (nodes / str(k) / "properties").write_text("cpu_cores_count 128\nsimd_count 0\ndrm_render_minor 0\n")
+        (nodes / "2").mkdir()    # somebody else's GPU: unreadable
+        (nodes / "3").mkdir()
+        (nodes / "3" / "properties").write_text("cpu_cores_count 0\nsimd_count 1024\nlocation_id 3328\ndomain 0\ndrm_render_minor 136\n")
+        if with_pci:
+            d = base / "bus/pci/devices/0000:0d:00.0"
+            d.mkdir(parents=True)
+            (d / "numa_node").write_text("1\n")
+            (d / "local_cpulist").write_text("64-127,192-255\n")
+        if with_link:
+            ln = nodes / "3" / "io_links" / "0"
+            ln.mkdir(parents=True)
+            (ln / "properties").write_text("type 2\nnode_from 3\nnode_to 1\n")
+            nd = base / "devices/system/node/node1"
+            nd.mkdir(parents=True)
+            (nd / "cpulist").write_text("64-127,192-255\n")
+
+    want = (1, set(range(64, 128)) | set(range(192, 256)))
+    for name, pci, link in (("pci", True, False), ("link", False, True), ("both", True, True)):
+        base = tmp_path / name
+        tree(base, pci, link)
+        assert bench.gpu_local_cpus(0, str(base)) == want, name
+    base = tmp_path / "neither"
+    tree(base, False, False)
+    assert bench.gpu_local_cpus(0, str(base)) is None
+
+
+def test_cpu_baseline_child_reports_a_steady_point_under_the_cgroup_quota(tmp_path, monkeypatch):
+    """the CPU baseline runs in its own pinned process, never with more threads than the container's CPU quota
+    (the GPU boxes show 256 logical CPUs and grant 16), and `value` is the median region rate of the fastest thread count whose
+    regions hold together, with every measured point listed."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod3", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    q = bench.cpu_quota()
+    assert q is None or q > 0
+    import builtins
+    real_open = builtins.open
+
+    def fake_open(path, *a, **k):
+        if path == "/sys/fs/cgroup/cpu.max":
+            return real_open(tmp_path / "cpu.max", *a, **k)
+        return real_open(path, *a, **k)
+
+    (tmp_path / "cpu.max").write_text("1600000 100000\n")
+    monkeypatch.setattr(builtins, "open", fake_open)
+    assert bench.cpu_quota() == 16.0
+    (tmp_path / "cpu.max").write_text("max 100000\n")
+    assert bench.cpu_quota() is None
+    monkeypatch.undo()
+    p, line = _run_bench(["--cpu-baseline-child", "flight_easy,3,512,0.6"],
+                         env_extra={"OMP_PROC_BIND": "close", "OMP_PLACES": "cores", "OMP_DYNAMIC": "false"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert line["kind"] == "port" and line["unit"] == "env-steps/s" and line["value"] > 0
+    assert str(line["cores"]) in line["measured_points"] and line["cores"] <= line["pinning"]["physical_cores"]
+    p10, med, p90 = line["region_rate_p10_median_p90"]
+    assert p10 <= med <= p90 and med == line["value"] and abs(line["p90_over_p10"] - p90 / p10) < 1e-9
+    assert line["steady"] == (line["p90_over_p10"] < bench.STEADY_SPAN) or not line["steady"]
+    assert line["pinning"]["OMP_PROC_BIND"] == "close" and line["pinning"]["OMP_PLACES"] == "cores"
 
 
 def test_bench_launcher_propagates_rank_failure():

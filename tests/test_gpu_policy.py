@@ -419,6 +419,20 @@ def _load_net(z, args):
     return net
 
 
+def _report_lockstep(tag, compared, total, episodes):
+    """the walked fraction per checkpoint tag, printed (pytest -rP / -s shows it) and appended to
+    gpurun_out/lockstep_fractions.txt, which the measurement script copies to profiles/."""
+    line = f"{tag}: {compared} of {total} recorded steps walked in lockstep over {episodes} episodes ({compared / max(total, 1):.3f})"
+    print(line)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "lockstep_fractions.txt"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+
+
 @pytest.mark.parametrize("tag", EASY_TAGS + FLIGHT_TAGS)
 def test_trained_checkpoint_exact_trajectories(tag):
     """next to the statistical curves, EXACT closed-loop trajectories.  gen_trained.py starts its first four
@@ -458,6 +472,7 @@ def test_trained_checkpoint_exact_trajectories(tag):
             assert int(env.target_find[k]) == int(z["traj_found"][k, L - 1])
         compared += steps
         total += L
+    _report_lockstep(tag, compared, total, K)
     assert compared >= 0.3 * total, f"{tag}: only {compared} of {total} steps walked in lockstep before a near-tie broke it"
 
 

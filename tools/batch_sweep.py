@@ -1,14 +1,14 @@
 """Batch sweep of the flight_easy rollout kernels (SURVEY.md section 8d asks for 2^12..2^22): env-steps/s and the
 algorithmic-bytes roofline fraction per batch size: the 16-lane kernels of rounds 1-2 (solo / duo), the octet kernels (ode:
 kinematics, detection and emitting wavefront per 8 envs; od: kinematics and detection wavefront; oct: one wavefront per 8 envs)
-and the lane kernel.  Writes a markdown table."""
+and the lane-per-env kernels (lane: round 2's, lanev: round 4's).  Writes a markdown table."""
 import json, subprocess, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rows = []
 for n in (3, 5):
     for B in (1024, 2048, 4096, 8192, 16384, 32768, 65536, 262144, 1048576, 4194304):
-        for kernel in ("solo", "duo", "ode", "od", "oct", "lane"):
-            if kernel == "lane" and B in (2048, 8192):
+        for kernel in ("solo", "duo", "ode", "od", "oct", "lane", "lanev"):
+            if kernel in ("lane", "lanev") and B < 16384:
                 continue
             if kernel in ("solo", "duo") and B > (1 << 16):
                 continue

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r02_traffic_raw.json (tools/pmc_traffic.sh: FETCH_SIZE / WRITE_SIZE sums per kernel and workload) ->
+"""profiles/r04_traffic_raw.json (tools/pmc_traffic.sh: FETCH_SIZE / WRITE_SIZE sums per kernel and workload) ->
 profiles/traffic.json (HBM bytes per env-step per bench kernel label, what bench.py's roofline.traffic reads).
     python tools/make_traffic_json.py [raw.json] [out.json]"""
 import json
@@ -7,7 +7,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-raw_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03_traffic_raw.json")
+raw_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r04_traffic_raw.json")
 out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "traffic.json")
 raw = json.load(open(raw_path))
 
@@ -25,6 +25,11 @@ LABELS = [
     ("k_rollout_od<3>@100", "od3_16384", ["k_rollout_od<3, true, true, false>"], 100),
     ("k_rollout_oct<3>@100", "oct3_32768", ["k_rollout_oct<3, true, true>"], 100),
     ("k_rollout_oct<5>@100", "oct5_32768", ["k_rollout_oct<5, true, true>"], 100),
+    # (one label per kernel: the FIRST workload listed here that was measured; bytes per env-step of the lane-per-env kernel are
+    # batch independent above its dispatch threshold)
+    ("k_rollout_lanev<5>@100", "lane5_rollout", ["k_rollout_lanev<5, true>", "k_rollout_lanev<5, false>"], 100),
+    ("k_rollout_lanev<5>@100", "c5s_rollout", ["k_rollout_lanev<5, true>", "k_rollout_lanev<5, false>"], 100),
+    ("k_rollout_lanev<3>@100", "lane3_rollout", ["k_rollout_lanev<3, true>", "k_rollout_lanev<3, false>"], 100),
     ("k_rollout_lane<5>@100", "c5s_rollout", ["k_rollout_lane<5, true>", "k_rollout_lane<5, false>"], 100),
     ("k_rollout_lane<3>@100", "lane3_rollout", ["k_rollout_lane<3, true>", "k_rollout_lane<3, false>"], 100),
     ("k_step<3,1> + k_map<3>@1", "c4_step", ["k_map<3>", "k_step<3, 1>"], 1),

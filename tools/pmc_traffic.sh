@@ -24,7 +24,10 @@ run od3_16384 flight_easy 3 auto 16384 rollout 4 100
 run oct3_32768 flight_easy 3 auto 32768 rollout 4 100
 run oct5_32768 flight_easy 5 auto 32768 rollout 4 100
 run c5s_rollout flight_easy 5 auto 65536 rollout 3 100
-run lane3_rollout flight_easy 3 lane 262144 rollout 3 100
+run lane3_rollout flight_easy 3 auto 262144 rollout 3 100
+run lane5_rollout flight_easy 5 auto 262144 rollout 3 100
+run lane3_1m flight_easy 3 auto 1048576 rollout 2 100
+run lane5_1m flight_easy 5 auto 1048576 rollout 2 100
 run c4_step flight 3 group 8192 step 1 100
 run c4_rollout flight 3 group 8192 rollout 1 100
 python3 - "$OUT" <<'PY'
