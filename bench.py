@@ -832,9 +832,9 @@ def main():
                 side_measurement(cs, dev, comm, "flight_easy 3a15t B=1048576 (lane-per-env kernel; batch sweep asymptote)",
                                  "flight_easy", 3, 1048576, "rollout", 100, 100, "auto"),
                 side_measurement(cs, dev, comm, "flight_easy 5a15t B=262144 (lane-per-env kernel)",
-                                 "flight_easy", 5, 262144, "rollout", 200, 100, "auto"),
+                                 "flight_easy", 5, 262144, "rollout", 400, 100, "auto"),
                 side_measurement(cs, dev, comm, "flight_easy 5a15t B=1048576 (lane-per-env kernel)",
-                                 "flight_easy", 5, 1048576, "rollout", 100, 100, "auto"),
+                                 "flight_easy", 5, 1048576, "rollout", 200, 100, "auto"),
                 closed_loop_measurement(cs, dev, 3, 4096, 2000, 200),
                 closed_loop_measurement(cs, dev, 3, 65536, 400, 100),
                 closed_loop_measurement(cs, dev, 3, 8192, 400, 100, "flight"),

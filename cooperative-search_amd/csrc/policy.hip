@@ -230,6 +230,8 @@ __global__ __launch_bounds__(PBLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     __shared__ float s_h[16 * LDW];      // previous hidden state, fp32 (the GRU blend)
     __shared__ float s_q[4][16 * 17];    // partial q of the four wavefronts
     __shared__ float s_b3[16];
+    __shared__ uint4 s_w3[2 * 2 * 64];   // the fc3 fragments ([k-step][hi, lo][lane]): only wavefront 0 multiplies by them, once per tile --
+    //                                      in registers they cost every wavefront 16 VGPRs, and the kernel sits at its 256-register limit
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // w is wave-uniform
     const int crow = (lane >> 4) * 4, ccol = lane & 15;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -248,9 +250,7 @@ __global__ __launch_bounds__(PBLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     BFrag b2[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) b2[ks] = load_bfrag(p.w, HOFF_W2, w * 2 + ks, ulane);
-    BFrag b3[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ks++) b3[ks] = load_bfrag(p.w, HOFF_W3, ks, ulane);
+    s_w3[threadIdx.x] = reinterpret_cast<const uint4 *>(p.w + HOFF_W3)[threadIdx.x];   // 256 threads x 16 B = both fragments (visible after the first barrier)
     if (threadIdx.x < 16) s_b3[threadIdx.x] = p.w[HOFF_B3 + threadIdx.x];  // visible after the first barrier
     const int col = 16 * w + ccol;
     const float bias1 = p.w[HOFF_B1 + col], bias2 = p.w[HOFF_B2 + col];
@@ -272,18 +272,22 @@ __global__ __launch_bounds__(PBLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         kind[j] = k >= in_dim ? ZERO : k < fbase ? FEAT : (!p.last || ko < 4) ? OBS : ko < 4 + p.n_actions ? LAST : AGENT;
         kidx[j] = kind[j] == FEAT ? k : kind[j] == OBS ? ko : kind[j] == LAST ? ko - 4 : ko - 4 - p.n_actions;
     }
-    float xv[NCOL];
-    int lav[NCOL];
-    float4 hv;
-    auto fetch = [&](int tile) {   // loads only: nothing here waits for memory
+    // the inputs of the CURRENT tile (xv, lav, hv) and of the NEXT one (n*): the next tile's loads are issued right after the
+    // current tile has been staged and are first touched at the very end of the loop body (the empty asm below pins that use
+    // there), four phases later.  With one set of variables the compiler copied the freshly loaded values into the loop-carried
+    // registers straight after issuing the loads and waited for them in front of the first barrier: a full memory round trip per tile.
+    float xv[NCOL], nxv[NCOL];
+    int lav[NCOL], nlav[NCOL];
+    float4 hv, nhv;
+    auto fetch = [&](int tile, float (&fx)[NCOL], int (&fl)[NCOL], float4 &fh) {   // loads only: nothing here waits for memory
         const int row = 16 * tile + srow < p.rows ? 16 * tile + srow : p.rows - 1;
 #pragma unroll
         for (int j = 0; j < NCOL; j++) {
-            xv[j] = kind[j] == OBS ? p.obs[(size_t)row * p.obs_stride + p.obs_offset + kidx[j]]
+            fx[j] = kind[j] == OBS ? p.obs[(size_t)row * p.obs_stride + p.obs_offset + kidx[j]]
                   : kind[j] == FEAT ? p.feat[(size_t)(row / p.rows_per_feat) * NFEAT + kidx[j]] : 0.0f;
-            lav[j] = kind[j] == LAST ? (int)p.last[row] : -1;
+            fl[j] = kind[j] == LAST ? (int)p.last[row] : -1;
         }
-        hv = *reinterpret_cast<const float4 *>(p.hidden + (size_t)row * H + 4 * kcol);
+        fh = *reinterpret_cast<const float4 *>(p.hidden + (size_t)row * H + 4 * kcol);
     };
     auto input_value = [&](int j, int row) {
         if (kind[j] == OBS || kind[j] == FEAT) return xv[j];
@@ -292,7 +296,13 @@ __global__ __launch_bounds__(PBLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     };
 
     int tile = blockIdx.x;
-    if (tile < tiles) fetch(tile);
+    if (tile < tiles) fetch(tile, xv, lav, hv);
+#pragma unroll
+    for (int j = 0; j < NCOL; j++) {
+        nxv[j] = 0.0f;
+        nlav[j] = -1;
+    }
+    nhv = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int iter = 0; tile < tiles; tile += gridDim.x, iter++) {
         const int row0 = 16 * tile;
         POL_STAMP(0);
@@ -304,7 +314,8 @@ __global__ __launch_bounds__(PBLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         split_store(s_hs[0], s_hs[1], srow * HST + 4 * kcol + 1, hv.y);
         split_store(s_hs[0], s_hs[1], srow * HST + 4 * kcol + 2, hv.z);
         split_store(s_hs[0], s_hs[1], srow * HST + 4 * kcol + 3, hv.w);
-        if (tile + (int)gridDim.x < tiles) fetch(tile + gridDim.x);
+        const bool more = tile + (int)gridDim.x < tiles;   // block-uniform
+        if (more) fetch(tile + gridDim.x, nxv, nlav, nhv);
         __syncthreads();
         POL_STAMP(1);
 
@@ -372,7 +383,11 @@ __global__ __launch_bounds__(PBLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             for (int ks = 0; ks < 2; ks++) {
                 h8 ah, al;
                 load_afrag(s_b[0], s_b[1], 0, ks, lane, ah, al);
-                mfma_split(ah, al, b3[ks], hi, lo);
+                BFrag b3;
+                const uint4 wh = s_w3[(2 * ks) * 64 + lane], wl = s_w3[(2 * ks + 1) * 64 + lane];
+                __builtin_memcpy(&b3.hi, &wh, 16);
+                __builtin_memcpy(&b3.lo, &wl, 16);
+                mfma_split(ah, al, b3, hi, lo);
             }
 #pragma unroll
             for (int r = 0; r < 4; r++) s_q[0][(crow + r) * 17 + ccol] = split_sum(hi[r], lo[r]) + s_b3[ccol];
@@ -394,6 +409,15 @@ __global__ __launch_bounds__(PBLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             __builtin_amdgcn_wave_barrier();   // s_q[0] is free again (this wavefront's next tile)
         }
         POL_STAMP(6);
+        // first use of the next tile's inputs: here, not earlier (see above)
+#pragma unroll
+        for (int j = 0; j < NCOL; j++) {
+            asm volatile("" : "+v"(nxv[j]), "+v"(nlav[j]));
+            xv[j] = nxv[j];
+            lav[j] = nlav[j];
+        }
+        asm volatile("" : "+v"(nhv.x), "+v"(nhv.y), "+v"(nhv.z), "+v"(nhv.w));
+        hv = nhv;
     }
 }
 #endif   // CS_POLICY_F16
