@@ -209,6 +209,7 @@ def physical_cores():
 
 
 STEADY_SPAN = 1.25   # p90 / p10 of the per-region rates below which a thread count counts as a repeatable baseline
+QUOTA_HEADROOM = 2   # CPUs of a cgroup quota the baseline's team leaves unused (see cpu_baseline_inproc)
 
 
 def cpu_quota():
@@ -251,15 +252,20 @@ def cpu_baseline_inproc(env_name, n, batch, budget_s=10.0):
     flight_easy: orc_batch_rollout_rep -- ONE OpenMP region per 400 steps (the 100-step action table walked four times),
     env-major, so the fork/join cost is paid once per 400 steps and an env stays in its core's cache.  The team is pinned
     (see cpu_baseline): one thread per PHYSICAL core at most -- SMT siblings are never used -- and never more threads than the
-    cgroup's CPU quota (cpu_quota); thread counts from 1 to that limit are calibrated first (median of three regions each); the three best share the time budget
-    and `value` is the MEDIAN per-region rate of the fastest one whose regions span less than STEADY_SPAN between p10 and p90
-    (`cores` = that thread count); every measured point is listed with its p10 / median / p90.  The envs of a region are handed
-    out dynamically, four at a time, so one descheduled thread costs its current chunk and not the whole region."""
+    cgroup's CPU quota less QUOTA_HEADROOM (cpu_quota); thread counts from 1 to that limit are calibrated first (median of
+    three regions each); the three best share the time budget and `value` is the MEDIAN per-region rate of the fastest one
+    whose regions span less than STEADY_SPAN between p10 and p90 (`cores` = that thread count); every measured point is listed
+    with its p10 / median / p90.  The envs of a region are handed out dynamically, 64 at a time (whole cache lines of every
+    output), so one descheduled thread costs its current chunk and not the whole region."""
     import numpy as np
     from oracle import oracle as orc
     n_cores, smt = physical_cores()
     quota = cpu_quota()
-    max_threads = max(1, min(orc.OracleBatch.max_threads(), n_cores, int(quota) if quota and quota >= 1 else n_cores))
+    # two CPUs' worth of the quota stay free for the parent (its GPU runtime and RCCL helper threads keep polling while it waits
+    # for this child) and the box's own daemons: with a team of exactly `quota` threads the group still ran into the throttle
+    # now and then (16 threads of a 16-CPU quota: region rates spanning 1.02x in a bare child, 1.24-1.28x under bench.py)
+    cap = max(1, int(quota) - QUOTA_HEADROOM) if quota and quota >= 1 else n_cores
+    max_threads = max(1, min(orc.OracleBatch.max_threads(), n_cores, cap))
     flight = env_name == "flight"
     B = batch if not flight else min(batch, 256)
     T, R = (100, 4) if not flight else (10, 1)
@@ -323,7 +329,7 @@ def cpu_baseline_inproc(env_name, n, batch, budget_s=10.0):
             "pinning": {"OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES"),
                         "physical_cores": n_cores, "threads_per_core": smt, "cgroup_cpu_quota": quota,
                         "note": "own process, one thread per physical core at most (no SMT siblings), never more threads than "
-                                "the cgroup's CPU quota"},
+                                "the cgroup's CPU quota - 2"},
             "single_thread_value": single, "speedup_vs_single_thread": value / single,
             "thread_scaling_env_steps_per_s": scaling}
 

@@ -117,6 +117,20 @@ def load():
     if L.cs_abi_version() != ABI_VERSION:
         raise CoopSearchError(f"{path}: ABI version {L.cs_abi_version()}, this package binds version {ABI_VERSION} "
                               "(stale library: rebuild with `python -m cooperative_search_amd.build`)")
+    # The hash COMPILED INTO the library is the truth about what it was built from (the .srchash sidecar above is only the
+    # shortcut that decides about a rebuild before anything is dlopen'ed; a copied .so can carry a wrong or no sidecar).  The ABI
+    # version guards exports and structs only -- kernels change behaviour without touching either -- so a library of other sources
+    # is an error under COOPSEARCH_STRICT=1 (tests, CI) and a warning naming both hashes otherwise.  COOPSEARCH_LIB (experimental
+    # one-team-size builds) opts out.
+    if not os.environ.get("COOPSEARCH_LIB"):
+        built = L.cs_source_hash().decode() if hasattr(L, "cs_source_hash") else ""
+        want = _build.source_hash()
+        if built != want:
+            msg = (f"{path} was built from sources with hash {built!r}, the sources present here hash to {want!r}: "
+                   "kernels may behave differently from what the tests restate (rebuild with `python -m cooperative_search_amd.build`)")
+            if os.environ.get("COOPSEARCH_STRICT") == "1":
+                raise CoopSearchError(msg)
+            warnings.warn(msg, RuntimeWarning, stacklevel=2)
     _lib = L
     return L
 

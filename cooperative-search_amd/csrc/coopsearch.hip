@@ -3797,9 +3797,16 @@ __global__ __launch_bounds__(OCT_BLOCK, CS_OCT_WAVES) void k_rollout_oct(DevPara
 #ifndef CS_OD_RING
 #define CS_OD_RING 4
 #endif
+#ifndef CS_OD_RING_E3
+#define CS_OD_RING_E3 8   /* ring depth of the three-wavefront variant (measured at c2: 2 -> 2.74e9, 4 -> 3.07e9, 8 -> 3.15e9) */
+#endif
 constexpr int OD_BLOCK = 128;
-constexpr int OD_RING = CS_OD_RING;   // steps K may be ahead of D (power of two)
-static_assert((OD_RING & (OD_RING - 1)) == 0 && OD_RING >= 2, "ring depth");
+// steps K may be ahead of D (power of two).  The pair variant serves up to 16384 envs with eight workgroups per CU: 20 KB of LDS each,
+// four slots.  The three-wavefront variant stops at 10240 envs = five workgroups per CU, so its ring can be eight deep (29 KB):
+// K absorbs more of D's events before it has to wait for a slot.
+constexpr int od_ring(bool e3) { return e3 ? CS_OD_RING_E3 : CS_OD_RING; }
+static_assert((od_ring(false) & (od_ring(false) - 1)) == 0 && od_ring(false) >= 2, "ring depth");
+static_assert((od_ring(true) & (od_ring(true) - 1)) == 0 && od_ring(true) >= 2, "ring depth");
 
 struct __attribute__((aligned(16))) OdRing {   // what K hands to D for one step
     double2 pos[OCT_ENVS][OCT_PAD];
@@ -3808,8 +3815,9 @@ struct __attribute__((aligned(16))) OdRing {   // what K hands to D for one step
     unsigned out[OCT_ENVS];
     unsigned pad[OCT_ENVS];
 };
-struct __attribute__((aligned(16))) OdShared {
-    OdRing ring[OD_RING];
+template <int RING>
+struct __attribute__((aligned(16))) OdSharedT {
+    OdRing ring[RING];
     double2 kpos[OCT_ENVS][OCT_PAD];        // K: the team's current positions (the "old" ones of its next step)
     double2 dpos[OCT_ENVS][OCT_PAD];        // D: start poses for the reset-time detection pass
     float tile[OCT_ENVS * TILE_W];
@@ -3894,6 +3902,8 @@ template <int N, bool VEC, bool EMIT, bool E3>
 __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams p, StepIO io) {
     static_assert(!E3 || (VEC && EMIT), "the emitting wavefront has the full-wavefront, obs + state stores only");
     __shared__ double T[TRIG_ROWS * TRIG_COLS];
+    constexpr int OD_RING = od_ring(E3);
+    using OdShared = OdSharedT<OD_RING>;
     __shared__ OdShared sh;
     __shared__ OdOut outs[E3 ? OD_RING : 1];
     int &e_steps = sh.e_steps;
@@ -4246,24 +4256,44 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
 #ifndef CS_OD_DRAIN
 #define CS_OD_DRAIN 0
 #endif
-    constexpr int REQ = CS_OD_ASYNC ? LOW + (LOW > 96 ? LOW : 96) : 0;
+#ifndef CS_OD_REQ_SLACK
+#define CS_OD_REQ_SLACK 64   /* words above one step's worst case at which an env's row is requested (an env that falls below LOW
+                                before its turn is topped up on the spot).  The first setting, max(LOW, 96), refreshed a 5-agent row
+                                with 300 of its 624 words still unused: every refresh costs the same ~4000 cycles whatever it twists */
+#endif
+    constexpr int REQ = CS_OD_ASYNC ? LOW + CS_OD_REQ_SLACK : 0;
     // The requests of a step are issued BEFORE its output stores, and loads / stores retire in order: waiting until no more
     // than the step's own stores are in flight is waiting for the requests -- without also sitting out the stores, which were
     // issued a few hundred cycles ago and take a memory round trip (measured: a plain vmcnt(0) here cost ~1000 cycles per event).
-    constexpr int STEP_STORES = 3 + 1 + (OCT_ENVS * (4 * N + 3 * CS_MAX_TARGETS) / 4 + 63) / 64;   // reward, terminated, win, obs, Q state chunks (EMIT && VEC: exactly these)
+    // What this rests on, and what keeps it true:
+    //  * gfx9 returns vector-memory loads AND stores through one in-order counter (vmcnt): "at most k outstanding" means everything
+    //    issued before the last k operations has completed;
+    //  * the stores after the requests are EXACTLY the STEP_STORES below, each one instruction, none conditional: EMIT && VEC is a
+    //    compile-time property of the kernel (reward, terminated, win: three scalar stores; obs: one 16-byte store; state: Q 16-byte
+    //    stores, Q being the very constant the store loop below runs over).  Every other variant -- stores behind `if (io.obs)`, the
+    //    scalar tail loop, E3 -- takes drain_vmem();
+    //  * -DCS_OD_SAFE_WAIT turns the counted wait into a full drain and -DCS_OD_ASYNC=0 removes the requests altogether: both builds
+    //    must reproduce the shipped one bit for bit (tests/test_gpu_jitter.py builds and compares them).
+    constexpr int W_MAX = 4 * N + 3 * CS_MAX_TARGETS;
+    constexpr int Q = (OCT_ENVS * W_MAX / 4 + 63) / 64;   // float4 chunks per lane of the largest tile = state stores per step
+    constexpr int STEP_STORES = 3 + 1 + Q;                // reward, terminated, win | obs | state
+    static_assert(Q >= 1 && STEP_STORES == 4 + Q, "STEP_STORES counts the stores of the VEC && EMIT step: keep it next to them");
     auto wait_for_requests = [&]() __attribute__((always_inline)) {
+#ifdef CS_OD_SAFE_WAIT
+        drain_vmem();
+#else
         if (!E3 && EMIT && VEC && STEP_STORES <= 15) __builtin_amdgcn_s_waitcnt(0x0F70 | STEP_STORES);   // vmcnt(STEP_STORES)
         else drain_vmem();   // (E3: D stores nothing per step)
+#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
     int cand = -1;                       // env (octet) of the wavefront whose row is on its way into sh.rowbuf
+    int ack_wait = 0;                    // fix request of the previous step that K has yet to acknowledge (0: none)
     unsigned long long pre_need = 0ull;  // the reset mask sh.prebuf was filled for
     unsigned pre_valid = 0u;             // bit g: 16-lane group g's attempt batch is (on its way) in sh.prebuf
     oct_wave_advance<N, CS_OD_DRAIN != 0>(p, wave_b0, nvalid, lane, io.min_ahead > LOW ? io.min_ahead : LOW, sh.rowbuf, e, tape, tape_ok);   // while K produces step 0
     // ---- write-out plan (loop invariant)
     const int rows_valid = nvalid;
-    constexpr int W_MAX = 4 * N + 3 * CS_MAX_TARGETS;
-    constexpr int Q = (OCT_ENVS * W_MAX / 4 + 63) / 64;   // float4 chunks per lane of the largest tile
     const int ol = lane < rows_valid * N ? lane : rows_valid * N - 1;
     const int orow = ol / N, oag = ol - orow * N;
     const int obs_lds = orow * W + 4 * oag;
@@ -4359,6 +4389,11 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
         DUO_STAMP(9);
         OD_JITTER(6);
         // ---- K's step s (normally produced long ago): out flags, the agents' four floats (get_obs / get_state), positions
+        if (__builtin_expect(ack_wait != 0, 0)) {   // ... redone for the envs of the previous step's fix request (see below)
+            OD_JITTER(10);
+            while (peek(&sh.fix_ack) != ack_wait) __builtin_amdgcn_s_sleep(1);
+            ack_wait = 0;
+        }
         while (peek(&sh.k_steps) <= s) { SPIN_TICK; __builtin_amdgcn_s_sleep(1); }
         OD_JITTER(7);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -4493,9 +4528,13 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
             }
         }
         DUO_STAMP(11);
-        if (__builtin_expect(mb != 0ull, 0)) {   // slot s stays ours until K has restored the flagged envs from it
-            while (peek(&sh.fix_ack) != s + 1) __builtin_amdgcn_s_sleep(1);
-        }
+        // A fix request is NOT waited for here.  Slot s is safe without it: K may overwrite slot s only when it produces step
+        // s + RING, which it does after a loop head at which it has seen d_steps (E3: e_steps) > s -- a read that also returns this
+        // fix_req, posted earlier through the same in-order LDS queue -- and a seen request is handled before the next produce.
+        // What D must wait for is the REDONE slot s + 1 (K had produced it long ago; k_steps says nothing about the redo): that
+        // wait sits in front of the next step's read of the ring, AFTER that step's reset work -- so the reset of the env that just
+        // won (target placement, 7-9 k cycles) runs beside K's redo (2-3 produce calls, 4.5-10 k) instead of after it.
+        if (__builtin_expect(mb != 0ull, 0)) ack_wait = s + 1;
         OD_JITTER(9);
         post(&sh.d_steps, s + 1);
         DUO_STAMP(12);
@@ -5340,6 +5379,10 @@ int cs_rollout(const cs_config *cfg, void *state_dev, const void *actions_dev, i
     if (rc) return rc;
     if (T < 1) return fail(CS_E_ARG, "T must be >= 1");
     if (!actions_dev || !reward_dev || !terminated_dev || !win_dev) return fail(CS_E_ARG, "null rollout buffer");
+    // the octet and lane kernels write an (env, agent) observation as ONE 16-byte store in every variant (the state table has a scalar
+    // fallback, the observations do not): a caller's slice at a 4- or 8-byte offset is refused, not stored to with misaligned dwordx4
+    if (cfg->variant == 0 && obs_dev && (reinterpret_cast<size_t>(obs_dev) & 15) != 0)
+        return fail(CS_E_ARG, "obs_dev must be 16-byte aligned");
     if (cfg->variant == 1) {
         // flight: k_step for step 0, then T - 1 launches of k_flight_pipe (the map sweep of step t beside the kinematics /
         // detection of step t + 1), then k_map for the last step's sweep -- enqueued back to back by this one call, each

@@ -125,8 +125,10 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
 // per-row random bits of one selection: counter-based, keyed by (seed, step, GLOBAL row) -- global, so that a sharded
 // batch draws the same exploration noise whatever the split (row = (env_offset + env) * n_agents + agent)
 __device__ __forceinline__ unsigned long long row_bits(unsigned long long seed, unsigned step, unsigned long long grow) {
-    // the three fields are hashed separately: no bit of the 32-bit step counter or of the 64-bit row is shifted out
-    return mix64(seed ^ mix64((unsigned long long)step) ^ mix64(grow * 0x9e3779b97f4a7c15ull));
+    // the fields are CHAINED through the mixer, each entering a value that already depends on the ones before it: XOR-ing
+    // separately hashed fields (the first version) let (step = a, row = b) collide with (step = b, row = a) whenever the two hashed
+    // to swapped values, and cancelled for equal ones.  seed and step are wave-uniform: two of the three mixes run on the scalar unit.
+    return mix64(mix64(mix64(seed) + (unsigned long long)step) + grow * 0x9e3779b97f4a7c15ull);
 }
 
 // epsilon-greedy on top of the greedy choice `arg` (agent/agent.py:70-75): with probability epsilon a uniform action
@@ -163,7 +165,9 @@ __device__ __forceinline__ int select_action(QF qf, int n_actions, int sel, floa
     for (int a = 0; a < n_actions; a++) sum += __expf(qf(a) - best);
     if (!(sel & CS_SELECT_SAMPLE)) {
         // argmax over the float32 prob, like agent.py:93 -- not over q: two q values close enough to round to the same
-        // prob tie there, and the first of them wins
+        // prob tie there, and the first of them wins.  (The probabilities here come from the hardware exp2 and a multiplication
+        // by the reciprocal of the sum, torch's from expf and a division: the SAME q values can round to a tie in one and not in
+        // the other.  The parity tests therefore treat near-ties -- top two outputs within 1e-3 -- as either way.)
         const float inv0 = (1.0f - epsilon) / sum, uni0 = epsilon / (float)n_actions;
         float pbest = -1.0f;
         int parg = 0;

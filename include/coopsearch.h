@@ -200,7 +200,9 @@ int cs_step(const cs_config *cfg, void *state_dev, const void *actions_dev, int 
  * obs [T][B][n][obs width]; state_out [T][B][4n+3m] (obs/state_out may be NULL).  Same results as T cs_step calls
  * with the same flags.  flight_easy: one launch with the env resident in registers; flight: one launch per step in
  * which the map sweep of step t (update + the map part of get_obs) runs beside the kinematics / detection of step
- * t + 1 -- the two are independent once the sweep reads the step's job record (cs_layout.job_off). */
+ * t + 1 -- the two are independent once the sweep reads the step's job record (cs_layout.job_off).
+ * flight_easy: obs_dev must be 16-byte aligned (CS_E_ARG otherwise): an (env, agent) observation is one 16-byte store;
+ * state_out_dev may be anywhere (a table that is not 16-byte aligned, or whose rows per step are not, takes scalar stores). */
 int cs_rollout(const cs_config *cfg, void *state_dev, const void *actions_dev, int T, int flags,
                float *reward_dev, uint8_t *terminated_dev, uint8_t *win_dev,
                float *obs_dev, float *state_out_dev, void *stream);

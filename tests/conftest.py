@@ -6,6 +6,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# a library whose EMBEDDED source hash is not the present sources' is an error in the tests, not a warning (_lib.load); child
+# processes of the tests inherit the switch
+os.environ.setdefault("COOPSEARCH_STRICT", "1")
 
 
 def pytest_configure(config):

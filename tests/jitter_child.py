@@ -1,4 +1,5 @@
-"""Child of tests/test_gpu_jitter.py: runs with COOPSEARCH_LIB pointing at a -DCS_JITTER -DCS_ONLY_N=3 build.  The octet pair
+"""Child of tests/test_gpu_jitter.py: runs with COOPSEARCH_LIB pointing at one of its -DCS_ONLY_N=3 builds (-DCS_JITTER, -DCS_OD_SAFE_WAIT,
+-DCS_OD_ASYNC=0).  The octet pair
 kernels (K + D, and K + D + E) -- their hand-shakes stretched by pseudo-random pauses -- against the 16-lane step kernel of the
 same library, bit for bit, on a scenario where nearly every episode ends with a win K could not predict (fix request, restore
 from the ring, redo, acknowledge: every other step) and on the shipped configuration."""
@@ -43,14 +44,15 @@ def run(kernel, args, B, lengths, mode):
 
 
 def main():
-    assert "jitter" in os.path.basename(cs.lib.library_path()), cs.lib.library_path()
+    name = os.path.basename(cs.lib.library_path())
+    assert name in ("jitter_n3.so", "odsafe_n3.so", "odsync_n3.so"), cs.lib.library_path()
     for kernel in ("od", "ode"):
         w = run(kernel, custom(target_num=2, target_mode=1, detect_prob=1.0, view_range=25), 1000, (7, 64, 3, 100, 26),
                 dict(freeze_done=False, auto_reset=True))
         assert w > 5000, w   # tens of unpredicted wins per env
         run(kernel, custom(target_num=2, target_mode=1, detect_prob=1.0, view_range=25), 520, (40, 9), dict(freeze_done=True))
         run(kernel, cs.make_env_args("flight_easy", n_agents=3), 4096, (100, 20), dict(freeze_done=False, auto_reset=True))
-        print(f"jitter build, {kernel}: bit-identical to the step kernel ({w} unpredicted wins handled)", flush=True)
+        print(f"{name}, {kernel}: bit-identical to the step kernel ({w} unpredicted wins handled)", flush=True)
 
 
 if __name__ == "__main__":

@@ -43,7 +43,8 @@ def test_staleness_is_decided_by_source_content_not_mtime(tmp_path, monkeypatch)
     as its ABI version matches."""
     from cooperative_search_amd import build
     L = _lib.load()
-    assert L.cs_source_hash().decode() == build.source_hash() == build._recorded_hash(build.LIB_PATH)
+    build_hash = L.cs_source_hash().decode()
+    assert build_hash == build.source_hash() == build._recorded_hash(build.LIB_PATH)
     assert not build.is_stale() and not build.torch_ops_stale()
     src = os.path.join(build.CSRC, "episodes.hip")
     st = os.stat(src)
@@ -57,9 +58,22 @@ def test_staleness_is_decided_by_source_content_not_mtime(tmp_path, monkeypatch)
     assert build.is_stale()
     monkeypatch.setattr(build, "hipcc_path", lambda: None)
     monkeypatch.setattr(_lib, "_lib", None)
-    with pytest.warns(RuntimeWarning, match="not built from the sources"):
+    monkeypatch.delenv("COOPSEARCH_STRICT", raising=False)
+    with pytest.warns(RuntimeWarning) as rec:
         L2 = _lib.load()
     assert L2.cs_abi_version() == _lib.ABI_VERSION
+    msgs = [str(w.message) for w in rec]
+    assert any("not built from the sources" in m for m in msgs)            # the sidecar's verdict, before dlopen
+    assert any("was built from sources with hash" in m and build_hash in m and "0" * 16 in m for m in msgs)   # the embedded hash's
+    # the EMBEDDED hash is the truth (a copied .so can carry any sidecar), and under COOPSEARCH_STRICT=1 -- what
+    # tests/conftest.py sets -- a library of other sources is an error: kernels change behaviour without touching the ABI version
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(build, "_recorded_hash", lambda path: "0" * 16)    # a sidecar that agrees with the (fake) sources
+    assert not build.is_stale()
+    monkeypatch.setenv("COOPSEARCH_STRICT", "1")
+    with pytest.raises(_lib.CoopSearchError, match="was built from sources with hash"):
+        _lib.load()
+    monkeypatch.delenv("COOPSEARCH_STRICT", raising=False)
     # ... and a missing library with no compiler is an error, not a fallback
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(build, "LIB_PATH", str(tmp_path / "libmissing.so"))

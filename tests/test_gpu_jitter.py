@@ -1,6 +1,15 @@
-"""The octet pair kernel's K / D / E hand-shakes under perturbed timing: a -DCS_JITTER build inserts pseudo-random
-pauses of up to two thirds of a step into every role at every counter read / post, so the wavefronts meet in interleavings the
-natural timing never produces; the results must stay bit-identical to the step kernel's."""
+"""The octet pair kernel's K / D / E hand-shakes under perturbed timing, and its counted wait without the counting
+(ADVICE r3).  Three one-team-size builds of the library, each compared bit for bit with the 16-lane step kernel of the same build
+(tests/jitter_child.py):
+  jitter_n3   -DCS_JITTER        pseudo-random pauses of up to two thirds of a step in every role at every counter read / post: the
+                                 wavefronts meet in interleavings the natural timing never produces;
+  odsafe_n3   -DCS_OD_SAFE_WAIT  D's wait for its asynchronous requests (a row of MT19937 words, a reset's first attempt batch, both
+                                 loaded straight into LDS a step ahead) is `s_waitcnt vmcnt(STEP_STORES)` in the shipped kernel -- it
+                                 rests on vector-memory operations retiring in order and on the number of stores issued after the
+                                 requests; here it is a full drain;
+  odsync_n3   -DCS_OD_ASYNC=0    no requests ahead of time at all: every row and every attempt batch is loaded where it is used.
+If the shipped kernel ever read LDS before a request had landed, it would differ from the step kernel where these two do not."""
+import concurrent.futures
 import os
 import subprocess
 import sys
@@ -9,30 +18,48 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-JITTER_LIB = os.path.join(ROOT, "build", "var", "jitter_n3.so")
+VARIANTS = {"jitter_n3": ["-DCS_JITTER"], "odsafe_n3": ["-DCS_OD_SAFE_WAIT"], "odsync_n3": ["-DCS_OD_ASYNC=0"]}
 
 
-def build_jitter_lib():
-    """hipcc -DCS_JITTER -DCS_ONLY_N=3 -> build/var/jitter_n3.so (also built by __graft_entry__.build(), so that it travels to
-    the GPU box); rebuilt when older than its sources."""
+def variant_path(name):
+    return os.path.join(ROOT, "build", "var", name + ".so")
+
+
+def build_variant(name):
+    """hipcc <flags> -DCS_ONLY_N=3 -> build/var/<name>.so (also built by __graft_entry__.build(), so that it travels to the GPU
+    box); rebuilt when older than its sources.  None when it is missing and there is no hipcc."""
     from cooperative_search_amd import build as b
+    lib = variant_path(name)
     srcs = [os.path.join(b.CSRC, s) for s in b.SOURCES] + b.HEADERS
-    if os.path.exists(JITTER_LIB) and all(os.path.getmtime(JITTER_LIB) >= os.path.getmtime(s) for s in srcs):
-        return JITTER_LIB
+    if os.path.exists(lib) and all(os.path.getmtime(lib) >= os.path.getmtime(s) for s in srcs):
+        return lib
     hipcc = b.hipcc_path()
     if hipcc is None:
-        return JITTER_LIB if os.path.exists(JITTER_LIB) else None
-    os.makedirs(os.path.dirname(JITTER_LIB), exist_ok=True)
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-DCS_JITTER",
-                           "-DCS_ONLY_N=3", "-I", os.path.join(ROOT, "include"), "coopsearch.hip", "policy.hip", "episodes.hip",
-                           "-o", JITTER_LIB], cwd=b.CSRC)
-    return JITTER_LIB
+        return lib if os.path.exists(lib) else None
+    os.makedirs(os.path.dirname(lib), exist_ok=True)
+    tmp = f"{lib}.tmp.{os.getpid()}"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"] + VARIANTS[name] +
+                          ["-DCS_ONLY_N=3", "-I", os.path.join(ROOT, "include"), "coopsearch.hip", "policy.hip", "episodes.hip", "-o", tmp],
+                          cwd=b.CSRC)
+    os.replace(tmp, lib)
+    return lib
 
 
-def test_pair_kernel_handshakes_survive_timing_jitter():
-    lib = build_jitter_lib()
+def build_all_variants():
+    """All three, side by side (each is one single-threaded hipcc run of ~2 minutes)."""
+    with concurrent.futures.ThreadPoolExecutor(max_workers=len(VARIANTS)) as ex:
+        return list(ex.map(build_variant, VARIANTS))
+
+
+def build_jitter_lib():   # (the name round 4's first version exported)
+    return build_variant("jitter_n3")
+
+
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_pair_kernel_variant_builds_equal_the_step_kernel(name):
+    lib = build_variant(name)
     if lib is None:
-        pytest.skip("no jitter build and no hipcc")
+        pytest.skip(f"no {name} build and no hipcc")
     env = dict(os.environ, COOPSEARCH_LIB=lib)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "jitter_child.py")], env=env, capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]

@@ -502,6 +502,38 @@ def test_octet_kernels_partial_outputs(kernel):
     assert torch.equal(e1.get_obs(), e2.get_obs()) and torch.equal(e1.get_state(), e2.get_state())
 
 
+@pytest.mark.parametrize("kernel", ["oct", "od", "lanev"])
+def test_rollout_output_alignment_rules(kernel):
+    """an (env, agent) observation is ONE 16-byte store in the octet and lane kernels, so cs_rollout refuses an obs table
+    that is not 16-byte aligned (include/coopsearch.h) instead of issuing misaligned dwordx4 stores; the state table may sit anywhere
+    -- off a 16-byte boundary it takes the scalar-store launch -- and must then hold exactly what the aligned run writes."""
+    B, n, T = 264, 3, 30
+    args = cs.make_env_args("flight_easy", n_agents=n)
+    args.time_limit = 25
+    seeds = np.arange(B, dtype=np.uint32) + 77
+    acts = torch.randint(0, 3, (T, B, n), dtype=torch.int32, device="cuda", generator=torch.Generator("cuda").manual_seed(5))
+    e1 = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, kernel=kernel, freeze_done=False, auto_reset=True)
+    e2 = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, kernel=kernel, freeze_done=False, auto_reset=True)
+    e3 = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, kernel=kernel, freeze_done=False, auto_reset=True)
+    full = e1.rollout(acts)
+    W = e1.state_shape
+
+    def off_by_one_float(shape):
+        flat = torch.zeros(int(np.prod(shape)) + 1, dtype=torch.float32, device="cuda")
+        view = flat[1:].view(*shape)
+        assert view.data_ptr() % 16 == 4 and view.is_contiguous()
+        return view
+
+    out = dict(reward=torch.empty_like(full["reward"]), terminated=torch.empty_like(full["terminated"]),
+               win=torch.empty_like(full["win"]), obs=torch.empty_like(full["obs"]), state=off_by_one_float((T, B, W)))
+    got = e2.rollout(acts, out=out)
+    for key in ("reward", "terminated", "win", "obs", "state"):
+        assert torch.equal(full[key], got[key]), key
+    bad = dict(out, obs=off_by_one_float((T, B, n, 4)), state=torch.empty_like(full["state"]))
+    with pytest.raises(Exception, match="obs_dev must be 16-byte aligned"):
+        e3.rollout(acts, out=bad)
+
+
 @pytest.mark.parametrize("n", [3, 5])
 def test_group_and_lane_kernels_can_be_interleaved(n):
     """Both kernels share one state layout (incl. the mirrored head of the MT rows that only the lane kernel reads

@@ -329,7 +329,7 @@ def _row_uniform(seed, step, rows):
         z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
         z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
         return z ^ (z >> 31)
-    return np.array([(mix64(seed ^ mix64(step & 0xFFFFFFFF) ^ mix64((int(r) * 0x9E3779B97F4A7C15) & M)) >> 40) / 16777216.0
+    return np.array([(mix64((mix64((mix64(seed & M) + (step & 0xFFFFFFFF)) & M) + int(r) * 0x9E3779B97F4A7C15) & M) >> 40) / 16777216.0
                      for r in rows], dtype=np.float64)
 
 

@@ -32,3 +32,9 @@ dt = st[5:60, 9] - st[5:60, 8]
 print("  D top per step:", [int(v) for v in dt])
 dp = st[5:60, 12] - st[5:60, 11]
 print("  D publish per step:", [int(v) for v in dp])
+# resets (steps whose top-up / reset phase is long): placement (incl. E3's wait for E before the tile is touched) / bookkeeping + barrier /
+# near test + reset-time detection pass
+ev = [i for i in range(5, 60) if st[i, 9] - st[i, 8] > 2000 and st[i, 13] >= st[i, 8] and st[i, 15] <= st[i, 9]]
+for i in ev:
+    print(f"  reset at D step {i}: before {st[i, 13] - st[i, 8]}  placement {st[i, 14] - st[i, 13]}  top-up + barrier {st[i, 15] - st[i, 14]}"
+          f"  near test / detection pass {st[i, 9] - st[i, 15]}  total {st[i, 9] - st[i, 8]}")
