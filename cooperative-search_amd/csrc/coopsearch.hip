@@ -1969,6 +1969,9 @@ void k_rollout_policy(DevParams p, StepIO io, PolicyIO pio) {
     const float bias1 = pio.w[PO_B1 + col], bias2 = pio.w[PO_B2 + col];
     const float bir = pio.w[PO_BIH + col], biz = pio.w[PO_BIH + 64 + col], bin = pio.w[PO_BIH + 128 + col];
     const float bhr = pio.w[PO_BHH + col], bhz = pio.w[PO_BHH + 64 + col], bhn = pio.w[PO_BHH + 128 + col];
+#if CS_POLICY_F16
+    const float b_r = bir + bhr, b_z = biz + bhz;   // the r and z gates run as one chain over [x | h] with one bias (gru_cell)
+#endif
     if (threadIdx.x < 16) s_b3[threadIdx.x] = pio.w[PO_B3 + threadIdx.x];
     if (threadIdx.x < BLOCK / G)
         s_eps[threadIdx.x] = (pio.eps_dev && b0 + (int)threadIdx.x < p.B) ? pio.eps_dev[b0 + threadIdx.x] : pio.epsilon;
@@ -2040,48 +2043,32 @@ void k_rollout_policy(DevParams p, StepIO io, PolicyIO pio) {
         _Float16 *hn_hi = hs_base + (size_t)((s + 1) & 1) * 2 * ROWS * HST, *hn_lo = hn_hi + ROWS * HST;    // hidden state out
         float *s_q = reinterpret_cast<float *>(hc_hi);   // [ROWS][17] floats (68 B per row <= a plane's 144 B), written after the GRU
 #pragma unroll
-        for (int m = 0; m < N; m++) {   // h1 = relu(W1 x + b1), columns 16w..16w+15 of every row tile
-            f32x4 hi = zero, lo = zero;
+        for (int m = 0; m < N; m++) {   // h1 = relu(W1 x + b1), columns 16w..16w+15 of every row tile (the bias enters the accumulator)
+            f32x4 hi = splat4(bias1), lo = zero;
             h8 ah, al;
             load_afrag<HXS>(x_hi, x_lo, 16 * m, 0, lane, ah, al);
             mfma_split(ah, al, b1, hi, lo);
 #pragma unroll
             for (int r = 0; r < 4; r++)
-                split_store(b_hi, b_lo, (16 * m + crow + r) * HST + col, fmaxf(split_sum(hi[r], lo[r]) + bias1, 0.0f));
+                split_store(b_hi, b_lo, (16 * m + crow + r) * HST + col, fmaxf(split_sum(hi[r], lo[r]), 0.0f));
         }
         LANE_STAMP(8);
         __syncthreads();
         LANE_STAMP(9);
 #pragma unroll
-        for (int m = 0; m < N; m++) {   // GRUCell: per row tile the six chains in k_policy_h's order
-            f32x4 hi[6], lo[6];
-#pragma unroll
-            for (int c = 0; c < 6; c++) hi[c] = lo[c] = zero;
-            // gate by gate (r, z, n), both k-steps of a gate's two chains together: the r and z chains are complete while the matrix
-            // pipe still works on n, and their sigmoids issue in its shadow (each chain's own summation order is unchanged)
+        for (int m = 0; m < N; m++) {   // GRUCell of row tile m (gru_products / gru_cell: the very code k_policy_h runs)
             h8 xh[2], xl[2], hh[2], hl[2];
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
                 load_afrag(b_hi, b_lo, 16 * m, ks, lane, xh[ks], xl[ks]);
                 load_afrag(hc_hi, hc_lo, 16 * m, ks, lane, hh[ks], hl[ks]);
             }
-#pragma unroll
-            for (int g = 0; g < 3; g++)
-#pragma unroll
-                for (int ks = 0; ks < 2; ks++) {
-                    mfma_split(xh[ks], xl[ks], bg[2 * g][ks], hi[2 * g], lo[2 * g]);
-                    mfma_split(hh[ks], hl[ks], bg[2 * g + 1][ks], hi[2 * g + 1], lo[2 * g + 1]);
-                }
+            GruAcc acc;
+            gru_products(xh, xl, hh, hl, bg, b_r, b_z, bin, bhn, acc);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const float ir = split_sum(hi[0][r], lo[0][r]), hr = split_sum(hi[1][r], lo[1][r]);
-                const float iz = split_sum(hi[2][r], lo[2][r]), hz = split_sum(hi[3][r], lo[3][r]);
-                const float in_ = split_sum(hi[4][r], lo[4][r]), hn_ = split_sum(hi[5][r], lo[5][r]);
-                const float rg = sigmoidf_((ir + bir) + (hr + bhr));
-                const float zg = sigmoidf_((iz + biz) + (hz + bhz));
-                const float ng = tanhf_((in_ + bin) + rg * (hn_ + bhn));
                 const int o = 16 * m + crow + r;
-                const float hnew = (1.0f - zg) * ng + zg * s_h[o * LDW + col];
+                const float hnew = gru_cell(acc, r, s_h[o * LDW + col]);
                 s_h[o * LDW + col] = hnew;                          // (this thread's own element)
                 split_store(hn_hi, hn_lo, o * HST + col, hnew);     // h' for fc2 and for the next step's GRU
             }
@@ -2091,7 +2078,7 @@ void k_rollout_policy(DevParams p, StepIO io, PolicyIO pio) {
         LANE_STAMP(11);
 #pragma unroll
         for (int m = 0; m < N; m++) {   // f = relu(W2 h' + b2)
-            f32x4 hi = zero, lo = zero;
+            f32x4 hi = splat4(bias2), lo = zero;
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
                 h8 ah, al;
@@ -2100,7 +2087,7 @@ void k_rollout_policy(DevParams p, StepIO io, PolicyIO pio) {
             }
 #pragma unroll
             for (int r = 0; r < 4; r++)
-                split_store(b_hi, b_lo, (16 * m + crow + r) * HST + col, fmaxf(split_sum(hi[r], lo[r]) + bias2, 0.0f));
+                split_store(b_hi, b_lo, (16 * m + crow + r) * HST + col, fmaxf(split_sum(hi[r], lo[r]), 0.0f));
         }
         LANE_STAMP(12);
         __syncthreads();   // f complete
@@ -2110,7 +2097,7 @@ void k_rollout_policy(DevParams p, StepIO io, PolicyIO pio) {
 #pragma unroll
         for (int m = 0; m < N; m++) {
             if ((m & 3) != w) continue;   // wave-uniform
-            f32x4 hi = zero, lo = zero;
+            f32x4 hi = splat4(s_b3[ccol]), lo = zero;
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
                 h8 ah, al;
@@ -2118,7 +2105,7 @@ void k_rollout_policy(DevParams p, StepIO io, PolicyIO pio) {
                 mfma_split(ah, al, b3[ks], hi, lo);
             }
 #pragma unroll
-            for (int r = 0; r < 4; r++) s_q[(16 * m + crow + r) * 17 + ccol] = split_sum(hi[r], lo[r]) + s_b3[ccol];
+            for (int r = 0; r < 4; r++) s_q[(16 * m + crow + r) * 17 + ccol] = split_sum(hi[r], lo[r]);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -256,6 +256,7 @@ __global__ __launch_bounds__(PBLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const float bias1 = p.w[HOFF_B1 + col], bias2 = p.w[HOFF_B2 + col];
     const float bir = p.w[HOFF_BIH + col], biz = p.w[HOFF_BIH + 64 + col], bin = p.w[HOFF_BIH + 128 + col];
     const float bhr = p.w[HOFF_BHH + col], bhz = p.w[HOFF_BHH + 64 + col], bhn = p.w[HOFF_BHH + 128 + col];
+    const float b_r = bir + bhr, b_z = biz + bhz;   // the r and z gates run as one chain over [x | h] with one bias (gru_cell)
 
     // staging: 16 threads per row, two input columns (k, k + 16) and four hidden values each.  Input row (agent.py:41-52,
     // base_net.py:31-39): [16 conv features |] obs(4) | one_hot(last action) | one_hot(agent id), zero up to column 32; raw mode
@@ -319,41 +320,29 @@ __global__ __launch_bounds__(PBLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         __syncthreads();
         POL_STAMP(1);
 
-        {   // h1 = relu(W1 x + b1), columns 16w..16w+15
-            f32x4 hi = zero, lo = zero;
+        {   // h1 = relu(W1 x + b1), columns 16w..16w+15 (the bias enters the accumulator)
+            f32x4 hi = splat4(bias1), lo = zero;
             h8 ah, al;
             load_afrag(s_a[0], s_a[1], 0, 0, lane, ah, al);
             mfma_split(ah, al, b1, hi, lo);
 #pragma unroll
-            for (int r = 0; r < 4; r++) split_store(s_b[0], s_b[1], (crow + r) * HST + col, fmaxf(split_sum(hi[r], lo[r]) + bias1, 0.0f));
+            for (int r = 0; r < 4; r++) split_store(s_b[0], s_b[1], (crow + r) * HST + col, fmaxf(split_sum(hi[r], lo[r]), 0.0f));
         }
         __syncthreads();
         POL_STAMP(2);
 
-        {   // GRUCell, columns 16w..16w+15: six independent chains (an accumulator pair each), interleaved
-            f32x4 hi[6], lo[6];
-#pragma unroll
-            for (int c = 0; c < 6; c++) hi[c] = lo[c] = zero;
+        {   // GRUCell, columns 16w..16w+15 (gru_products / gru_cell of policy_dev.h: the very code the fused closed loop runs)
+            h8 xh[2], xl[2], hh[2], hl[2];
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
-                h8 xh, xl, hh, hl;
-                load_afrag(s_b[0], s_b[1], 0, ks, lane, xh, xl);
-                load_afrag(s_hs[0], s_hs[1], 0, ks, lane, hh, hl);
-#pragma unroll
-                for (int g = 0; g < 3; g++) {
-                    mfma_split(xh, xl, bg[2 * g][ks], hi[2 * g], lo[2 * g]);
-                    mfma_split(hh, hl, bg[2 * g + 1][ks], hi[2 * g + 1], lo[2 * g + 1]);
-                }
+                load_afrag(s_b[0], s_b[1], 0, ks, lane, xh[ks], xl[ks]);
+                load_afrag(s_hs[0], s_hs[1], 0, ks, lane, hh[ks], hl[ks]);
             }
+            GruAcc acc;
+            gru_products(xh, xl, hh, hl, bg, b_r, b_z, bin, bhn, acc);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const float ir = split_sum(hi[0][r], lo[0][r]), hr = split_sum(hi[1][r], lo[1][r]);
-                const float iz = split_sum(hi[2][r], lo[2][r]), hz = split_sum(hi[3][r], lo[3][r]);
-                const float in_ = split_sum(hi[4][r], lo[4][r]), hn_ = split_sum(hi[5][r], lo[5][r]);
-                const float rg = sigmoidf_((ir + bir) + (hr + bhr));
-                const float zg = sigmoidf_((iz + biz) + (hz + bhz));
-                const float ng = tanhf_((in_ + bin) + rg * (hn_ + bhn));
-                const float hnew = (1.0f - zg) * ng + zg * s_h[(crow + r) * LDW + col];
+                const float hnew = gru_cell(acc, r, s_h[(crow + r) * LDW + col]);
                 split_store(s_a[0], s_a[1], (crow + r) * HST + col, hnew);  // s_a (x) was last read before the previous barrier
                 if (row0 + crow + r < p.rows) p.hidden[(size_t)(row0 + crow + r) * H + col] = hnew;
             }
@@ -362,7 +351,7 @@ __global__ __launch_bounds__(PBLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         POL_STAMP(3);
 
         {   // f = relu(W2 h' + b2), columns 16w..16w+15
-            f32x4 hi = zero, lo = zero;
+            f32x4 hi = splat4(bias2), lo = zero;
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
                 h8 ah, al;
@@ -370,7 +359,7 @@ __global__ __launch_bounds__(PBLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 mfma_split(ah, al, b2[ks], hi, lo);
             }
 #pragma unroll
-            for (int r = 0; r < 4; r++) split_store(s_b[0], s_b[1], (crow + r) * HST + col, fmaxf(split_sum(hi[r], lo[r]) + bias2, 0.0f));
+            for (int r = 0; r < 4; r++) split_store(s_b[0], s_b[1], (crow + r) * HST + col, fmaxf(split_sum(hi[r], lo[r]), 0.0f));
         }
         __syncthreads();
         POL_STAMP(4);
@@ -378,7 +367,7 @@ __global__ __launch_bounds__(PBLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         // q = W3 f + b3 and the choice, by ONE wavefront (no K split, no exchange of partial sums, no barrier: the other wavefronts go
         // on to the next tile's staging, which touches neither s_b nor s_q; wavefront 0 joins the next barrier when it is done)
         if (w == 0) {
-            f32x4 hi = zero, lo = zero;
+            f32x4 hi = splat4(s_b3[ccol]), lo = zero;
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
                 h8 ah, al;
@@ -390,7 +379,7 @@ __global__ __launch_bounds__(PBLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 mfma_split(ah, al, b3, hi, lo);
             }
 #pragma unroll
-            for (int r = 0; r < 4; r++) s_q[0][(crow + r) * 17 + ccol] = split_sum(hi[r], lo[r]) + s_b3[ccol];
+            for (int r = 0; r < 4; r++) s_q[0][(crow + r) * 17 + ccol] = split_sum(hi[r], lo[r]);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

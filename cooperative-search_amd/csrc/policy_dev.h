@@ -30,12 +30,12 @@ constexpr int PACKED_FLOATS_F32 = OFF_B3 + 16;
 // Split-fp16 matrix path (default).  The fp32 matrix pipe (v_mfma_f32_16x16x4_f32) runs at the vector rate, 1/16 of the 16-bit
 // rate, and at 92 kFLOP per env-step it caps the closed loop at ~1.7e9 env-steps/s however fast the env is.  Here every fp32
 // operand v is carried as TWO fp16 numbers, v = hi + lo / 2048 with hi = fp16(v) and lo = fp16((v - hi) * 2048) -- 22 significant
-// bits, the low part pre-scaled so that it never falls into fp16's subnormal range -- and a product a*b is evaluated as
+// bits, the low part pre-scaled so that it stays in fp16's normal range wherever hi is normal -- and a product a*b is evaluated as
 //     a_hi*b_hi + (a_lo*b_hi + a_hi*b_lo) / 2048
 // with three v_mfma_f32_16x16x32_f16 (exact fp16 products, fp32 accumulation; the dropped a_lo*b_lo term is 2^-22 relative):
 // three matrix instructions per K = 32 instead of eight fp32 ones per K = 32, each ~17 instead of 32 cycles -- 5x the rate at
 // an error of ~2.4e-7 per product, two orders below the 2e-5 parity bar with the reference network (network/base_net.py:31-46).
-// Values below fp16's normal range (6.1e-5) go entirely to the scaled low part, so no subnormal is ever handed to the matrix pipe.
+// Values below fp16's normal range (6.1e-5) become subnormal halves; the matrix pipe multiplies those exactly (see split_f16).
 // ---------------------------------------------------------------------------------------------------------------------------
 #ifndef CS_POLICY_F16
 #define CS_POLICY_F16 1
@@ -62,9 +62,21 @@ constexpr int PACKED_FLOATS_F16 = HOFF_B3 + 16;
 constexpr int PACKED_FLOATS = CS_POLICY_F16 ? PACKED_FLOATS_F16 : PACKED_FLOATS_F32;
 
 // v -> (hi, lo) of the split representation (same code on the host for the weights, cs_policy_pack)
+// hi = fp16(v) whatever v's size: the gfx950 matrix pipe takes SUBNORMAL fp16 inputs exactly (tools/mfma_f16_denorm.hip, run by
+// tests/test_gpu_mfma_denorm.py: products of subnormal halves against the fp64 sum, 1.4e-7 = the fp32 accumulation).  The first
+// version zeroed hi below fp16's normal range "so that no subnormal is handed to the matrix pipe": a compare and a select per stored
+// element in phases that are bound by VALU issue (closed loop 5.90 -> 6.11e8 without them).  -DCS_SPLIT_GUARD=1 brings the guard back
+// for a pipe that flushes.
+#ifndef CS_SPLIT_GUARD
+#define CS_SPLIT_GUARD 0
+#endif
 __host__ __device__ __forceinline__ void split_f16(float v, _Float16 &hi, _Float16 &lo) {
+#if CS_SPLIT_GUARD
     const float a = v < 0.0f ? -v : v;
     hi = a < F16_MIN_NORMAL ? (_Float16)0.0f : (_Float16)v;
+#else
+    hi = (_Float16)v;
+#endif
     lo = (_Float16)((v - (float)hi) * LO_SCALE);
 }
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
@@ -111,6 +123,51 @@ __device__ __forceinline__ float split_sum(float hi, float lo) { return __builti
 // instructions each, and VALU work competes with the co-resident block's MFMAs for the SIMD.
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+
+#if CS_POLICY_F16 && (defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__))
+// GRUCell (torch.nn.GRUCell: gates r, z, n in weight_ih / weight_hh) of one 16-row tile for a wavefront's 16 hidden columns, shared by
+// k_policy_h and the fused closed loop so that both walk the SAME products in the SAME order (their actions must agree bit for bit).
+//   r = sigmoid(W_ir x + b_ir + W_hr h + b_hr), z likewise: ONE accumulator chain each over [x | h] (K = 128: x's two k-steps, then
+//   h's) and ONE bias (b_i + b_h, summed once per kernel) -- the first version kept W_i x and W_h h apart and paid two accumulator
+//   reads, a split sum and two additions more per output element and gate, in a phase that is bound by VALU issue;
+//   n = tanh(W_in x + b_in + r * (W_hn h + b_hn)): the two halves stay apart, r multiplies the hidden half only.
+// bg[2 g][ks] / bg[2 g + 1][ks]: fragments of W_i / W_h of gate g, k-step ks.
+struct GruAcc {
+    f32x4 r_hi, r_lo, z_hi, z_lo, in_hi, in_lo, hn_hi, hn_lo;
+};
+__device__ __forceinline__ f32x4 splat4(float v) { return f32x4{v, v, v, v}; }
+// b_r = b_ir + b_hr, b_z = b_iz + b_hz.  Every bias ENTERS its accumulator (a lane's four elements are four rows of one column: one
+// bias value) instead of being added to the finished sum: no bias addition in the epilogue at all.
+__device__ __forceinline__ void gru_products(const h8 (&xh)[2], const h8 (&xl)[2], const h8 (&hh)[2], const h8 (&hl)[2],
+                                             const BFrag (&bg)[6][2], float b_r, float b_z, float b_in, float b_hn, GruAcc &a) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    a.r_hi = splat4(b_r);
+    a.z_hi = splat4(b_z);
+    a.in_hi = splat4(b_in);
+    a.hn_hi = splat4(b_hn);
+    a.r_lo = a.z_lo = a.in_lo = a.hn_lo = zero;
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) mfma_split(xh[ks], xl[ks], bg[0][ks], a.r_hi, a.r_lo);
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) mfma_split(hh[ks], hl[ks], bg[1][ks], a.r_hi, a.r_lo);
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) mfma_split(xh[ks], xl[ks], bg[2][ks], a.z_hi, a.z_lo);
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) mfma_split(hh[ks], hl[ks], bg[3][ks], a.z_hi, a.z_lo);
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) mfma_split(xh[ks], xl[ks], bg[4][ks], a.in_hi, a.in_lo);
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) mfma_split(hh[ks], hl[ks], bg[5][ks], a.hn_hi, a.hn_lo);
+}
+// new hidden value of element r (0..3: the lane's four rows) from the tile's accumulators: h' = n + z (h - n), n = tanh(i_n + r h_n)
+// (each a single fma: the translation unit is compiled without contraction, so they are written out)
+__device__ __forceinline__ float gru_cell(const GruAcc &a, int r, float h_prev) {
+    const float rg = sigmoidf_(split_sum(a.r_hi[r], a.r_lo[r]));
+    const float zg = sigmoidf_(split_sum(a.z_hi[r], a.z_lo[r]));
+    const float ng = tanhf_(__builtin_fmaf(rg, split_sum(a.hn_hi[r], a.hn_lo[r]), split_sum(a.in_hi[r], a.in_lo[r])));
+    return __builtin_fmaf(zg, h_prev - ng, ng);
+}
+#endif
 
 // splitmix64: per-row uniform for the epsilon-greedy choice (the reference draws from numpy's global stream on the
 // host; any iid uniform source is equivalent)

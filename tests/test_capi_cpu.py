@@ -188,8 +188,8 @@ def test_c_example_compiles_and_links_against_the_abi(tmp_path, example):
 
 
 def test_policy_pack_layout_host_only():
-    """cs_policy_pack is pure host code.  Split-fp16 layout (csrc/policy_dev.h): every weight w travels as hi = fp16(w) (0 below
-    fp16's normal range) and lo = fp16((w - hi) * 2048); fragment (column tile nt, k-step ks of 32) is the hi plane then the lo
+    """cs_policy_pack is pure host code.  Split-fp16 layout (csrc/policy_dev.h): every weight w travels as hi = fp16(w) (subnormal
+    below fp16's normal range) and lo = fp16((w - hi) * 2048); fragment (column tile nt, k-step ks of 32) is the hi plane then the lo
     plane, each [64 lanes][8 halves] with lane l, j holding W[16 nt + (l & 15)][32 ks + 8 (l >> 4) + j] -- the B operand of one
     16x16x32 MFMA --, zero padded; fp32 biases follow.  hi + lo / 2048 reproduces the weight to 22 bits."""
     import ctypes as C
@@ -207,7 +207,7 @@ def test_policy_pack_layout_host_only():
     lanes = np.arange(64)
 
     def split(w):
-        hi = np.where(np.abs(w) < np.float32(6.2e-5), np.float16(0), w.astype(np.float16))
+        hi = w.astype(np.float16)   # subnormal halves included: the matrix pipe takes them exactly (tests/test_gpu_mfma_denorm.py)
         lo = ((w - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
         return hi, lo
 
