@@ -297,20 +297,25 @@ def cpu_baseline_inproc(env_name, n, batch, budget_s=10.0):
         # spread and is not the baseline: GPU boxes are slices of a shared 8-GPU host, and above ~16-32 threads the regions
         # of the same pinned team were 4x apart while the per-thread rate up to 16 threads repeats to 2 % box after box
         top = sorted(cands, key=lambda th: scaling[str(th)], reverse=True)[:3]
-        points = {}
-        for th in top:
-            per = B * T * R / scaling[str(th)]
-            n_rep = int(max(10, min(5000, budget_s / len(top) / max(per, 1e-6))))
-            t0 = time.perf_counter()
-            rates = regions(th, n_rep)
-            d = time.perf_counter() - t0
-            q = statistics.quantiles(rates, n=10)
-            v = statistics.median(rates)
-            scaling[str(th)] = v
-            points[th] = {"p10": q[0], "median": v, "p90": q[-1], "span": q[-1] / q[0] if q[0] > 0 else float("inf"),
-                          "regions": n_rep, "wall_s": d}
-        steady = [th for th in top if points[th]["span"] < STEADY_SPAN]
-        best = max(steady, key=lambda th: points[th]["median"]) if steady else min(top, key=lambda th: points[th]["span"])
+        points, steady, attempts = {}, [], 0
+        # a pass in which the largest team does not hold together (a neighbour's burst on the shared host) is repeated, twice at
+        # most, before a smaller team's figure is taken: the smaller teams are steadier but a different number
+        while top[0] not in steady and attempts < 3:
+            attempts += 1
+            for th in top:
+                per = B * T * R / scaling[str(th)]
+                n_rep = int(max(10, min(5000, budget_s / len(top) / max(per, 1e-6))))
+                t0 = time.perf_counter()
+                rates = regions(th, n_rep)
+                d = time.perf_counter() - t0
+                q = statistics.quantiles(rates, n=10)
+                v = statistics.median(rates)
+                scaling[str(th)] = v
+                points[th] = {"p10": q[0], "median": v, "p90": q[-1], "span": q[-1] / q[0] if q[0] > 0 else float("inf"),
+                              "regions": n_rep, "wall_s": d}
+            steady = [th for th in top if points[th]["span"] < STEADY_SPAN]
+        # none steady even then: the FASTEST point, flagged -- the one that moves least from run to run
+        best = max(steady, key=lambda th: points[th]["median"]) if steady else max(top, key=lambda th: points[th]["median"])
     finally:
         orc.set_exact_pow(True)
     pt = points[best]
@@ -323,7 +328,7 @@ def cpu_baseline_inproc(env_name, n, batch, budget_s=10.0):
                       f"{top} whose regions span < {STEADY_SPAN}x; calibrated over {cands}), auto-reset, "
                       f"obs+state emitted, {pt['wall_s']:.1f} s wall on {cpu_model()} ({os.cpu_count()} logical CPUs, {n_cores} physical cores)",
             "region_rate_p10_median_p90": [pt["p10"], pt["median"], pt["p90"]], "statistic": "median over the timed regions",
-            "p90_over_p10": pt["span"], "steady": bool(steady),
+            "p90_over_p10": pt["span"], "steady": bool(steady), "passes": attempts,
             "measured_points": {str(th): [points[th]["p10"], points[th]["median"], points[th]["p90"]] for th in top},
             "faster_but_unsteady": faster or None,
             "pinning": {"OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES"),

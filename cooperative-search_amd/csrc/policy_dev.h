@@ -70,14 +70,28 @@ constexpr int PACKED_FLOATS = CS_POLICY_F16 ? PACKED_FLOATS_F16 : PACKED_FLOATS_
 #ifndef CS_SPLIT_GUARD
 #define CS_SPLIT_GUARD 0
 #endif
+// float -> half, round to nearest even, subnormal results kept: the instruction is PINNED on the device.  Written as a C cast, the
+// conversions of split_f16 came out of the compiler differently in k_policy_h and in the fused loop once the subnormal guard was
+// gone, and the two kernels' hidden states -- which must agree bit for bit -- differed by an ulp in rare elements after ~50 steps
+// (values below fp16's normal range; v_cvt_f16_f32 and v_cvt_pk_f16_f32 themselves agree on every input tried).  With the
+// instruction pinned they agree again (tests/test_gpu_policy.py::test_fused_closed_loop_rollout_equals_stepwise, 200 steps).
+__host__ __device__ __forceinline__ _Float16 cvt_half(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    _Float16 h;
+    asm("v_cvt_f16_f32 %0, %1" : "=v"(h) : "v"(v));
+    return h;
+#else
+    return (_Float16)v;
+#endif
+}
 __host__ __device__ __forceinline__ void split_f16(float v, _Float16 &hi, _Float16 &lo) {
 #if CS_SPLIT_GUARD
     const float a = v < 0.0f ? -v : v;
     hi = a < F16_MIN_NORMAL ? (_Float16)0.0f : (_Float16)v;
 #else
-    hi = (_Float16)v;
+    hi = cvt_half(v);
 #endif
-    lo = (_Float16)((v - (float)hi) * LO_SCALE);
+    lo = cvt_half((v - (float)hi) * LO_SCALE);
 }
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
 // one element of a split activation plane pair in LDS (planes: [rows][HST] halves)
