@@ -3826,6 +3826,24 @@ struct __attribute__((aligned(16))) OdSharedT {
     double rtab[4 * G];                      // the reset's target tables (load_reset_tab)
 };
 
+// CS_OD_E_REFRESH (three-wavefront variant): E, which has most of a step to spare, does the MT19937 row refreshes instead of D.
+// D posts (env, cursor, twisted words ahead) and goes on drawing from the env's old tape, which covers the words still ahead; E loads
+// the row, twists it ahead of THAT cursor (the words it writes lie behind the cursor D reads from, in ring order), computes the
+// 320-slot hit tape and posts it; D adopts it at a step boundary, shifted by the slots it consumed meanwhile.  One request at a time;
+// anything that needs the row itself (a reset, an on-the-spot top-up) first waits for the outstanding one.
+#ifndef CS_OD_E_REFRESH
+#define CS_OD_E_REFRESH 1   /* measured: c2 3.17 -> 3.30e9 at 100 steps per launch, 1.75 -> 1.79e9 at 20; c5's 8192-env shard 3.77 -> 4.00e9 */
+#endif
+template <bool ON>
+struct __attribute__((aligned(16))) OdRefreshT {
+    int rf_req, rf_done;                     // D -> E: sequence number of the latest request / E -> D: ... of the latest one served
+    int rf_env, rf_pos, rf_ahead;            // the request: octet, cursor, twisted words ahead of it
+    int d_done;                              // D -> E: no further requests (E's exit condition)
+    int pad[2];
+    unsigned rf_tape[TAPE_DW + 2];           // E -> D: hit bits of the 312 slots from rf_pos
+    unsigned erow[ON ? MT_N + 16 : 4];       // E's row buffer
+};
+
 // The pair's counters are plain LDS words written and polled with hand-placed ds instructions.  The LDS serves one
 // wavefront's accesses in order, so slot data written before a counter is visible to whoever has seen the counter; nothing
 // else is needed -- and anything else costs: a workgroup-scope release fence, and even a relaxed workgroup-scope atomic store,
@@ -3893,6 +3911,8 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
     using OdShared = OdSharedT<OD_RING>;
     __shared__ OdShared sh;
     __shared__ OdOut outs[E3 ? OD_RING : 1];
+    constexpr bool EREF = E3 && (CS_OD_E_REFRESH != 0);
+    __shared__ OdRefreshT<EREF> rf;
     int &e_steps = sh.e_steps;
     const int lane = threadIdx.x & 63;
     // Which wavefront of the workgroup plays which role decides who shares a SIMD: at 4096 envs a CU holds two workgroups,
@@ -4122,11 +4142,46 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
         int chunk[Q];
 #pragma unroll
         for (int q = 0; q < Q; q++) chunk[q] = lane + 64 * q < OCT_ENVS * W / 4 - 1 ? lane + 64 * q : OCT_ENVS * W / 4 - 1;
+        int rf_served = 0;
+        auto rf_serve = [&]() __attribute__((always_inline)) {   // EREF: a row refresh for D, if one is asked for
+            const int seq = peek(&rf.rf_req);
+            if (__builtin_expect(seq == rf_served, 1)) return;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int g = __builtin_amdgcn_readfirstlane(rf.rf_env), pos = __builtin_amdgcn_readfirstlane(rf.rf_pos);
+            const int a = __builtin_amdgcn_readfirstlane(rf.rf_ahead);
+            unsigned *m = OD_COLD().mt + (size_t)(wave_b0 + g) * MT_STRIDE;
+            RowRegs rr;
+            row_load(m, lane, rr);
+            row_to_lds(rr, rf.erow, lane);
+            row_twist_ahead(rf.erow, m, pos, a < 0 ? 0 : a, lane);
+#pragma unroll
+            for (int it = 0; it < TAPE_DW / 2; it++) {
+                const unsigned long long bm = row_slot_hits(OD_COLD(), rf.erow, pos, it, lane);
+                if (lane == 0) {
+                    rf.rf_tape[2 * it] = (unsigned)(bm & 0xffffffffull);
+                    rf.rf_tape[2 * it + 1] = (unsigned)(bm >> 32);
+                }
+            }
+            drain_vmem();   // the new words are in memory before D learns of them (its resets read stream words from there)
+            {
+                const int s = seq;   // (the jitter hash's step)
+                (void)s;
+                OD_JITTER(11);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            if (lane == 0) lds_post(&rf.rf_done, seq);
+            rf_served = seq;
+        };
         for (int s = 0; s < io.T; s++) {
             asm volatile("" : "+v"(t));
             ag = t < N;
             OD_JITTER(3);
-            while (peek(&sh.d_steps) <= s) { SPIN_TICK; __builtin_amdgcn_s_sleep(1); }   // D has judged step s: its record and K's slot are final
+            if (EREF) rf_serve();
+            while (peek(&sh.d_steps) <= s) {   // D has judged step s: its record and K's slot are final
+                if (EREF) rf_serve();           // (D may be waiting for the refresh before it can finish the step)
+                SPIN_TICK;
+                __builtin_amdgcn_s_sleep(1);
+            }
             OD_JITTER(4);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const OdRing &r = sh.ring[s & (OD_RING - 1)];
@@ -4174,6 +4229,13 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
             OD_JITTER(5);
             if (lane == 0) lds_post(&e_steps, s + 1);
         }
+        if (EREF) {   // D may still ask until its loop has ended (it waits for every answer before it says so)
+            for (;;) {
+                rf_serve();
+                if (peek(&rf.d_done)) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
         SPIN_STORE(2);
         return;
     }
@@ -4203,6 +4265,9 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
         sh.fix_ack = 0;
         sh.fix_mask = 0u;
         e_steps = 0;
+        rf.rf_req = 0;
+        rf.rf_done = 0;
+        rf.d_done = 0;
     }
     load_reset_tab(sh.rtab, lane);
     load_trig_to_lds(T);   // (K's table; D only joins its barrier -- after which K produces ahead, up to OD_RING steps)
@@ -4276,6 +4341,35 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
     };
     int cand = -1;                       // env (octet) of the wavefront whose row is on its way into sh.rowbuf
     int ack_wait = 0;                    // fix request of the previous step that K has yet to acknowledge (0: none)
+    // EREF: the refresh E is working on
+    int rf_seq = 0, rf_pending = -1;     // sequence number of the latest request; octet it is for (-1: none outstanding)
+    unsigned long long rf_words0 = 0ull; // this lane's env's word count when the request was posted
+    auto rf_poll = [&](bool wait) __attribute__((always_inline)) {   // adopt E's answer (wait: stay until it is there)
+        if (rf_pending < 0) return;
+        if (wait) {
+            {
+                const int s = rf_seq;   // (the jitter hash's step)
+                (void)s;
+                OD_JITTER(12);
+            }
+            while (peek(&rf.rf_done) != rf_seq) __builtin_amdgcn_s_sleep(1);
+        } else if (peek(&rf.rf_done) != rf_seq) {
+            return;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        unsigned nt[TAPE_DW];
+#pragma unroll
+        for (int k = 0; k < TAPE_DW; k++) nt[k] = rf.rf_tape[k];
+        const int c = (int)((e.words - rf_words0) >> 1);   // draw slots this lane's env has consumed since the request
+        tape_shift<8>(nt, c);
+        if (o == rf_pending) {
+#pragma unroll
+            for (int k = 0; k < TAPE_DW; k++) tape[k] = nt[k];
+            e.ahead = MT_N - 2 * c;
+            tape_ok = true;
+        }
+        rf_pending = -1;
+    };
     unsigned long long pre_need = 0ull;  // the reset mask sh.prebuf was filled for
     unsigned pre_valid = 0u;             // bit g: 16-lane group g's attempt batch is (on its way) in sh.prebuf
     oct_wave_advance<N, CS_OD_DRAIN != 0>(p, wave_b0, nvalid, lane, io.min_ahead > LOW ? io.min_ahead : LOW, sh.rowbuf, e, tape, tape_ok);   // while K produces step 0
@@ -4303,8 +4397,12 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
             oct_advance_finish<N>(OD_COLD(), wave_b0, cand, lane, sh.rowbuf, e, tape, tape_ok);
             cand = -1;
         }
-        if (__builtin_expect(__ballot(live && e.ahead < LOW) != 0ull, 0))   // could not wait for its turn
-            oct_wave_advance<N, CS_OD_DRAIN != 0>(OD_COLD(), wave_b0, nvalid, lane, LOW, sh.rowbuf, e, tape, tape_ok);
+        if (EREF) rf_poll(false);
+        if (__builtin_expect(__ballot(live && e.ahead < LOW) != 0ull, 0)) {   // could not wait for its turn
+            if (EREF) rf_poll(true);   // (E may be at this very row; and its answer may be all that was needed)
+            if (!EREF || __ballot(live && e.ahead < LOW) != 0ull)
+                oct_wave_advance<N, CS_OD_DRAIN != 0>(OD_COLD(), wave_b0, nvalid, lane, LOW, sh.rowbuf, e, tape, tape_ok);
+        }
         bool done = e.target_find >= p.n_targets || e.time_step >= p.time_limit;
         e.flags &= ~(FLAG_DIRTY | FLAG_RESET_PASS);
         // ---- auto-reset: target placement on the 16-lane code (one resetting env per 16-lane group and round), then the
@@ -4312,6 +4410,7 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
         const unsigned long long need = __ballot(live && done && auto_reset && t == 0);   // bit 8 o'
         if (__builtin_expect(need != 0ull, 0)) {
             DUO_STAMP(13);
+            if (EREF) rf_poll(true);   // a reset tops rows up on the spot and reads stream words: not beside E's refresh
             const DevParams &cp = OD_COLD();
             const bool mine = (need >> sh8) & 1ull;
             const StartTab<N> st = start_tab<N>();
@@ -4459,8 +4558,21 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (CS_OD_ASYNC && s + 1 < io.T) {   // requests for the next step, before this step's stores
             // (a) the row of the env running lowest on twisted words, if any is below REQ: ten dword columns -> sh.rowbuf
-            const unsigned long long lowb = __ballot(live && e.ahead < REQ && t == 0);
+            const unsigned long long lowb = (EREF && rf_pending >= 0) ? 0ull : __ballot(live && e.ahead < REQ && t == 0);
             cand = lowb ? __builtin_amdgcn_readfirstlane((__ffsll((long long)lowb) - 1) >> 3) : -1;
+            if (EREF && cand >= 0) {   // E's job: post the request, go on with the old tape
+                if (o == cand && t == 0) {
+                    rf.rf_env = cand;
+                    rf.rf_pos = e.mt_pos;
+                    rf.rf_ahead = e.ahead;
+                }
+                rf_words0 = e.words;
+                rf_pending = cand;
+                rf_seq += 1;
+                OD_JITTER(13);
+                post(&rf.rf_req, rf_seq);
+                cand = -1;
+            }
             if (__builtin_expect(cand >= 0, 0)) {
                 const unsigned *m = OD_COLD().mt + (size_t)(wave_b0 + cand) * MT_STRIDE;
 #pragma unroll
@@ -4528,6 +4640,10 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
     }
     BLK_STAMP(6);
     SPIN_STORE(1);
+    if (EREF) {
+        rf_poll(true);
+        post(&rf.d_done, 1);
+    }
     if (live) {   // header, cursor and tape are D's part of the state; targets were stored at each reset
         const DevParams &cp = OD_COLD();
         if (t == 0) {
