@@ -8,7 +8,9 @@
                                  rests on vector-memory operations retiring in order and on the number of stores issued after the
                                  requests; here it is a full drain;
   odsync_n3   -DCS_OD_ASYNC=0    no requests ahead of time at all: every row and every attempt batch is loaded where it is used.
-If the shipped kernel ever read LDS before a request had landed, it would differ from the step kernel where these two do not."""
+If the shipped kernel ever read LDS before a request had landed, it would differ from the step kernel where these two do not.
+The three-wavefront variant's row refreshes run in its emitting wavefront (request / old tape meanwhile / adoption, CS_OD_E_REFRESH):
+the jitter build pauses at those hand-shakes too, and the child's last scenario makes every env refresh its row every few steps."""
 import concurrent.futures
 import os
 import subprocess
