@@ -157,7 +157,7 @@ def kernel_label(env_name, n, B, mode, kernel):
         return f"k_rollout_lanev<{n}>" if (n <= 5 and kernel != "lane") else f"k_rollout_lane<{n}>"
     if mode == "step":
         return f"k_step<{n},0>"
-    if kernel == "ode" or (kernel == "auto" and B <= 10240):       # CS_ODE_UPTO: K + D + emitting wavefront per 8 envs
+    if kernel == "ode" or (kernel == "auto" and B <= 8192):        # CS_ODE_UPTO: K + D + emitting wavefront per 8 envs
         return f"k_rollout_od<{n},E>"
     if kernel == "od" or (kernel == "auto" and B <= 16384):      # CS_OD_UPTO
         return f"k_rollout_od<{n}>"

@@ -2314,7 +2314,7 @@ void k_rollout_policy(DevParams p, StepIO io, PolicyIO pio) {
 #define CS_LANEV_DEFAULT 1      /* the lane-per-env kernel of teams of up to 5 is k_rollout_lanev (rollout_lanev.h) */
 #endif
 #ifndef CS_ODE_UPTO
-#define CS_ODE_UPTO 10240       /* ... up to this many envs with the third (emitting) wavefront: five 3-wavefront workgroups per CU x 256 CUs x 8 envs */
+#define CS_ODE_UPTO 8192        /* ... up to this many envs with the third (emitting) wavefront: four 3-wavefront workgroups per CU (32 KB of LDS each since E refreshes the rows: 10240 envs would need a fifth and run 3.7e9 against the pair variant's 5.0e9) x 256 CUs x 8 envs */
 #endif
 #ifndef CS_OD_UPTO
 #define CS_OD_UPTO 16384        /* cs_rollout up to this many envs: the octet pair kernel */
@@ -3752,7 +3752,7 @@ __global__ __launch_bounds__(OCT_BLOCK, CS_OCT_WAVES) void k_rollout_oct(DevPara
 
 // =========================================================================================================
 // Octet pair (flight_easy): the octet layout split by ROLE -- per 8 envs a kinematics wavefront K, a detection
-// wavefront D and (up to 10240 envs) an emitting wavefront E, one such team per workgroup, no barrier in the loops.
+// wavefront D and (up to 8192 envs) an emitting wavefront E, one such team per workgroup, no barrier in the loops.
 //
 // In the octet kernel one wavefront walks the whole dependent chain of a step -- kinematics (~1800 cycles for 3 agents),
 // then detection + reward + rows (~1500) -- and at the batch sizes where every SIMD holds at most one or two wavefronts
@@ -3789,7 +3789,7 @@ __global__ __launch_bounds__(OCT_BLOCK, CS_OCT_WAVES) void k_rollout_oct(DevPara
 #endif
 constexpr int OD_BLOCK = 128;
 // steps K may be ahead of D (power of two).  The pair variant serves up to 16384 envs with eight workgroups per CU: 20 KB of LDS each,
-// four slots.  The three-wavefront variant stops at 10240 envs = five workgroups per CU, so its ring can be eight deep (29 KB):
+// four slots.  The three-wavefront variant stops at 8192 envs = four workgroups per CU, so its ring can be eight deep (30 KB + E's row buffer):
 // K absorbs more of D's events before it has to wait for a slot.
 constexpr int od_ring(bool e3) { return e3 ? CS_OD_RING_E3 : CS_OD_RING; }
 static_assert((od_ring(false) & (od_ring(false) - 1)) == 0 && od_ring(false) >= 2, "ring depth");
@@ -3883,7 +3883,7 @@ __device__ __forceinline__ int2 lds_peek2(const int *base) {
 // a quarter of D's plain step.  D, which also carries every reset and row top-up, is the pair's slower half (K alone sustains
 // ~3500 cycles per step, D ~2650 + ~1450 of events); without the emission it has the slack to absorb its events.  D hands each
 // step's reward / terminated / win / found mask to E through a ring of OdOut records; E reads the agents' floats from K's
-// ring slot.  Three wavefronts of 128 VGPRs: five workgroups per CU, so this variant serves batches up to 10240 envs.
+// ring slot.  Three wavefronts of 128 VGPRs and 32 KB of LDS: four workgroups per CU, so this variant serves batches up to 8192 envs.
 struct __attribute__((aligned(16))) OdOut {
     float reward[OCT_ENVS];
     int term[OCT_ENVS], win[OCT_ENVS];

@@ -72,7 +72,7 @@ class BatchedFlightEnv:
                 SIMD empty), "oct" (rollout only: 8 lanes per env, lane t owns agent t and targets t, t + 8), "od"
                 (rollout only: the octet layout with a kinematics wavefront running steps ahead of a detection
                 wavefront), "ode" ("od" with a third wavefront per 8 envs that writes the outputs), "lane" (one env per
-                lane: no replicated arithmetic, for large batches) or "auto" (rollout: "ode" up to 10240 envs, "od" up to
+                lane: no replicated arithmetic, for large batches) or "auto" (rollout: "ode" up to 8192 envs, "od" up to
                 16384, "oct" below 131072 envs (teams of 5 and more: 2^20), "lane" from there; single steps: the 16-lane step kernel, "lane" from 32768).
                 All produce bit-identical results.
     step_advance  step(): refresh the hit tapes every STEP_ADVANCE_EVERY single steps (default).  False leaves every

@@ -73,7 +73,7 @@ enum {
                             the pair kernel's range and the lane kernel's); same results */
     CS_KERNEL_OD = 256,  /* cs_rollout, flight_easy: force the octet PAIR kernel (the 8-lane layout with a kinematics wavefront
                             running steps ahead of a detection wavefront, per 8 envs); same results */
-    CS_KERNEL_ODE = 512, /* ... with a third wavefront per 8 envs that writes the outputs (default up to 10240 envs when obs
+    CS_KERNEL_ODE = 512, /* ... with a third wavefront per 8 envs that writes the outputs (default up to 8192 envs when obs
                             and state are both requested); same results */
     CS_KERNEL_LANEV = 1024 /* flight_easy, teams of up to 5: force the second-generation lane-per-env kernel (targets in
                             registers, half-wavefront staging of the get_state rows: three to four wavefronts per SIMD instead of
