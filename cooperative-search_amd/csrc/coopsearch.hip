@@ -4956,9 +4956,13 @@ __global__ __launch_bounds__(MAP_UPD_BLOCK) void k_map_update(DevParams p, int p
 #ifndef CS_PIPE_WAVES
 #define CS_PIPE_WAVES 4   // wavefronts per SIMD the register budget must allow (<= 128 VGPRs): four workgroups per CU
 #endif
+// Larger teams get a larger register budget instead of spills: at four wavefronts per SIMD (128 VGPRs) the step role of teams of 4..8
+// spilled 105..473 VGPRs; with three (168) teams of 4 and 5 spill nothing, with two (256) neither do teams of 6..8.  Measured, flight
+// B = 8192, us per step of cs_rollout: 5 agents 107.0 -> 100.2, 8 agents 179.7 -> 169.8 (three) -> 160.3 (two).
+constexpr int pipe_waves(int n) { return n <= 3 ? CS_PIPE_WAVES : (n <= 5 ? 3 : 2); }
 constexpr int PIPE_ILP = CS_PIPE_ILP;
 template <int N>
-__global__ __launch_bounds__(BLOCK, CS_PIPE_WAVES) void k_flight_pipe(DevParams p, StepIO io, float *map_obs, int map_parity,
+__global__ __launch_bounds__(BLOCK, pipe_waves(N)) void k_flight_pipe(DevParams p, StepIO io, float *map_obs, int map_parity,
                                                                       int nstep, int stride, int ysplit) {
     static_assert(BLOCK == MAP_BLOCK, "one workgroup shape for both roles");
     __shared__ double T[TRIG_ROWS * TRIG_COLS];
