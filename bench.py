@@ -73,10 +73,14 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads reported under 'also'")
+    ap.add_argument("--also", action="store_true",
+                    help="N > 1: run the whole list of secondary workloads on every rank too (default at N > 1: the headline and "
+                         "the two c5 lines only, so that a scaling run is not 8x longer than it has to be)")
     ap.add_argument("--kernel", default="auto", choices=["auto", "group", "solo", "duo", "od", "ode", "oct", "lane", "lanev"],
                     help="flight_easy kernel: 16 lanes per env (solo / duo wavefront roles, or chosen by batch), 8 lanes per env "
                          "(od: kinematics + detection wavefront pair, oct: one wavefront), one lane per env, or everything by "
-                         "batch size (auto: od up to 16384 envs, oct below 131072, lane from there)")
+                         "batch size (auto: ode up to 8192 envs, od up to 16384, oct below 65536 -- teams of 6 to 8: below 2^20 --, lanev from 65536 "
+                         "for teams of up to 5, lane from 2^20 for larger ones; DESIGN.md section 4)")
     ap.add_argument("--min-gpu-s", type=float, default=MIN_GPU_S)
     ap.add_argument("--pg", default="auto", choices=["auto", "on", "off"],
                     help="process group at N = 1: 'on' = init_process_group('nccl') even for one rank and fail if RCCL does "
@@ -195,6 +199,18 @@ def cpu_model():
     return "unknown"
 
 
+def cpu_list_str(cpus):
+    """{0,1,2,3,8,9} -> '0-3,8-9' (the kernel's cpulist notation)."""
+    cs_, out, i = sorted(cpus), [], 0
+    while i < len(cs_):
+        j = i
+        while j + 1 < len(cs_) and cs_[j + 1] == cs_[j] + 1:
+            j += 1
+        out.append(str(cs_[i]) if i == j else f"{cs_[i]}-{cs_[j]}")
+        i = j + 1
+    return ",".join(out)
+
+
 def physical_cores():
     """(number of physical cores this process may run on, threads per core): sibling lists of the CPUs in the affinity mask."""
     cpus = sorted(os.sched_getaffinity(0))
@@ -238,6 +254,10 @@ def cpu_baseline(env_name, n, batch, budget_s=10.0):
     env = dict(os.environ)
     env.update({"OMP_PROC_BIND": "close", "OMP_PLACES": "cores", "OMP_DYNAMIC": "false"})
     env.pop("OMP_NUM_THREADS", None)
+    # the rank was bound to the CPUs of its GPU's NUMA node (bind_rank_to_gpu_node) and a child inherits that mask: the
+    # "host's cores" would be one node's.  The child restores the mask the process had before the binding.
+    if ORIGINAL_AFFINITY is not None:
+        env["BENCH_CPU_BASELINE_AFFINITY"] = ",".join(str(c) for c in sorted(ORIGINAL_AFFINITY))
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", f"{env_name},{n},{batch},{budget_s}"]
     out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -333,6 +353,9 @@ def cpu_baseline_inproc(env_name, n, batch, budget_s=10.0):
             "faster_but_unsteady": faster or None,
             "pinning": {"OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES"),
                         "physical_cores": n_cores, "threads_per_core": smt, "cgroup_cpu_quota": quota,
+                        "affinity_cpus": len(os.sched_getaffinity(0)), "affinity": cpu_list_str(os.sched_getaffinity(0)),
+                        "affinity_source": "parent's mask before its NUMA binding" if os.environ.get("BENCH_CPU_BASELINE_AFFINITY")
+                        else "inherited",
                         "note": "own process, one thread per physical core at most (no SMT siblings), never more threads than "
                                 "the cgroup's CPU quota - 2"},
             "single_thread_value": single, "speedup_vs_single_thread": value / single,
@@ -423,6 +446,9 @@ def gpu_local_cpus(local_rank, sysfs="/sys"):
     return found
 
 
+ORIGINAL_AFFINITY = None   # this process's CPU mask BEFORE bind_rank_to_gpu_node narrowed it: what the cpu_baseline child runs on
+
+
 def bind_rank_to_gpu_node(local_rank, sysfs="/sys"):
     """Restricts this process (and every thread it starts later: HIP's, RCCL's) to the CPUs of its GPU's NUMA node.  The
     path shards with no data-path collective, so the host cost of a launch (7 us per call against a 40 us region) is the one
@@ -432,9 +458,13 @@ def bind_rank_to_gpu_node(local_rank, sysfs="/sys"):
     if not found:
         return None
     node, cpus = found
-    allowed = cpus & os.sched_getaffinity(0)
+    global ORIGINAL_AFFINITY
+    before = os.sched_getaffinity(0)
+    allowed = cpus & before
     if not allowed:
         return None
+    if ORIGINAL_AFFINITY is None:
+        ORIGINAL_AFFINITY = set(before)   # children inherit the narrowed mask: cpu_baseline() hands this one to its child
     os.sched_setaffinity(0, allowed)
     return {"numa_node": node, "cpus": len(allowed), "source": "KFD topology + drm local_cpulist, before any GPU call"}
 
@@ -462,6 +492,38 @@ class Comm:
         t = self.torch.tensor([x], dtype=self.torch.float64, device=self.cdev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
+
+    def gather(self, x):
+        """x of every rank, in rank order (every rank gets the list)."""
+        if not self.pg:
+            return [float(x)]
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.cdev)
+        got = [self.torch.zeros_like(t) for _ in range(self.dist.get_world_size())]
+        self.dist.all_gather(got, t)
+        return [float(g.item()) for g in got]
+
+
+METRIC_PARTIALS = 204   # 4 sums (reward, wins, targets found, envs) + the 200-step found-fraction curve (runner.py:86-96, :139-171)
+
+
+def time_metric_allgather(dist, cdev, reps=100, torch=None, sync=None):
+    """The path's ONE collective, timed on its own: `reps` all-gathers of the [204] float32 metric partials (SURVEY.md
+    section 8e: latency-bound, over xGMI at N > 1), each bracketed by a device synchronisation; median / min / max in
+    microseconds.  Every rank must call it."""
+    part = torch.zeros(METRIC_PARTIALS, dtype=torch.float32, device=cdev)
+    got = [torch.zeros_like(part) for _ in range(dist.get_world_size())]
+    sync = sync or (lambda: None)
+    for _ in range(5):
+        dist.all_gather(got, part)
+    sync()
+    us = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        dist.all_gather(got, part)
+        sync()
+        us.append((time.perf_counter() - t0) * 1e6)
+    return {"median": statistics.median(us), "min": min(us), "max": max(us), "reps": reps, "floats": METRIC_PARTIALS,
+            "clock": "host wall time around all_gather + device synchronisation"}
 
 
 def timed_region(region, dev, comm, min_gpu_s):
@@ -545,6 +607,8 @@ def run_workload(cs, dev, comm, env_name, n, B, mode, K, W, kernel, rank=0, no_g
     ev, wall = timed_region(region, dev, comm, min_gpu_s)
     t_ev = comm.max(statistics.median(ev))
     t_wall = comm.max(statistics.median(wall))
+    # every rank's own rate (its median region), not only the slowest one's: a straggler shows as min << median
+    per_rank = [B * K / t for t in comm.gather(statistics.median(ev))]
     steps_per_launch = S if mode == "rollout" and env_name != "flight" else 1   # flight: one launch per step either way
     alg = algorithmic_bytes_per_env_step(env_name, n, m, mode)
     label = kernel_label(env_name, n, B, mode, kernel)
@@ -555,6 +619,8 @@ def run_workload(cs, dev, comm, env_name, n, B, mode, K, W, kernel, rank=0, no_g
         "wall_ms_per_step": t_wall * 1e3 / K, "repeats": len(ev), "timed_gpu_s": sum(ev),
         "region_ms_min_median_max": [min(ev) * 1e3, statistics.median(ev) * 1e3, max(ev) * 1e3],
         "steps_per_launch": steps_per_launch,
+        "per_rank_value": {"min": min(per_rank), "median": statistics.median(per_rank), "max": max(per_rank),
+                           "slowest_rank": per_rank.index(min(per_rank)), "unit": "env-steps/s per GPU"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "traffic_source": (traffic_source + ": committed rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), per "
@@ -641,14 +707,23 @@ def dry_run(a, rank, world):
     if world > 1:
         dist.init_process_group("gloo")
     part = torch.tensor([-100.0 * B, 0.0, 3.0 * B, float(B)], dtype=torch.float64)
+    allgather_us, per_rank = None, None
     if world > 1:
         gathered = [torch.zeros_like(part) for _ in range(world)]
         dist.all_gather(gathered, part)
         part = torch.stack(gathered).sum(0)
+        # the fields of the real line that only exist at N > 1, through the same code (gloo instead of RCCL; fabricated rates)
+        allgather_us = time_metric_allgather(dist, torch.device("cpu"), reps=20, torch=torch)
+        comm = Comm(world, torch.device("cpu"), True, True)
+        rates = comm.gather(1.0e9 + rank)
+        per_rank = {"min": min(rates), "median": statistics.median(rates), "max": max(rates), "slowest_rank": rates.index(min(rates)),
+                    "unit": "env-steps/s per GPU (fabricated: 1e9 + rank)"}
     if rank == 0:
         print(json.dumps({"metric": "env-steps/sec", "value": None, "unit": "env-steps/s", "n_gpus": world,
                           "steps": a.steps, "warmup": a.warmup, "dry_run": True,
-                          "eval": {"envs": int(part[3].item()), "world_size": world},
+                          "eval": {"envs": int(part[3].item()), "world_size": world, "allgather_us": allgather_us},
+                          "per_rank_value": per_rank,
+                          "also_at_this_n": "all" if (world == 1 or a.also) else "c5 weak + c5 strong only",
                           "c5_strong_total": {"value": None, "n_gpus": world, "envs_total": C5_GLOBAL_BATCH,
                                               "envs_per_gpu": C5_GLOBAL_BATCH // world if C5_GLOBAL_BATCH % world == 0 else None},
                           "c5_weak_total": {"value": None, "n_gpus": world, "envs_total": 8192 * world, "envs_per_gpu": 8192}}),
@@ -662,6 +737,12 @@ def main():
     argv = sys.argv[1:]
     a = parse_args(argv)
     if a.cpu_baseline_child:   # the pinned child of cpu_baseline(): numpy + the oracle only, never the GPU
+        mask = os.environ.get("BENCH_CPU_BASELINE_AFFINITY")
+        if mask:   # the parent's mask from before its NUMA binding (must happen before libgomp places its team)
+            try:
+                os.sched_setaffinity(0, {int(c) for c in mask.split(",")})
+            except (OSError, ValueError) as exc:
+                sys.stderr.write(f"bench.py: cpu baseline child keeps the inherited CPU mask ({exc})\n")
         env_name, n, batch, budget = a.cpu_baseline_child.split(",")
         print(json.dumps(cpu_baseline_inproc(env_name, int(n), int(batch), float(budget))), flush=True)
         return
@@ -788,6 +869,14 @@ def main():
             pg, pg_error = False, f"all_gather: {type(exc).__name__}: {exc}"[:300]
             comm.pg = False
     part = part.cpu().numpy()
+    allgather_us = None
+    if pg:
+        try:
+            allgather_us = time_metric_allgather(dist, comm.cdev, torch=torch, sync=lambda: torch.cuda.synchronize(dev))
+        except Exception as exc:   # noqa: BLE001
+            if world > 1 or in_torchrun or a.pg == "on":
+                raise
+            allgather_us = {"error": f"{type(exc).__name__}: {exc}"[:200]}
     del env
     torch.cuda.empty_cache()
 
@@ -811,7 +900,9 @@ def main():
             "roofline": res["roofline"],
             "eval": {"mean_episode_reward_so_far": part[0] / part[3], "win_rate_now": part[1] / part[3],
                      "mean_targets_found_now": part[2] / part[3], "envs": int(part[3]), "world_size": world,
-                     "reduced_by": "all_gather over the process group" if pg else "local (no process group)"},
+                     "reduced_by": "all_gather over the process group" if pg else "local (no process group)",
+                     "allgather_us": allgather_us},
+            "per_rank_value": res["per_rank_value"],
         }
     also = []
     if not a.no_also and a.workload == "c2" and not a.batch:
@@ -822,7 +913,7 @@ def main():
         if C5_GLOBAL_BATCH % world == 0:
             also.append(side_measurement(cs, dev, comm, f"c5 strong: flight_easy 5a15t, 65536 envs over {world} GPU(s)",
                                          "flight_easy", 5, C5_GLOBAL_BATCH // world, "rollout", 400, 100, "auto", rank=rank))
-        if world == 1:
+        if world == 1 or a.also:
             also += [
                 side_measurement(cs, dev, comm, "c2 flight_easy 3a15t B=4096, one launch per step (hipGraph)",
                                  "flight_easy", 3, 4096, "step", 2000, 200, "auto"),

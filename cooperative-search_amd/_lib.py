@@ -5,7 +5,7 @@ import warnings
 
 from . import build as _build
 
-ABI_VERSION = 6   # CS_ABI_VERSION of include/coopsearch.h; bumped whenever an export or a struct changes
+ABI_VERSION = 7   # CS_ABI_VERSION of include/coopsearch.h; bumped whenever an export or a struct changes
 MT_STRIDE = 672    # CS_MT_STRIDE
 MAX_AGENTS = 8
 MAX_TARGETS = 16
@@ -14,7 +14,7 @@ H_WORDS = 16
 H_FOUND, H_NEWLY, H_TARGET_FIND, H_FLAGS, H_TIME_STEP, H_TOTAL_REWARD, H_MT_POS, H_EPISODES = range(8)
 H_WORDS_LO, H_WORDS_HI, H_CURR_REWARD, H_NEWLY_RESET = 8, 9, 10, 11
 SELECT_SOFTMAX, SELECT_SAMPLE = 1, 2
-FREEZE_DONE, AUTO_RESET, ACTIONS_I64, KERNEL_GROUP, KERNEL_LANE, KERNEL_SOLO, KERNEL_DUO, KERNEL_OCT, KERNEL_OD, KERNEL_ODE, KERNEL_LANEV = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024
+FREEZE_DONE, AUTO_RESET, ACTIONS_I64, KERNEL_GROUP, KERNEL_LANE, KERNEL_SOLO, KERNEL_DUO, KERNEL_OCT, KERNEL_OD, KERNEL_ODE, KERNEL_LANEV, CHECK_ACTIONS = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048
 
 EXPORTS = ["cs_abi_version", "cs_source_hash", "cs_last_error", "cs_state_layout", "cs_init", "cs_seed", "cs_reset", "cs_step",
            "cs_rollout", "cs_rollout_policy", "cs_rollout_policy_flight", "cs_emit", "cs_metrics", "cs_mt_canonical", "cs_mt_advance", "cs_policy_packed_floats", "cs_policy_pack", "cs_policy_forward",
@@ -122,7 +122,15 @@ def load():
     # version guards exports and structs only -- kernels change behaviour without touching either -- so a library of other sources
     # is an error under COOPSEARCH_STRICT=1 (tests, CI) and a warning naming both hashes otherwise.  COOPSEARCH_LIB (experimental
     # one-team-size builds) opts out.
-    if not os.environ.get("COOPSEARCH_LIB"):
+    if os.environ.get("COOPSEARCH_LIB"):
+        # a variant build says what it should have been compiled from (build.variant_hash: sources AND flags) through
+        # COOPSEARCH_LIB_HASH; without that variable the opt-out stands (ad-hoc experiments)
+        want = os.environ.get("COOPSEARCH_LIB_HASH")
+        built = L.cs_source_hash().decode() if hasattr(L, "cs_source_hash") else ""
+        if want and built != want:
+            raise CoopSearchError(f"{path} carries source hash {built!r}, expected {want!r}: a stale variant build "
+                                  "(rebuild it: cooperative_search_amd.build.build_variant)")
+    else:
         built = L.cs_source_hash().decode() if hasattr(L, "cs_source_hash") else ""
         want = _build.source_hash()
         if built != want:
@@ -183,4 +191,14 @@ def pick_binding(binding=None):
 
 def check(rc):
     if rc != 0:
-        raise CoopSearchError(f"coopsearch error {rc}: {load().cs_last_error().decode()}")
+        msg = load().cs_last_error().decode()
+        if msg.startswith("list index out of range"):   # CS_CHECK_ACTIONS: the reference's IndexError (dyaw[act], flight_env_easy.py:262)
+            raise IndexError(msg)
+        raise CoopSearchError(f"coopsearch error {rc}: {msg}")
+
+
+def check_actions_default(batch):
+    """CS_CHECK_ACTIONS is on by default for batches of up to 64 envs; COOPSEARCH_CHECK_ACTIONS=0 / 1 forces it off / on
+    (same rule as csrc/torch_ops.cpp:check_actions_default)."""
+    e = os.environ.get("COOPSEARCH_CHECK_ACTIONS", "")
+    return batch <= 64 if e == "" else e[0] != "0"

@@ -98,6 +98,53 @@ def build_extension(force=False, verbose=False):
     return LIB_PATH
 
 
+# ---- experimental / test builds of the library for ONE team size (build/var/<name>.so, used through COOPSEARCH_LIB) ----------
+VAR_DIR = os.path.join(ROOT, "build", "var")
+
+
+def variant_path(name):
+    return os.path.join(VAR_DIR, name + ".so")
+
+
+def variant_hash(flags, only_n):
+    """What a variant build is compiled from: the sources' hash AND its flags.  Embedded in the variant (cs_source_hash()) and
+    written next to it; a variant is current when both equal this -- never decided by mtime (the .so files travel by copy)."""
+    h = hashlib.sha256()
+    h.update(source_hash().encode() + b"\0" + " ".join(list(flags) + [f"-DCS_ONLY_N={only_n}"]).encode())
+    return h.hexdigest()[:16]
+
+
+def embedded_hash(lib_path):
+    """cs_source_hash() of a built library, read in a child process (dlopen of several HIP libraries in one process registers
+    their code objects side by side; a child keeps the caller clean)."""
+    code = ("import ctypes, sys; L = ctypes.CDLL(sys.argv[1]); L.cs_source_hash.restype = ctypes.c_char_p; "
+            "print(L.cs_source_hash().decode())")
+    r = subprocess.run([shutil.which("python3") or "python3", "-c", code, lib_path], capture_output=True, text=True)
+    return r.stdout.strip() if r.returncode == 0 else None
+
+
+def build_variant(name, flags, only_n=3, force=False):
+    """hipcc <flags> -DCS_ONLY_N=<n> -DCS_SOURCE_HASH=<variant_hash> -> build/var/<name>.so (+ .srchash).  Rebuilt when the
+    recorded hash is not variant_hash(flags, only_n).  Without hipcc: the existing file (the caller compares its embedded
+    hash) or None."""
+    lib = variant_path(name)
+    want = variant_hash(flags, only_n)
+    if not force and os.path.exists(lib) and _recorded_hash(lib) == want:
+        return lib
+    hipcc = hipcc_path()
+    if hipcc is None:
+        return lib if os.path.exists(lib) else None
+    os.makedirs(VAR_DIR, exist_ok=True)
+    tmp = f"{lib}.tmp.{os.getpid()}"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"] + list(flags) +
+                          [f"-DCS_ONLY_N={only_n}", f'-DCS_SOURCE_HASH="{want}"', "-I", os.path.join(ROOT, "include"),
+                           "coopsearch.hip", "policy.hip", "episodes.hip", "-o", tmp], cwd=CSRC)
+    os.replace(tmp, lib)
+    with open(lib + ".srchash", "w") as f:
+        f.write(want + "\n")
+    return lib
+
+
 def torch_ops_stale():
     if os.environ.get("COOPSEARCH_TORCH_LIB"):
         return False

@@ -19,6 +19,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <mutex>
 
 #include "coopsearch.h"
 
@@ -2850,7 +2851,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO i
                     if ((newly >> j) & 1u) row[4 * N + 3 * j + 2] = 1.0f;
             }
         }
-        if (live && io.state) {
+        if (live && (io.state || io.obs)) {
 #pragma unroll
             for (int i = 0; i < N; i++) {
                 row[4 * i + 0] = f[i].x;
@@ -2878,14 +2879,26 @@ __global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO i
             io.reward[slot] = (float)reward;
             io.terminated[slot] = term ? 1 : 0;
             io.win[slot] = (e.flags & FLAG_WIN) ? 1 : 0;
-            if (io.obs) {
-                float4 *o = reinterpret_cast<float4 *>(io.obs) + slot * N;
+        }
+        if (io.obs) {
+            // get_obs: the wavefront's 64 N float4 are one contiguous block of the table; stored from the lanes that own the envs
+            // they would be N stores of 64 pieces at a stride of 16 N bytes each (partial sectors, which non-temporal stores do not
+            // let the L2 merge).  The agents' floats are in the tile already (the get_state rows): chunk k = (env k / N, agent k % N)
+            // is gathered from there and the block leaves as N coalesced 1 KB stores.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            v4f *o = reinterpret_cast<v4f *>(io.obs) + ((size_t)s * p.B + b0) * N;
+            v4f ov[N];
 #pragma unroll
-                for (int i = 0; i < N; i++) {
-                    const v4f nv = {f[i].x, f[i].y, f[i].z, f[i].w};
-                    __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(o + i));
-                }
+            for (int q = 0; q < N; q++) {
+                const int k = lane + 64 * q, r = k / N, i = k - r * N;
+                const float *src = tile + (size_t)r * W + 4 * i;
+                ov[q] = v4f{src[0], src[1], src[2], src[3]};
             }
+#pragma unroll
+            for (int q = 0; q < N; q++)
+                if (lane + 64 * q < rows_valid * N) __builtin_nontemporal_store(ov[q], o + lane + 64 * q);
         }
         if (!VEC && io.state) {   // plain launch: the wave's rows (contiguous in get_state's [B][W] layout) leave now
             float *dst = io.state + ((size_t)s * p.B + b0) * W;
@@ -5081,6 +5094,24 @@ __global__ void k_eps_step(DevParams p, int flags, double *eps, double anneal, d
     if (executed) eps[b] = v > min_eps ? v - anneal : v;   // common/rollout.py:75-76
 }
 
+// CS_CHECK_ACTIONS: every action of a call must index dyaw = [0, pi/18, -pi/18] (flight_env_easy.py:259-262).  The first
+// offender (lowest flat index wins a compare-and-swap) is reported through four host-mapped words: flag, index lo / hi, value.
+__global__ void k_check_actions(const void *actions, unsigned long long count, int i64, int n_actions, int *report) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        const long long v = i64 ? static_cast<const long long *>(actions)[i] : (long long)static_cast<const int *>(actions)[i];
+        if (v < 0 || v >= n_actions) {
+            if (atomicCAS_system(report, 0, 1) == 0) {
+                report[1] = (int)(unsigned)(i & 0xffffffffull);
+                report[2] = (int)(unsigned)(i >> 32);
+                report[3] = (int)(v < -2147483647ll ? -2147483647ll : (v > 2147483647ll ? 2147483647ll : v));
+                __threadfence_system();
+            }
+            return;
+        }
+    }
+}
+
 __global__ void k_metrics(DevParams p, double *out4) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
@@ -5195,6 +5226,51 @@ int make_params(const cs_config *c, void *state, DevParams *p) {
     return CS_OK;
 }
 
+// CS_CHECK_ACTIONS (debug aid; -DCS_CHECK_ACTIONS_ALWAYS turns it on for every call of a debug build): the actions of a cs_step /
+// cs_rollout call are validated on the device BEFORE anything is stepped; the call then returns CS_E_ARG with the reference's
+// IndexError wording and the env state untouched.  The kernels themselves treat any value other than 1 / 2 as 0 (no bounds
+// check in the hot loops); the reference raises at dyaw[act] (flight_env_easy.py:262).  Costs a stream synchronisation: not for
+// stream capture, not for the production loop.
+int check_actions(const void *actions_dev, size_t count, int flags, int n_agents, size_t B, hipStream_t s) {
+    static std::mutex mu;
+    static int *report = nullptr;   // four host-mapped words
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return CS_OK;   // a captured call cannot synchronise: unchecked
+    (void)hipGetLastError();
+    std::lock_guard<std::mutex> lock(mu);
+    if (!report) {
+        if (hipHostMalloc((void **)&report, 4 * sizeof(int), hipHostMallocMapped) != hipSuccess) {
+            report = nullptr;
+            (void)hipGetLastError();
+            return fail(CS_E_LAUNCH, "CS_CHECK_ACTIONS: cannot allocate the report words");
+        }
+    }
+    report[0] = report[1] = report[2] = report[3] = 0;
+    int *report_dev = nullptr;
+    if (hipHostGetDevicePointer((void **)&report_dev, report, 0) != hipSuccess) return fail(CS_E_LAUNCH, "CS_CHECK_ACTIONS: no device view of the report words");
+    const unsigned blocks = (unsigned)((count + 255) / 256 < 4096 ? (count + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_check_actions, dim3(blocks ? blocks : 1), dim3(256), 0, s, actions_dev, (unsigned long long)count,
+                       (flags & CS_ACTIONS_I64) ? 1 : 0, 3, report_dev);
+    if (hipStreamSynchronize(s) != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "CS_CHECK_ACTIONS: %s", hipGetErrorString(hipGetLastError()));
+        return CS_E_LAUNCH;
+    }
+    if (report[0]) {
+        const unsigned long long i = (unsigned long long)(unsigned)report[1] | ((unsigned long long)(unsigned)report[2] << 32);
+        const unsigned long long per_step = (unsigned long long)B * (unsigned long long)n_agents;
+        snprintf(g_err, sizeof(g_err), "list index out of range: action %d of step %llu, env %llu, agent %llu is not in 0..2 "
+                 "(dyaw[act], flight_env_easy.py:262; the batched path takes no negative indices)", report[3],
+                 i / per_step, (i % per_step) / (unsigned long long)n_agents, i % (unsigned long long)n_agents);
+        return CS_E_ARG;
+    }
+    return CS_OK;
+}
+#ifdef CS_CHECK_ACTIONS_ALWAYS
+constexpr int CHECK_ACTIONS_FORCED = CS_CHECK_ACTIONS;
+#else
+constexpr int CHECK_ACTIONS_FORCED = 0;
+#endif
+
 int launched(const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -5240,7 +5316,7 @@ inline size_t lane_smem(const cs_config *c) {
 template <int N>
 void launch_lanev(const cs_config *cfg, const DevParams &p, StepIO io, hipStream_t s) {
     const size_t W = 4 * (size_t)cfg->n_agents + 3 * (size_t)cfg->n_targets;
-    const size_t smem = LV_HEAD_BYTES + (LV_BLOCK / 64) * lv_wave_bytes((int)W);
+    const size_t smem = LV_HEAD_BYTES + (LV_BLOCK / 64) * lv_wave_bytes((int)W, cfg->n_agents);
     const bool aligned = io.state && io.obs && (reinterpret_cast<size_t>(io.state) & 15) == 0 &&
                          (reinterpret_cast<size_t>(io.obs) & 15) == 0 && ((size_t)p.B * W) % 4 == 0;
     const int full = aligned ? (p.B / 64) * 64 : 0;
@@ -5459,7 +5535,14 @@ int cs_step(const cs_config *cfg, void *state_dev, const void *actions_dev, int 
     if (rc) return rc;
     if (!actions_dev || !reward_dev || !terminated_dev || !win_dev) return fail(CS_E_ARG, "null step buffer");
     hipStream_t s = (hipStream_t)stream;
+    if ((flags | CHECK_ACTIONS_FORCED) & CS_CHECK_ACTIONS) {
+        rc = check_actions(actions_dev, (size_t)p.B * cfg->n_agents, flags, cfg->n_agents, (size_t)p.B, s);
+        if (rc) return rc;
+    }
     StepIO io{actions_dev, reward_dev, terminated_dev, win_dev, obs_dev, state_out_dev, flags, 1};
+    // (the lane-per-env kernels store an (env, agent) observation as one 16-byte piece of a coalesced block: same rule as cs_rollout)
+    if (cfg->variant == 0 && use_lane_kernel(cfg, flags, false) && obs_dev && (reinterpret_cast<size_t>(obs_dev) & 15) != 0)
+        return fail(CS_E_ARG, "obs_dev must be 16-byte aligned");
     if (cfg->variant == 0 && use_lane_kernel(cfg, flags, false)) {
         if (use_lanev(cfg, flags)) {
             CS_DISPATCH_N(cfg->n_agents, launch_lanev<N>(cfg, p, io, s));
@@ -5490,6 +5573,10 @@ int cs_rollout(const cs_config *cfg, void *state_dev, const void *actions_dev, i
     // fallback, the observations do not): a caller's slice at a 4- or 8-byte offset is refused, not stored to with misaligned dwordx4
     if (cfg->variant == 0 && obs_dev && (reinterpret_cast<size_t>(obs_dev) & 15) != 0)
         return fail(CS_E_ARG, "obs_dev must be 16-byte aligned");
+    if ((flags | CHECK_ACTIONS_FORCED) & CS_CHECK_ACTIONS) {
+        rc = check_actions(actions_dev, (size_t)T * p.B * cfg->n_agents, flags, cfg->n_agents, (size_t)p.B, (hipStream_t)stream);
+        if (rc) return rc;
+    }
     if (cfg->variant == 1) {
         // flight: k_step for step 0, then T - 1 launches of k_flight_pipe (the map sweep of step t beside the kinematics /
         // detection of step t + 1), then k_map for the last step's sweep -- enqueued back to back by this one call, each

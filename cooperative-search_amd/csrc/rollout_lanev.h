@@ -65,10 +65,13 @@ struct EnvV {
     unsigned long long words;
 };
 
-// bytes of LDS per wavefront: the staging piece (aliased by the MT19937 row of the in-loop refresh) + the reset hand-over
-__host__ __device__ inline size_t lv_wave_bytes(int W) {
+// bytes of LDS per wavefront: the staging piece (aliased by the MT19937 row of the in-loop refresh and by the wavefront's block
+// of observations on its way out) + the reset hand-over + the hit tapes
+__host__ __device__ inline size_t lv_wave_bytes(int W, int n_agents) {
     size_t piece = (size_t)LV_PIECE * W * sizeof(float), row = (size_t)MT_N * sizeof(unsigned);
+    size_t obs = (size_t)64 * n_agents * 4 * sizeof(float);
     size_t u = piece > row ? piece : row;
+    u = u > obs ? u : obs;
     return (u + 15) / 16 * 16 + LV_SLOT_FLOATS * sizeof(float) + LV_TAPE_ROWS * 64 * sizeof(unsigned);
 }
 constexpr size_t LV_HEAD_BYTES = ((TRIG_ROWS * TRIG_COLS * 8 + 15) / 16) * 16 + 4 * G * sizeof(double);   // trig table | reset tables
@@ -173,10 +176,10 @@ __global__ __launch_bounds__(LV_BLOCK, lv_waves(N)) void k_rollout_lanev(DevPara
     const int W = 4 * N + 3 * p.n_targets;
     int lane = threadIdx.x & 63;   // (made opaque once per step, see the loop)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    char *wbase = smem + LV_HEAD_BYTES + (size_t)wave * lv_wave_bytes(W);
+    char *wbase = smem + LV_HEAD_BYTES + (size_t)wave * lv_wave_bytes(W, N);
     float *piece = reinterpret_cast<float *>(wbase);                // [LV_PIECE][W] get_state rows of half the wavefront ...
     unsigned *rowbuf = reinterpret_cast<unsigned *>(wbase);         // ... or one MT19937 row (in-loop refresh): never live together
-    unsigned *tl = reinterpret_cast<unsigned *>(wbase + lv_wave_bytes(W) - LV_TAPE_ROWS * 64 * sizeof(unsigned));   // hit tapes, [dword][lane]
+    unsigned *tl = reinterpret_cast<unsigned *>(wbase + lv_wave_bytes(W, N) - LV_TAPE_ROWS * 64 * sizeof(unsigned));   // hit tapes, [dword][lane]
     float2 *slots = reinterpret_cast<float2 *>(reinterpret_cast<char *>(tl) - LV_SLOT_FLOATS * sizeof(float));      // [4][G] reset hand-over
     const int b = io.env0 + blockIdx.x * LV_BLOCK + threadIdx.x;
     const int b0 = b - lane;  // first env of this wavefront
@@ -572,14 +575,29 @@ __global__ __launch_bounds__(LV_BLOCK, lv_waves(N)) void k_rollout_lanev(DevPara
             io.reward[slot] = (float)reward;
             io.terminated[slot] = term ? 1 : 0;
             io.win[slot] = (e.flags & FLAG_WIN) ? 1 : 0;
-            if (VEC || io.obs) {
-                float4 *o = reinterpret_cast<float4 *>(io.obs) + slot * N;
+        }
+        if (VEC || io.obs) {
+            // get_obs (flight_env_easy.py:218-221): one float4 per (env, agent).  Stored straight from the lanes, the N stores of a
+            // step each scatter 64 16-byte pieces at a stride of 16 N bytes -- partial sectors that non-temporal stores do not let
+            // the L2 merge (WRITE_SIZE +115 B per env-step at 5 agents, profiles/r04_lanev5_pmc.json).  The wavefront's block of
+            // 64 N float4 is contiguous in the table: it goes through the staging piece and leaves as N fully coalesced 1 KB stores.
+            v4f *ob = reinterpret_cast<v4f *>(piece);
+            if (live) {
 #pragma unroll
-                for (int i = 0; i < N; i++) {
-                    const v4f nv = {fx[i], fy[i], e.csf[i], e.snf[i]};
-                    __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(o + i));
-                }
+                for (int i = 0; i < N; i++) ob[lane * N + i] = v4f{fx[i], fy[i], e.csf[i], e.snf[i]};
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            v4f *o = reinterpret_cast<v4f *>(io.obs) + ((size_t)s * p.B + b0) * N;
+            v4f ov[N];
+#pragma unroll
+            for (int q = 0; q < N; q++) ov[q] = ob[lane + 64 * q];
+#pragma unroll
+            for (int q = 0; q < N; q++)
+                if (VEC || lane + 64 * q < rows_valid * N) __builtin_nontemporal_store(ov[q], o + lane + 64 * q);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();   // every lane has read its chunks: the get_state rows may overwrite the piece
         }
         if (VEC || io.state) {   // get_state rows (flight_env_easy.py:190-216), half a wavefront at a time through the staging piece
 #pragma unroll

@@ -15,6 +15,7 @@
 #include <torch/library.h>
 #include <torch/types.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -68,7 +69,11 @@ struct StreamOn {
 };
 StreamOn stream_of(const Tensor &t) { return StreamOn(t); }
 
-void ok(int rc) { TORCH_CHECK(rc == CS_OK, cs_last_error()); }
+void ok(int rc) {
+    // an action outside 0..2 is the reference's IndexError (dyaw[act], flight_env_easy.py:262): CS_CHECK_ACTIONS reports it with that wording
+    if (rc == CS_E_ARG && strncmp(cs_last_error(), "list index out of range", 23) == 0) TORCH_CHECK_INDEX(false, cs_last_error());
+    TORCH_CHECK(rc == CS_OK, cs_last_error());
+}
 
 template <class T>
 T *opt_ptr(const c10::optional<Tensor> &t) {
@@ -112,10 +117,21 @@ void env_reset(const Tensor &cfg, Tensor state, const c10::optional<Tensor> &mas
                 stream_of(state)));
 }
 
-int action_flags(const Tensor &actions, int64_t flags) {
+// CS_CHECK_ACTIONS is on by default for batches of up to 64 envs (the B = 1 adapters, debugging sessions: a stream
+// synchronisation costs nothing there); COOPSEARCH_CHECK_ACTIONS=0 / 1 turns it off / on for every batch.
+bool check_actions_default(int64_t batch) {
+    static const int mode = [] {
+        const char *e = getenv("COOPSEARCH_CHECK_ACTIONS");
+        return !e || !*e ? -1 : (e[0] == '0' ? 0 : 1);
+    }();
+    return mode < 0 ? batch <= 64 : mode != 0;
+}
+
+int action_flags(const Tensor &actions, int64_t flags, int64_t batch) {
     TORCH_CHECK(actions.scalar_type() == at::kInt || actions.scalar_type() == at::kLong,
                 "coopsearch: actions must be int32 or int64, got ", actions.scalar_type());
-    return (int)(flags & ~(int64_t)CS_ACTIONS_I64) | (actions.scalar_type() == at::kLong ? CS_ACTIONS_I64 : 0);
+    return (int)(flags & ~(int64_t)CS_ACTIONS_I64) | (actions.scalar_type() == at::kLong ? CS_ACTIONS_I64 : 0) |
+           (check_actions_default(batch) ? CS_CHECK_ACTIONS : 0);
 }
 
 // env.step(act_list) -- flight_env_easy.py:303-314, flight_env.py:357-368
@@ -125,7 +141,7 @@ void env_step(const Tensor &cfg, Tensor state, const Tensor &actions, int64_t fl
     check_state(c, state);
     const Shapes s = shapes_of(c);
     TORCH_CHECK(actions.dim() >= 1 && actions.size(-1) == s.n, "Act num mismatch agent");   // flight_env_easy.py:256-257
-    const int f = action_flags(actions, flags);
+    const int f = action_flags(actions, flags, s.B);
     check_dev(actions, "actions", actions.scalar_type(), s.B * s.n, state);
     check_dev(reward, "reward", at::kFloat, s.B, state);
     check_dev(terminated, "terminated", at::kByte, s.B, state);
@@ -145,7 +161,7 @@ void env_rollout(const Tensor &cfg, Tensor state, const Tensor &actions, int64_t
                 "coopsearch: rollout actions must be [T, ", s.B, ", ", s.n, "]");
     const int64_t T = actions.size(0);
     TORCH_CHECK(T >= 1, "coopsearch: T must be >= 1");
-    const int f = action_flags(actions, flags);
+    const int f = action_flags(actions, flags, s.B);
     check_dev(actions, "actions", actions.scalar_type(), T * s.B * s.n, state);
     check_dev(reward, "reward", at::kFloat, T * s.B, state);
     check_dev(terminated, "terminated", at::kByte, T * s.B, state);

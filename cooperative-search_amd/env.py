@@ -72,16 +72,22 @@ class BatchedFlightEnv:
                 SIMD empty), "oct" (rollout only: 8 lanes per env, lane t owns agent t and targets t, t + 8), "od"
                 (rollout only: the octet layout with a kinematics wavefront running steps ahead of a detection
                 wavefront), "ode" ("od" with a third wavefront per 8 envs that writes the outputs), "lane" (one env per
-                lane: no replicated arithmetic, for large batches) or "auto" (rollout: "ode" up to 8192 envs, "od" up to
-                16384, "oct" below 131072 envs (teams of 5 and more: 2^20), "lane" from there; single steps: the 16-lane step kernel, "lane" from 32768).
+                lane: no replicated arithmetic, for large batches) or "lanev" (the second-generation lane-per-env kernel, teams of up to 5) or "auto" (rollout: "ode" up to
+                8192 envs, "od" up to 16384, "oct" below 65536 envs (teams of 6 to 8: below 2^20), "lanev" from 65536 for teams of up
+                to 5, "lane" from 2^20 for larger ones; single steps: the 16-lane step kernel, the lane-per-env kernel from 32768;
+                the one table is DESIGN.md section 4).
                 All produce bit-identical results.
+    check_actions  validate every action on the device before stepping (CS_CHECK_ACTIONS): a value outside 0..2 raises the
+                reference's IndexError ("list index out of range", dyaw[act], flight_env_easy.py:262) and leaves the envs
+                untouched; costs a stream synchronisation per call.  None (default): on for batches of up to 64 envs.
+                Without it the kernels treat any value other than 1 / 2 as action 0.
     step_advance  step(): refresh the hit tapes every STEP_ADVANCE_EVERY single steps (default).  False leaves every
                 MT19937 word to be twisted on demand by the step kernel itself -- same results, one more dependent load per
                 launch.
     """
 
     def __init__(self, args, circle_dict=None, batch=1, device="cuda", seeds=None, env_offset=0, freeze_done=True,
-                 auto_reset=False, variant=None, kernel="auto", binding=None, step_advance=True):
+                 auto_reset=False, variant=None, kernel="auto", binding=None, step_advance=True, check_actions=None):
         if not torch.cuda.is_available():
             raise RuntimeError("BatchedFlightEnv needs a GPU: the HIP path has no CPU fallback")
         self._L = _lib.load()
@@ -130,6 +136,8 @@ class BatchedFlightEnv:
             self._terminated = torch.zeros(B, dtype=torch.uint8, device=self.device)
             self._win = torch.zeros(B, dtype=torch.uint8, device=self.device)
             self.step_advance = bool(step_advance)
+            # CS_CHECK_ACTIONS: None = the library's rule (batches of up to 64 envs, COOPSEARCH_CHECK_ACTIONS overrides)
+            self.check_actions = _lib.check_actions_default(int(batch)) if check_actions is None else bool(check_actions)
             self._steps_since_advance = STEP_ADVANCE_EVERY   # the first step() refreshes the tapes
             self._obs = torch.zeros(B, n, self.obs_width, dtype=torch.float32, device=self.device)
             self._state = torch.zeros(B, self.state_shape, dtype=torch.float32, device=self.device)
@@ -256,6 +264,8 @@ class BatchedFlightEnv:
             f |= _lib.AUTO_RESET
         if actions.dtype == torch.int64:
             f |= _lib.ACTIONS_I64
+        if self.check_actions:
+            f |= _lib.CHECK_ACTIONS
         if self.kernel == "group":
             f |= _lib.KERNEL_GROUP
         elif self.kernel == "solo":

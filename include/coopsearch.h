@@ -33,9 +33,9 @@
 extern "C" {
 #endif
 
-#define CS_ABI_VERSION 6   /* 2: cs_layout.ahead_off (pre-twisted MT words), cs_mt_canonical; 3: cs_layout.job_off;
+#define CS_ABI_VERSION 7   /* 2: cs_layout.ahead_off (pre-twisted MT words), cs_mt_canonical; 3: cs_layout.job_off;
                               4: cs_source_hash, CS_KERNEL_OCT; 5: CS_KERNEL_ODE; 6: cs_epsilon (exploration schedule),
-                              cs_epsilon_step, CS_KERNEL_LANEV */
+                              cs_epsilon_step, CS_KERNEL_LANEV; 7: CS_CHECK_ACTIONS */
 #define CS_MAX_AGENTS 8
 #define CS_MAX_TARGETS 16
 #define CS_MAX_MAP 64
@@ -75,9 +75,17 @@ enum {
                             running steps ahead of a detection wavefront, per 8 envs); same results */
     CS_KERNEL_ODE = 512, /* ... with a third wavefront per 8 envs that writes the outputs (default up to 8192 envs when obs
                             and state are both requested); same results */
-    CS_KERNEL_LANEV = 1024 /* flight_easy, teams of up to 5: force the second-generation lane-per-env kernel (targets in
+    CS_KERNEL_LANEV = 1024, /* flight_easy, teams of up to 5: force the second-generation lane-per-env kernel (targets in
                             registers, half-wavefront staging of the get_state rows: three to four wavefronts per SIMD instead of
                             two; CS_KERNEL_LANE forces the first generation); same results */
+    CS_CHECK_ACTIONS = 2048 /* debug aid: validate every action of the call on the device BEFORE anything is stepped.  A value
+                            outside 0..2 makes the call return CS_E_ARG with the reference's IndexError wording ("list index out
+                            of range": dyaw[act], flight_env_easy.py:259-262) and leaves the env state untouched.  Without the
+                            flag the kernels treat any value other than 1 / 2 as 0 (no bounds check in the hot loops).  Python's
+                            negative indices (dyaw[-1]) are NOT accepted by the batched path; the B = 1 adapter maps them like the
+                            reference.  Synchronises the stream: not for stream capture.  A library built with
+                            -DCS_CHECK_ACTIONS_ALWAYS checks every call; the torch op layer sets the flag for batches of up to
+                            64 envs (COOPSEARCH_CHECK_ACTIONS=0 / 1 turns that off / on for every batch). */
 };
 
 /* Exploration schedule of RolloutWorker.generate_episode -- common/rollout.py:35-41 (episode / epoch scale: one anneal before
@@ -189,7 +197,7 @@ int cs_reset(const cs_config *cfg, void *state_dev, const uint8_t *mask_dev, int
 
 /* env.step(act_list) -- flight_env_easy.py:303-314 (_agent_step :255-291, _potential_energy_force :293-301,
  * _update_obs :223-253), flight_env.py:357-368 (+ _update_prob_map :275-303) -- for every env.
- *   actions_dev    int32 or int64 [B][n], values 0/1/2
+ *   actions_dev    int32 or int64 [B][n], values 0/1/2 (validated only with CS_CHECK_ACTIONS)
  *   reward_dev     float [B]   (integer valued)     terminated_dev / win_dev  uint8 [B]
  *   obs_dev / state_out_dev as in cs_reset (may be NULL) */
 int cs_step(const cs_config *cfg, void *state_dev, const void *actions_dev, int flags,

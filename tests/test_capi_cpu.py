@@ -33,7 +33,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert set(syms) == set(_lib.EXPORTS), (syms, _lib.EXPORTS)
     for s in syms:
         assert hasattr(L, s), s
-    assert L.cs_abi_version() == _lib.ABI_VERSION == 6
+    assert L.cs_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_staleness_is_decided_by_source_content_not_mtime(tmp_path, monkeypatch):
@@ -309,3 +309,18 @@ def test_dispatch_table_matches_the_code():
     for fn in ("README.md", "INTEGRATION.md", os.path.join("include", "coopsearch.h")):
         txt = open(os.path.join(ROOT, fn)).read()
         assert "131072" not in txt, fn + " still names the old lane-kernel threshold; refer to DESIGN.md section 4 instead"
+
+
+def test_variant_builds_present_carry_the_hash_of_the_present_sources_and_their_flags():
+    """ADVICE r4: the timing-jitter / drained-wait / no-async builds of tests/test_gpu_jitter.py travel to the GPU box as files;
+    one compiled from older sources would still equal its own step kernel.  Every variant that is present must carry (embedded
+    and in its sidecar) build.variant_hash(flags): regenerate with `python -c "import __graft_entry__ as g; g.build()"`."""
+    import test_gpu_jitter as tj
+    from cooperative_search_amd import build as b
+    present = [n for n in tj.VARIANTS if os.path.exists(b.variant_path(n))]
+    if not present:
+        pytest.skip("no variant builds in this tree")
+    for n in present:
+        want = tj.expected_hash(n)
+        assert b._recorded_hash(b.variant_path(n)) == want, f"build/var/{n}.so: stale sidecar"
+        assert b.embedded_hash(b.variant_path(n)) == want, f"build/var/{n}.so: compiled from other sources or flags"

@@ -145,3 +145,111 @@ def test_generate_episodes_straight_into_the_replay_ring():
         filled = rb_a.current_size
         for k in rb_a.buffers:
             assert torch.equal(rb_a.buffers[k][:filled], rb_b.buffers[k][:filled]), (rnd, k)
+
+
+def _tagged_batch(rb, first_seq, k):
+    """k episodes whose every element of every key carries the episode's sequence number (+ a per-key offset)."""
+    seq = torch.arange(first_seq, first_seq + k, dtype=torch.float32, device="cuda")
+    d = {}
+    for j, (key, buf) in enumerate(rb.buffers.items()):
+        d[key] = (seq + 0.01 * j).reshape((k,) + (1,) * (buf.dim() - 1)).expand((k,) + tuple(buf.shape[1:])).contiguous()
+    return d
+
+
+@pytest.mark.parametrize("route", ["store_episode", "cs_store_episodes"])
+def test_replay_ring_contents_match_reference_recordings(route):
+    """Row f2 on the device (common/replay_buffer.py:63-101): every recorded store sequence of the REFERENCE ReplayBuffer
+    (tests/golden/replay_indices.json, gen_golden.py:capture_replay_indices) is replayed on the HBM ring with episodes
+    tagged by sequence number; after every store the ring's contents must sit in the slots the reference handed out, and
+    current_idx / current_size / the latest-k slots (and what sample_latest returns) must be the recorded ones.
+    route 'cs_store_episodes': the episodes are assembled by the HIP kernel straight into the ring slots
+    (collector.assemble_episodes(out=rb.buffers, slots=...), what generate_episodes(into=rb) does)."""
+    import types
+    from cooperative_search_amd.collector import assemble_episodes
+    cases = json.load(open(os.path.join(GOLDEN_DIR, "replay_indices.json")))
+    args = types.SimpleNamespace(n_actions=3, n_agents=3, state_shape=57, obs_shape=4, episode_limit=4, conv=False, map_size=50)
+    T, n, A = args.episode_limit, args.n_agents, args.n_actions
+    for case in cases:
+        size = case["size"]
+        rb = cs.DeviceReplayBuffer(args, size, device="cuda")
+        for buf in rb.buffers.values():
+            buf.fill_(-1.0)
+        want_tag = np.full(size, -1.0)          # sequence number the reference's slot holds
+        seq = 0
+        for st in case["steps"]:
+            k = st["inc"]
+            if route == "store_episode":
+                rb.store_episode(_tagged_batch(rb, seq, k))
+            else:
+                # raw rollout tables [T(+1), k, ...] whose reward column carries the sequence number; never terminated, so
+                # no step is padded and r[slot, t] = seq for every t
+                o = torch.zeros(T + 1, k, n, 4, device="cuda")
+                s = torch.zeros(T + 1, k, 57, device="cuda")
+                tagv = torch.arange(seq, seq + k, dtype=torch.float32, device="cuda")
+                o[:] = tagv[None, :, None, None]
+                s[:] = tagv[None, :, None] + 0.5
+                u = torch.zeros(T, k, n, dtype=torch.int64, device="cuda")
+                r = tagv[None, :].expand(T, k).contiguous()
+                term = torch.zeros(T, k, dtype=torch.bool, device="cuda")
+                slots = torch.as_tensor(rb._get_storage_idx(inc=k), device="cuda")
+                assemble_episodes(o, s, u, r, term, A, out=rb.buffers, slots=slots)
+            want_tag[np.asarray(st["idx"])] = np.arange(seq, seq + k)
+            seq += k
+            assert (rb.current_idx, rb.current_size) == (st["current_idx"], st["current_size"])
+            got_r = rb.buffers["r"][:, :, 0].cpu().numpy()
+            if route == "store_episode":
+                j_r = list(rb.buffers).index("r")
+                np.testing.assert_allclose(got_r, np.where(want_tag >= 0, want_tag + 0.01 * j_r, -1.0)[:, None].repeat(T, 1), rtol=0, atol=1e-4)
+                for j, (key, buf) in enumerate(rb.buffers.items()):     # every key of a slot belongs to the same episode
+                    flat = buf.reshape(size, -1).cpu().numpy()
+                    np.testing.assert_allclose(flat, np.where(want_tag >= 0, want_tag + 0.01 * j, -1.0)[:, None].repeat(flat.shape[1], 1),
+                                               rtol=0, atol=1e-4, err_msg=key)
+            else:
+                np.testing.assert_array_equal(got_r, want_tag[:, None].repeat(T, 1))
+                filled = want_tag >= 0
+                np.testing.assert_array_equal(rb.buffers["o"][:, :, 0, 0].cpu().numpy()[filled], want_tag[filled, None].repeat(T, 1))
+                np.testing.assert_array_equal(rb.buffers["s_next"][:, :, 0].cpu().numpy()[filled], want_tag[filled, None].repeat(T, 1) + 0.5)
+                assert (rb.buffers["o"][:, :, 0, 0].cpu().numpy()[~filled] == -1.0).all()
+            if st["latest3"] is not None:
+                kk = min(3, rb.current_size)
+                assert rb.latest_indices(kk) == st["latest3"]
+                lat = rb.sample_latest(kk)["r"][:, 0, 0].cpu().numpy()
+                off = 0.01 * list(rb.buffers).index("r") if route == "store_episode" else 0.0
+                np.testing.assert_allclose(lat, want_tag[np.asarray(st["latest3"])] + off, rtol=0, atol=1e-4)
+        # sample(): uniform over the filled part, with replacement (:63-68) -- every drawn row is a stored episode
+        g = torch.Generator(device="cuda").manual_seed(size)
+        smp = rb.sample(64, generator=g)["r"][:, 0, 0].cpu().numpy()
+        off = 0.01 * list(rb.buffers).index("r") if route == "store_episode" else 0.0
+        assert np.isin(np.round(smp - off).astype(int), want_tag[want_tag >= 0].astype(int)).all()
+
+
+def test_generate_episodes_into_ring_follows_reference_slots():
+    """The collector's `into=` route against the reference's recorded slot sequence (case size 16: stores of 1..7 episodes):
+    an env of `inc` copies is run per store, the ring must hold the batch's rewards in the recorded slots."""
+    cases = json.load(open(os.path.join(GOLDEN_DIR, "replay_indices.json")))
+    case = [c for c in cases if c["size"] == 16][0]
+    args = cs.make_env_args("flight_easy", n_agents=3)
+    envs = {}
+    rb = None
+    want = {}
+    for step_no, st in enumerate(case["steps"][:16]):
+        k = st["inc"]
+        if k not in envs:
+            envs[k] = cs.BatchedFlightEnv(args, batch=k, freeze_done=True)
+            cs.apply_env_info(args, envs[k])
+        env = envs[k]
+        if rb is None:
+            rb = cs.DeviceReplayBuffer(args, case["size"])
+        env.seed(np.arange(k) + 1000 * step_no)
+        acts = torch.randint(0, 3, (args.episode_limit, k, 3), device="cuda", generator=torch.Generator(device="cuda").manual_seed(step_no))
+        col = cs.EpisodeCollector(env)
+        ep, rew, win, found = col.generate_episodes(actions=acts, init=True)
+        env.seed(np.arange(k) + 1000 * step_no)
+        ep2, rew2, _, _ = col.generate_episodes(actions=acts, init=True, into=rb)
+        assert ep2 is None and torch.equal(rew, rew2)
+        assert (rb.current_idx, rb.current_size) == (st["current_idx"], st["current_size"])
+        for j, slot in enumerate(st["idx"]):
+            want[slot] = {key: ep[key][j].clone() for key in ep}
+        for slot, epd in want.items():
+            for key in epd:
+                assert torch.equal(rb.buffers[key][slot], epd[key]), (step_no, slot, key)

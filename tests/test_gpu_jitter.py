@@ -24,27 +24,21 @@ VARIANTS = {"jitter_n3": ["-DCS_JITTER"], "odsafe_n3": ["-DCS_OD_SAFE_WAIT"], "o
 
 
 def variant_path(name):
-    return os.path.join(ROOT, "build", "var", name + ".so")
+    from cooperative_search_amd import build as b
+    return b.variant_path(name)
 
 
 def build_variant(name):
-    """hipcc <flags> -DCS_ONLY_N=3 -> build/var/<name>.so (also built by __graft_entry__.build(), so that it travels to the GPU
-    box); rebuilt when older than its sources.  None when it is missing and there is no hipcc."""
+    """build/var/<name>.so through cooperative_search_amd.build.build_variant (also run by __graft_entry__.build(), so that the
+    variants travel to the GPU box): compiled with -DCS_SOURCE_HASH=<hash of sources + flags>, current when its recorded hash is
+    that -- never by mtime.  None when it is missing and there is no hipcc."""
     from cooperative_search_amd import build as b
-    lib = variant_path(name)
-    srcs = [os.path.join(b.CSRC, s) for s in b.SOURCES] + b.HEADERS
-    if os.path.exists(lib) and all(os.path.getmtime(lib) >= os.path.getmtime(s) for s in srcs):
-        return lib
-    hipcc = b.hipcc_path()
-    if hipcc is None:
-        return lib if os.path.exists(lib) else None
-    os.makedirs(os.path.dirname(lib), exist_ok=True)
-    tmp = f"{lib}.tmp.{os.getpid()}"
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"] + VARIANTS[name] +
-                          ["-DCS_ONLY_N=3", "-I", os.path.join(ROOT, "include"), "coopsearch.hip", "policy.hip", "episodes.hip", "-o", tmp],
-                          cwd=b.CSRC)
-    os.replace(tmp, lib)
-    return lib
+    return b.build_variant(name, VARIANTS[name], only_n=3)
+
+
+def expected_hash(name):
+    from cooperative_search_amd import build as b
+    return b.variant_hash(VARIANTS[name], 3)
 
 
 def build_all_variants():
@@ -62,7 +56,11 @@ def test_pair_kernel_variant_builds_equal_the_step_kernel(name):
     lib = build_variant(name)
     if lib is None:
         pytest.skip(f"no {name} build and no hipcc")
-    env = dict(os.environ, COOPSEARCH_LIB=lib)
+    # the variant must have been compiled from the PRESENT sources with ITS flags: the hash compiled into it says so (a stale
+    # build would still equal its own step kernel and pass without testing the current protocol); the child's loader checks again
+    from cooperative_search_amd import build as b
+    assert b.embedded_hash(lib) == expected_hash(name), f"{lib} is a stale build: run __graft_entry__.build() where hipcc is"
+    env = dict(os.environ, COOPSEARCH_LIB=lib, COOPSEARCH_LIB_HASH=expected_hash(name))
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "jitter_child.py")], env=env, capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     assert p.stdout.count("bit-identical") == 2, p.stdout

@@ -1007,3 +1007,65 @@ def test_flight_c4_scale_auto_reset_matches_oracle():
                 np.testing.assert_allclose(env.get_state().cpu().numpy(), ob.state, rtol=0, atol=F32_TOL)
         compare_with_oracle(env, ob, B, n, m, "flight B=1024 auto-reset")
         assert hdr(env)[:, _lib.H_EPISODES].min() >= 3
+
+
+@pytest.mark.parametrize("binding", ["torch", "ctypes"])
+@pytest.mark.parametrize("call", ["step", "rollout"])
+@pytest.mark.parametrize("variant", ["flight_easy", "flight"])
+def test_check_actions_refuses_out_of_range_values_like_the_reference(binding, call, variant):
+    """CS_CHECK_ACTIONS (include/coopsearch.h): the reference raises IndexError at dyaw[act] for an action >= 3
+    (flight_env_easy.py:259-262); the batched kernels have no bounds check in their loops (any value other than 1 / 2 acts
+    as 0), so the check runs on the device before the call steps anything: IndexError with the reference's wording, the
+    env state untouched.  On by default for batches of up to 64 envs; a 3 and a -1 (Python's negative index is the B = 1
+    adapter's business, not the batched path's) are both refused."""
+    B, n, T = 8, 3, 5
+    env = cs.BatchedFlightEnv(cs.make_env_args(variant, n_agents=n), batch=B, binding=binding)
+    assert env.check_actions          # B <= 64
+    before = {k: v.clone() for k, v in raw_state(env).items()}
+    good = torch.randint(0, 3, (T, B, n), device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    for bad_value, where in ((3, (2, 5, 1)), (-1, (0, 0, 0)), (7, (4, 7, 2))):
+        acts = good.clone()
+        acts[where] = bad_value
+        with pytest.raises(IndexError, match="list index out of range") as ei:
+            if call == "rollout":
+                env.rollout(acts)
+            else:
+                env.step(acts[where[0]])
+        msg = str(ei.value)
+        assert f"action {bad_value} " in msg and f"env {where[1]}, agent {where[2]}" in msg
+        if call == "rollout":
+            assert f"step {where[0]}," in msg
+        after = raw_state(env)
+        for k in before:
+            assert torch.equal(before[k], after[k]), (k, "a refused call must not step anything")
+    # int32 tables too; and the call goes through once the table is clean
+    with pytest.raises(IndexError):
+        bad32 = good.to(torch.int32)
+        bad32[1, 1, 1] = 3
+        env.rollout(bad32) if call == "rollout" else env.step(bad32[1])
+    if call == "rollout":
+        env.rollout(good)
+    else:
+        env.step(good[0])
+    assert not torch.equal(before["agent"], raw_state(env)["agent"])
+    # large batches: unchecked by default (no synchronisation in the production loop), checked on request
+    big = cs.BatchedFlightEnv(cs.make_env_args(variant, n_agents=n), batch=256, binding=binding)
+    assert not big.check_actions
+    a = torch.full((256, n), 3, dtype=torch.int64, device="cuda")
+    big.step(a)                                           # acts as action 0, like every value other than 1 / 2
+    chk = cs.BatchedFlightEnv(cs.make_env_args(variant, n_agents=n), batch=256, binding=binding, check_actions=True)
+    with pytest.raises(IndexError, match="list index out of range"):
+        chk.step(a)
+
+
+def test_b1_adapter_action_indices_follow_python_list_indexing():
+    """dyaw[act] (flight_env_easy.py:259-262): 3 raises IndexError, -1 is dyaw[-1] = -pi/18 (action 2)."""
+    args = cs.make_env_args("flight_easy", n_agents=3)
+    a, b = cs.FlightSearchEnvEasy(args, cs.load_targets(), seed=3), cs.FlightSearchEnvEasy(args, cs.load_targets(), seed=3)
+    for e in (a, b):
+        e.seed(3)
+        e.reset()
+    with pytest.raises(IndexError, match="list index out of range"):
+        a.step([0, 3, 1])
+    ra, rb = a.step([-1, -2, -3]), b.step([2, 1, 0])
+    assert ra == rb and np.array_equal(a.get_state(), b.get_state())
