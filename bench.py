@@ -278,6 +278,7 @@ def cpu_baseline_inproc(env_name, n, batch, budget_s=10.0):
     with its p10 / median / p90.  The envs of a region are handed out dynamically, 64 at a time (whole cache lines of every
     output), so one descheduled thread costs its current chunk and not the whole region."""
     import numpy as np
+    mask0 = set(os.sched_getaffinity(0))   # before libgomp binds the master thread to its place (OMP_PROC_BIND)
     from oracle import oracle as orc
     n_cores, smt = physical_cores()
     quota = cpu_quota()
@@ -353,7 +354,7 @@ def cpu_baseline_inproc(env_name, n, batch, budget_s=10.0):
             "faster_but_unsteady": faster or None,
             "pinning": {"OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES"),
                         "physical_cores": n_cores, "threads_per_core": smt, "cgroup_cpu_quota": quota,
-                        "affinity_cpus": len(os.sched_getaffinity(0)), "affinity": cpu_list_str(os.sched_getaffinity(0)),
+                        "affinity_cpus": len(mask0), "affinity": cpu_list_str(mask0),
                         "affinity_source": "parent's mask before its NUMA binding" if os.environ.get("BENCH_CPU_BASELINE_AFFINITY")
                         else "inherited",
                         "note": "own process, one thread per physical core at most (no SMT siblings), never more threads than "
@@ -929,6 +930,8 @@ def main():
                                  "flight", 3, 8192, "step", 400, 100, "auto"),
                 side_measurement(cs, dev, comm, "c4 flight 3a15t B=8192 (cs_rollout: sweep of step t beside step t + 1)",
                                  "flight", 3, 8192, "rollout", 400, 100, "auto"),
+                side_measurement(cs, dev, comm, "flight 3a15t B=32768 (cs_rollout; 328 MB of maps: past the 256 MiB Infinity Cache)",
+                                 "flight", 3, 32768, "rollout", 40, 20, "auto"),
                 side_measurement(cs, dev, comm, "flight_easy 3a15t B=262144 (lane-per-env kernel: the HBM-regime kernel)",
                                  "flight_easy", 3, 262144, "rollout", 200, 100, "auto"),
                 side_measurement(cs, dev, comm, "flight_easy 3a15t B=1048576 (lane-per-env kernel; batch sweep asymptote)",

@@ -3028,8 +3028,10 @@ __device__ __forceinline__ void trig_heading_pair(const double *T, double ya, do
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
     const unsigned long long u = (unsigned long long)__double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u & 0xffffffffull), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
+    // bound_ctrl: a lane whose source lies outside its 16-lane row receives 0 -- what the zero "old" operand gave before, without the
+    // two v_mov 0 per moved double that operand cost (16 VALU instructions per repulsion stage at 5 agents)
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u & 0xffffffffull), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
     return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
 }
 // lane I of every octet receives the value of lane J of the same octet (octets are aligned halves of the 16-lane DPP rows)
@@ -3074,9 +3076,12 @@ struct OctKin {   // one lane's agent during the kinematics of a step
 #endif
 __device__ __forceinline__ void div2_same_denominator(double nx, double ny, double den, double &qx, double &qy) {
 #if CS_SHARED_RCP_DIV
+    // the guard: den within 2^-100 .. 2^100, each numerator zero or within that range (NaN and infinities fail the <=).  The lower
+    // bounds of the numerators are tested on their binary exponents (v_frexp_exp_i32_f64 gives 0 for a zero, so a zero passes): eight
+    // instructions where the six range comparisons of round 4 took eighteen
     const double LO = 0x1p-100, HI = 0x1p100;
-    const double ax = fabs(nx), ay = fabs(ny);
-    const bool plain = (den >= LO) & (den <= HI) & ((ax == 0.0) | ((ax >= LO) & (ax <= HI))) & ((ay == 0.0) | ((ay >= LO) & (ay <= HI)));
+    const int e_lo = min(__builtin_amdgcn_frexp_exp(nx), __builtin_amdgcn_frexp_exp(ny));
+    const bool plain = (den >= LO) & (den <= HI) & (fabs(nx) <= HI) & (fabs(ny) <= HI) & (e_lo >= -99);
     if (__builtin_expect(__ballot(!plain) == 0ull, 1)) {
         double r = __builtin_amdgcn_rcp(den);
         r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
@@ -3098,14 +3103,18 @@ __device__ __forceinline__ void div2_same_denominator(double nx, double ny, doub
 // later stages.  The two fp64 divisions run only if SOME env of the wavefront has such a neighbour in this stage.
 template <int N, int I, bool SHARED_DIV>
 struct OctStage {
-    static __device__ __forceinline__ void run(const DevParams &p, const double2 (*pos)[OCT_PAD], int o, int t, bool act_lane,
-                                               OctKin &k) {
+    static __device__ __forceinline__ void run(const DevParams &p, const double2 (&pre)[N], int t, bool act_lane,
+                                               unsigned long long act_mask, OctKin &k) {
         if constexpr (I < N) {
-            const double2 pi = pos[o][I];   // agent I's position BEFORE its move (the array is rewritten after the loop)
+            const double2 pi = pre[I];   // agent I's position BEFORE its move (read from the team's LDS row ahead of the trig evaluation)
             const double xi = pi.x, yi = pi.y;
             const double dx = k.cx - xi, dy = k.cy - yi;
-            const bool inr = act_lane & (t != I) & (dx * dx + dy * dy < p.force_d2) & ((k.cx != xi) | (k.cy != yi));
-            if (__ballot(inr)) {   // wave-uniform
+            const bool c_lt = dx * dx + dy * dy < p.force_d2, c_nx = k.cx != xi, c_ny = k.cy != yi;
+            const bool inr = act_lane & (t != I) & c_lt & (c_nx | c_ny);
+            // "some lane is in range", from the three comparisons' own lane masks (a ballot of a bare comparison IS its result register;
+            // a ballot of the combined predicate costs a select and a compare to rebuild that mask) and the step's mask of agent lanes
+            const unsigned long long not_i = ~(0x0101010101010101ull << I);
+            if (__ballot(c_lt) & (__ballot(c_nx) | __ballot(c_ny)) & act_mask & not_i) {   // wave-uniform
                 const double ex = xi - k.cx, ey = yi - k.cy;
                 const double den = ex * ex + ey * ey;
                 double qx, qy;   // force_k*(x-x_a)/den: product first, then the division
@@ -3132,7 +3141,7 @@ struct OctStage {
                 k.cy = k.yf;
                 k.hit = k.hitf;
             }
-            OctStage<N, I + 1, SHARED_DIV>::run(p, pos, o, t, act_lane, k);
+            OctStage<N, I + 1, SHARED_DIV>::run(p, pre, t, act_lane, act_mask, k);
         }
     }
 };
@@ -3149,6 +3158,11 @@ __device__ __forceinline__ unsigned oct_kinematics(const DevParams &p, const dou
     const double PI = 3.141592653589793, TWO_PI = 2.0 * 3.141592653589793, THREE_PI = 3.0 * 3.141592653589793;
     const double DYAW = 3.141592653589793 / 18.0;
     const bool upd = (t < N) & stepping;
+    // the team's pre-move positions: every stage tests against one of them, and the LDS row does not change before the stages are
+    // through -- all N reads are issued here, ahead of the trig evaluation, instead of one exposed LDS round trip per stage
+    double2 pre[N];
+#pragma unroll
+    for (int I = 0; I < N; I++) pre[I] = pos[o][I];
     double yaw = e.yaw;
     yaw = act == 1 ? yaw + DYAW : (act == 2 ? yaw + -DYAW : yaw);  // dyaw = [0, pi/18, -pi/18][act]
     yaw = yaw > TWO_PI ? yaw - TWO_PI : (yaw < 0.0 ? yaw + TWO_PI : yaw);
@@ -3194,13 +3208,14 @@ __device__ __forceinline__ unsigned oct_kinematics(const DevParams &p, const dou
     bool any_pair = !FASTPATH;
 #pragma unroll
     for (int I = 0; I < (FASTPATH ? N : 0); I++) {
-        const double2 pi = pos[o][I];
+        const double2 pi = pre[I];
         const double qx = t < I ? k.xf : e.x, qy = t < I ? k.yf : e.y;
         const double dx = qx - pi.x, dy = qy - pi.y;
         any_pair = any_pair | ((t != I) & (dx * dx + dy * dy < p.force_d2) & ((qx != pi.x) | (qy != pi.y)));
     }
-    if (__ballot(any_pair & upd)) {
-        OctStage<N, 0, SHARED_DIV>::run(p, pos, o, t, upd, k);
+    const unsigned long long upd_mask = __ballot(upd);
+    if (FASTPATH ? __ballot(any_pair & upd) != 0ull : upd_mask != 0ull) {
+        OctStage<N, 0, SHARED_DIV>::run(p, pre, t, upd, upd_mask, k);
     } else {
         k.cx = k.xf;
         k.cy = k.yf;
@@ -3226,13 +3241,18 @@ __device__ __forceinline__ int oct_detect(const DevParams &p, const double2 (*po
     int rank0[N], rank1[N];
     int base = 0;
     const unsigned below0 = (1u << t) - 1u, below1 = (1u << (t + OG)) - 1u;
+    // (a ballot of a bare comparison is the comparison's own result register; the lanes that hold a target of a stepping env are
+    // the same for every agent: their mask is taken once and applied on the scalar side)
+    const unsigned long long has0m = __ballot(has0), has1m = __ballot(has1);
 #pragma unroll
     for (int i = 0; i < N; i++) {
         const double2 a = pos[o][i];
         const double dx0 = e.tx[0] - a.x, dy0 = e.ty[0] - a.y, dx1 = e.tx[1] - a.x, dy1 = e.ty[1] - a.y;
-        inr0[i] = has0 & (dx0 * dx0 + dy0 * dy0 <= p.view_r2);   // (t_x-x)**2 + (t_y-y)**2 <= view_range**2
-        inr1[i] = has1 & (dx1 * dx1 + dy1 * dy1 <= p.view_r2);
-        const unsigned gm = oct_slice(__ballot(inr0[i]), sh8) | (oct_slice(__ballot(inr1[i]), sh8) << OG);
+        const bool c0 = dx0 * dx0 + dy0 * dy0 <= p.view_r2;   // (t_x-x)**2 + (t_y-y)**2 <= view_range**2
+        const bool c1 = dx1 * dx1 + dy1 * dy1 <= p.view_r2;
+        inr0[i] = has0 & c0;
+        inr1[i] = has1 & c1;
+        const unsigned gm = oct_slice(__ballot(c0) & has0m, sh8) | (oct_slice(__ballot(c1) & has1m, sh8) << OG);
         rank0[i] = base + __popc(gm & below0);   // agent-major order of the reference's double loop
         rank1[i] = base + __popc(gm & below1);
         base += __popc(gm);
@@ -3245,10 +3265,21 @@ __device__ __forceinline__ int oct_detect(const DevParams &p, const double2 (*po
         return (bool)(((r >= 64 ? t64b : t64a) >> (r & 63)) & 1ull);
     };
     bool hit0 = false, hit1 = false;
+    // teams of 5 and more can draw past slot 63 -- an env with more than 64 (agent, target) pairs in range in ONE step, which no
+    // run has ever shown -- so the common case reads every slot from the first 64-bit window (no per-slot window select) and a
+    // wave-uniform test sends the other one through the general form
+    if (N * CS_MAX_TARGETS <= 64 || __builtin_expect(__ballot(base > 64) == 0ull, 1)) {
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-        hit0 = hit0 | (inr0[i] & slot(rank0[i]));
-        hit1 = hit1 | (inr1[i] & slot(rank1[i]));
+        for (int i = 0; i < N; i++) {
+            hit0 = hit0 | (inr0[i] & (bool)((t64a >> rank0[i]) & 1ull));
+            hit1 = hit1 | (inr1[i] & (bool)((t64a >> rank1[i]) & 1ull));
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            hit0 = hit0 | (inr0[i] & slot(rank0[i]));
+            hit1 = hit1 | (inr1[i] & slot(rank1[i]));
+        }
     }
     e.mt_pos = wrap624(e.mt_pos + 2 * base);
     e.words += (unsigned long long)(2 * base);
@@ -3801,6 +3832,21 @@ __global__ __launch_bounds__(OCT_BLOCK, CS_OCT_WAVES) void k_rollout_oct(DevPara
 #define CS_OD_RING_E3 8   /* ring depth of the three-wavefront variant (measured at c2: 2 -> 2.74e9, 4 -> 3.07e9, 8 -> 3.15e9) */
 #endif
 constexpr int OD_BLOCK = 128;
+// Envs per workgroup of the pair kernels.  8 = every octet of the wavefronts holds an env.  4 (experiment, VERDICT r4 #7: twice the
+// workgroups at 4096 envs, so that a workgroup with a close agent pair delays a smaller share of a short launch): octets 4..7 are dead
+// lanes.  Measured in DESIGN.md section 9.
+#ifndef CS_OD_ENVS
+#define CS_OD_ENVS 8
+#endif
+constexpr int OD_ENVS = CS_OD_ENVS;
+// Teams from this size on divide the two components of a repulsion term with ONE reciprocal in K (div2_same_denominator: the same
+// quotients bit for bit).  Small teams keep the plain divisions: K is alone on its SIMD there and the range check in front of the
+// shared sequence lengthens its chain (c2: -1.9 %, round 4); large teams run four wavefronts per SIMD at the VALU issue limit,
+// where only the instruction count matters.
+#ifndef CS_OD_SHARED_DIV_FROM_N
+#define CS_OD_SHARED_DIV_FROM_N 99
+#endif
+static_assert(OD_ENVS == 8 || OD_ENVS == 4, "envs per workgroup of k_rollout_od");
 // steps K may be ahead of D (power of two).  The pair variant serves up to 16384 envs with eight workgroups per CU: 20 KB of LDS each,
 // four slots.  The three-wavefront variant stops at 8192 envs = four workgroups per CU, so its ring can be eight deep (30 KB + E's row buffer):
 // K absorbs more of D's events before it has to wait for a slot.
@@ -3884,6 +3930,22 @@ __device__ __forceinline__ int2 lds_peek2(const int *base) {
     return make_int2(v.x, v.y);
 }
 
+// The same read in two halves: issued here, waited for (lds_peek2_wait) where the words are needed -- K reads its flow-control words for
+// the NEXT loop head in the middle of a step, so the LDS round trip runs beside the step's publication instead of in front of the next
+// step.  (The compiler does not know the asm is an LDS read; its own lgkmcnt waits can only become longer by one outstanding read it
+// does not count, never shorter: LDS operations return in order.)
+template <int OFF0, int OFF1>
+__device__ __forceinline__ int2 lds_peek2_issue(const int *base) {
+    static_assert(OFF0 >= 0 && OFF0 < 256 && OFF1 >= 0 && OFF1 < 256, "ds_read2_b32 offsets are 8-bit dword counts");
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    v2i v;
+    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=&v"(v) : "v"(lds_offset_of(base)), "n"(OFF0), "n"(OFF1) : "memory");
+    return make_int2(v.x, v.y);
+}
+__device__ __forceinline__ void lds_peek2_wait(int2 &v) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v.x), "+v"(v.y) : : "memory");
+}
+
 #ifndef CS_OD_COLD_PARAMS
 #define CS_OD_COLD_PARAMS 1
 #endif
@@ -3942,12 +4004,12 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
     SPIN_DECL;
     const int o = lane >> 3, sh8 = lane & ~(OG - 1);
     int t = lane & (OG - 1);   // (made opaque once per step: lane predicates are recomputed, not held in SGPR pairs)
-    const int wave_b0 = io.env0 + blockIdx.x * OCT_ENVS;
+    const int wave_b0 = io.env0 + blockIdx.x * OD_ENVS;
     const int b_end = io.env0 + io.env_n;
     const int b = wave_b0 + o;
-    const bool live = VEC || b < b_end;
+    const bool live = (VEC || b < b_end) && (OD_ENVS == OCT_ENVS || o < OD_ENVS);
     if (role < 2) BLK_STAMP(is_k ? 0 : 4);
-    const int nvalid = b_end - wave_b0 < OCT_ENVS ? b_end - wave_b0 : OCT_ENVS;   // >= 1: the grid covers env_n exactly
+    const int nvalid = b_end - wave_b0 < OD_ENVS ? b_end - wave_b0 : OD_ENVS;   // >= 1: the grid covers env_n exactly
     const int W = 4 * N + 3 * p.n_targets;
     bool ag = t < N;
     const bool auto_reset = io.flags & CS_AUTO_RESET, freeze = io.flags & CS_FREEZE_DONE;
@@ -4008,7 +4070,7 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
         };
         int fix_seen = 0;
         // the state after step `sp` from the state after step sp - 1, for the octets in `sel`, into ring slot sp % OD_RING
-        auto produce = [&](int sp, int a, bool sel) __attribute__((always_inline)) {
+        auto produce = [&](int sp, int a, bool sel, auto &&between) __attribute__((always_inline)) {
             const bool rs = sel && live && k_done && auto_reset;   // predicted reset (flight_env_easy.py:139-180: start poses)
             if (__ballot(rs)) {
                 if (rs) {
@@ -4028,9 +4090,10 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
 #ifdef CS_OD_ABL_NOKIN   /* experiment: what D alone sustains */
             const unsigned out = 0u;
 #else
-            const unsigned out = oct_kinematics<N>(p, T, sh.kpos, o, t, sh8, stepping, a, e, sp);
+            const unsigned out = oct_kinematics<N, (N >= CS_OD_SHARED_DIV_FROM_N)>(p, T, sh.kpos, o, t, sh8, stepping, a, e, sp);
 #endif
             KIN_STAMP_SP(6);
+            between();   // (the main loop issues its next flow-control read here)
             if (stepping) {
                 k_out = out;
                 k_time += 1;
@@ -4076,11 +4139,17 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                for (int j = fs + 1; j < produced; j++) produce(j, abase[(size_t)j * astep], mine);
+                for (int j = fs + 1; j < produced; j++) produce(j, abase[(size_t)j * astep], mine, []() {});
                 fix_seen = req;
                 post(&sh.fix_ack, req);
             }
         };
+#ifndef CS_OD_EARLY_PEEK
+#define CS_OD_EARLY_PEEK 1
+#endif
+        constexpr int OFF_FIX = (int)(offsetof(OdShared, fix_req) - offsetof(OdShared, d_steps)) / 4;
+        constexpr int OFF_E = (int)(offsetof(OdShared, e_steps) - offsetof(OdShared, d_steps)) / 4;
+        int2 pv = make_int2(0, 0);
         for (int s = 0; s < io.T; s++) {   // (D zeroed the counters before the barrier that published the trig table)
             asm volatile("" : "+v"(t));
             ag = t < N;
@@ -4092,19 +4161,28 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
             // s - OD_RING out; E never passes D).  The progress word and D's fix request come in ONE LDS round trip, and the
             // common case -- slot free, nothing to fix -- touches none of the fix-up code (whose state updates otherwise cost a
             // row of register copies at every pass through the loop head).
-            constexpr int OFF_FIX = (int)(offsetof(OdShared, fix_req) - offsetof(OdShared, d_steps)) / 4;
-            constexpr int OFF_E = (int)(offsetof(OdShared, e_steps) - offsetof(OdShared, d_steps)) / 4;
-            const int2 pv = E3 ? lds_peek2<OFF_E, OFF_FIX>(&sh.d_steps) : lds_peek2<0, OFF_FIX>(&sh.d_steps);
+            // (the words were requested in the middle of the previous step -- CS_OD_EARLY_PEEK -- and may be that old: both only ever
+            // grow, so an old progress word can only make K look again below, and an old fix_req only delays the fix by a step.  The
+            // slot rule holds as before: K overwrites slot s after ONE read that showed d_steps (e_steps) > s - RING, and that read
+            // also returned every fix_req posted before that progress word)
+            if (!CS_OD_EARLY_PEEK || s == 0) pv = E3 ? lds_peek2<OFF_E, OFF_FIX>(&sh.d_steps) : lds_peek2<0, OFF_FIX>(&sh.d_steps);
+            else lds_peek2_wait(pv);
             if (__builtin_expect(pv.x <= s - OD_RING || pv.y != fix_seen, 0)) {
                 for (;;) {
+                    // progress word FIRST, fix request second: the request that belongs to a progress value was posted before it,
+                    // so a fix read issued after the progress read cannot miss it (the other order could see an old fix_req and a
+                    // new progress word and overwrite the very slot the fix restores from)
+                    const int prog = peek(E3 ? &e_steps : &sh.d_steps);
                     handle_fix(s);
-                    if (peek(E3 ? &e_steps : &sh.d_steps) > s - OD_RING) break;
+                    if (prog > s - OD_RING) break;
                     SPIN_TICK;
                     __builtin_amdgcn_s_sleep(2);
                 }
             }
             DUO_STAMP(2);
-            produce(s, act, true);
+            produce(s, act, true, [&]() __attribute__((always_inline)) {
+                if (CS_OD_EARLY_PEEK) pv = E3 ? lds_peek2_issue<OFF_E, OFF_FIX>(&sh.d_steps) : lds_peek2_issue<0, OFF_FIX>(&sh.d_steps);
+            });
             DUO_STAMP(1);
             OD_JITTER(2);
             post(&sh.k_steps, s + 1);
@@ -4143,18 +4221,18 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
         }
         auto peek = [](const int *w) __attribute__((always_inline)) { return lds_peek(w); };
         constexpr int W_MAX = 4 * N + 3 * CS_MAX_TARGETS;
-        constexpr int Q = (OCT_ENVS * W_MAX / 4 + 63) / 64;   // float4 chunks per lane of the largest tile
-        const int ol = lane < OCT_ENVS * N ? lane : OCT_ENVS * N - 1;
+        constexpr int Q = (OD_ENVS * W_MAX / 4 + 63) / 64;   // float4 chunks per lane of the largest tile
+        const int ol = lane < OD_ENVS * N ? lane : OD_ENVS * N - 1;
         const int orow = ol / N, oag = ol - orow * N;
         const int obs_lds = orow * W + 4 * oag;
-        const int rtw = lane & 7;
+        const int rtw = (lane & 7) < OD_ENVS ? (lane & 7) : OD_ENVS - 1;
         float *p_rew = io.reward + wave_b0 + rtw;
         uint8_t *p_term = io.terminated + wave_b0 + rtw, *p_win = io.win + wave_b0 + rtw;
         v4f *p_obs = reinterpret_cast<v4f *>(io.obs + (size_t)wave_b0 * N * 4) + ol;
         v4f *p_st = reinterpret_cast<v4f *>(io.state + (size_t)wave_b0 * W);
         int chunk[Q];
 #pragma unroll
-        for (int q = 0; q < Q; q++) chunk[q] = lane + 64 * q < OCT_ENVS * W / 4 - 1 ? lane + 64 * q : OCT_ENVS * W / 4 - 1;
+        for (int q = 0; q < Q; q++) chunk[q] = lane + 64 * q < OD_ENVS * W / 4 - 1 ? lane + 64 * q : OD_ENVS * W / 4 - 1;
         int rf_served = 0;
         auto rf_serve = [&]() __attribute__((always_inline)) {   // EREF: a row refresh for D, if one is asked for
             const int seq = peek(&rf.rf_req);
@@ -4340,7 +4418,7 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
     //  * -DCS_OD_SAFE_WAIT turns the counted wait into a full drain and -DCS_OD_ASYNC=0 removes the requests altogether: both builds
     //    must reproduce the shipped one bit for bit (tests/test_gpu_jitter.py builds and compares them).
     constexpr int W_MAX = 4 * N + 3 * CS_MAX_TARGETS;
-    constexpr int Q = (OCT_ENVS * W_MAX / 4 + 63) / 64;   // float4 chunks per lane of the largest tile = state stores per step
+    constexpr int Q = (OD_ENVS * W_MAX / 4 + 63) / 64;   // float4 chunks per lane of the largest tile = state stores per step
     constexpr int STEP_STORES = 3 + 1 + Q;                // reward, terminated, win | obs | state
     static_assert(Q >= 1 && STEP_STORES == 4 + Q, "STEP_STORES counts the stores of the VEC && EMIT step: keep it next to them");
     auto wait_for_requests = [&]() __attribute__((always_inline)) {
@@ -4399,7 +4477,7 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
     v4f *p_st = reinterpret_cast<v4f *>(io.state + (size_t)wave_b0 * W);
     int chunk[Q];
 #pragma unroll
-    for (int q = 0; q < Q; q++) chunk[q] = lane + 64 * q < OCT_ENVS * W / 4 - 1 ? lane + 64 * q : OCT_ENVS * W / 4 - 1;
+    for (int q = 0; q < Q; q++) chunk[q] = lane + 64 * q < OD_ENVS * W / 4 - 1 ? lane + 64 * q : OD_ENVS * W / 4 - 1;
     BLK_STAMP(5);
     for (int s = 0; s < io.T; s++) {
         asm volatile("" : "+v"(t));
@@ -5366,12 +5444,12 @@ template <int N>
 void launch_od(const cs_config *cfg, const DevParams &p, StepIO io, hipStream_t s) {
     const size_t W = 4 * (size_t)cfg->n_agents + 3 * (size_t)cfg->n_targets;
     const bool aligned = !io.state || ((reinterpret_cast<size_t>(io.state) & 15) == 0 && ((size_t)p.B * W) % 4 == 0);
-    const int full = aligned ? (p.B / OCT_ENVS) * OCT_ENVS : 0;
+    const int full = aligned ? (p.B / OD_ENVS) * OD_ENVS : 0;
     io.min_ahead = 2 * cfg->n_agents * CS_MAX_TARGETS;  // rows are topped up in place whenever one runs low
     if (full > 0) {
         io.env0 = 0;
         io.env_n = full;
-        const dim3 grid((unsigned)(full / OCT_ENVS));
+        const dim3 grid((unsigned)(full / OD_ENVS));
         // three wavefronts per 8 envs (K, D and the emitting E) while five such workgroups per CU hold the batch in one round
         const bool e3 = (io.flags & CS_KERNEL_ODE) || (!(io.flags & CS_KERNEL_OD) && p.B <= CS_ODE_UPTO);
         if (io.obs && io.state && e3) hipLaunchKernelGGL((k_rollout_od<N, true, true, true>), grid, dim3(OD_BLOCK + 64), 0, s, p, io);
@@ -5381,7 +5459,7 @@ void launch_od(const cs_config *cfg, const DevParams &p, StepIO io, hipStream_t 
     if (p.B - full > 0) {   // the tail (or an unaligned output tensor): plain stores, runtime checks
         io.env0 = full;
         io.env_n = p.B - full;
-        hipLaunchKernelGGL((k_rollout_od<N, false, false, false>), dim3((unsigned)((p.B - full + OCT_ENVS - 1) / OCT_ENVS)), dim3(OD_BLOCK), 0, s, p, io);
+        hipLaunchKernelGGL((k_rollout_od<N, false, false, false>), dim3((unsigned)((p.B - full + OD_ENVS - 1) / OD_ENVS)), dim3(OD_BLOCK), 0, s, p, io);
     }
 }
 // cs_rollout: the first-generation lane kernel's lower bound, by bench.py's protocol (round 3): 3 agents 65536 envs octet 7.8e9 against
@@ -5797,6 +5875,18 @@ int cs_metrics(const cs_config *cfg, void *state_dev, double *out4_dev, void *st
     return launched("cs_metrics");
 }
 
+#ifdef CS_REGION_COUNTS
+// measurement builds only (tools/spill_exec.py): the region counters of k_rollout_lanev (rollout_lanev.h: LV_COUNT)
+int cs_debug_region_counts(unsigned long long *out16_host, int reset) {
+    if (out16_host && hipMemcpyFromSymbol(out16_host, HIP_SYMBOL(g_region), 16 * sizeof(unsigned long long)) != hipSuccess)
+        return fail(CS_E_LAUNCH, "cs_debug_region_counts: hipMemcpyFromSymbol");
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_region), z, sizeof(z)) != hipSuccess) return fail(CS_E_LAUNCH, "cs_debug_region_counts: reset");
+    }
+    return CS_OK;
+}
+#endif
 #ifdef CS_TIMELINE
 int cs_debug_read_spin(unsigned *host1024x4) {
     hipDeviceSynchronize();

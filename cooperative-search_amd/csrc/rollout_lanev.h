@@ -45,6 +45,13 @@
 #ifndef CS_LV_WAVES_LARGE
 #define CS_LV_WAVES_LARGE 2   /* ... teams of 6 to 8 */
 #endif
+// In-loop refresh: a wavefront tops up one env per step, and takes any env with fewer than this many twisted words left (the one
+// running lowest first).  A refresh reads and rewrites the whole 2.6 KB row whatever it twists, so the threshold sets the MT19937
+// traffic: at 352 some env always qualifies and every env comes round every 64 steps (42 B read + 39 B written per env-step,
+// profiles/r05_lanev_traffic.md); lower thresholds refresh by need.
+#ifndef CS_LV_NORMAL
+#define CS_LV_NORMAL 352
+#endif
 #ifndef CS_LV_BLOCK
 #define CS_LV_BLOCK 256   /* threads per workgroup of k_rollout_lanev (>= 128: load_trig_to_lds) */
 #endif
@@ -54,6 +61,16 @@ constexpr int LV_PIECE = 32;           // get_state rows per staging piece: half
 constexpr int LV_SLOT_FLOATS = 4 * G * 2;   // reset hand-over: four rows of 16 (ntx, nty) pairs
 constexpr int LV_TAPE_ROWS = TAPE_DW + 3;   // hit tapes of the wavefront's 64 envs in LDS, [dword][lane]; three rows of zeros behind
                                             // them so that a window of up to 96 + 31 bits never reads past the end
+
+// -DCS_REGION_COUNTS (measurement builds only, tools/spill_exec.py): how often each conditional region of the step loop runs, per
+// wavefront-step -- the weights that turn the static spill report (where the v_readlane / v_writelane instructions ARE) into executed
+// instructions.  Read back through cs_debug_region_counts().
+#ifdef CS_REGION_COUNTS
+__device__ unsigned long long g_region[16];
+#define LV_COUNT(k) do { if ((int)(__ffsll((long long)__ballot(1)) - 1) == (int)(threadIdx.x & 63)) atomicAdd(&g_region[k], 1ull); } while (0)
+#else
+#define LV_COUNT(k) do {} while (0)
+#endif
 
 template <int N>
 struct EnvV {
@@ -102,6 +119,7 @@ __device__ __forceinline__ void kinematics_v(const DevParams &p, const double *T
         }
         double fx = 0.0, fy = 0.0;
         while (pend) {   // flight_env_easy.py:293-301, the neighbours within force_dist in ascending order
+            LV_COUNT(11);
             const int j = __ffs((int)pend) - 1;
             pend &= pend - 1;
             double xa = 0.0, ya = 0.0;
@@ -158,7 +176,9 @@ __device__ __forceinline__ void lv_advance_finish(const DevParams &p, int b0, in
 template <class EnvT>
 __device__ __forceinline__ void lv_advance_now(const DevParams &p, int b0, int lane, unsigned long long need, unsigned *rowbuf, EnvT &e,
                                                unsigned *tl, int &tpos) {
+    LV_COUNT(6);
     while (need) {
+        LV_COUNT(7);
         const int src = __ffsll((long long)need) - 1;
         need &= need - 1;
         RowRegs rr;
@@ -260,12 +280,14 @@ __global__ __launch_bounds__(LV_BLOCK, lv_waves(N)) void k_rollout_lanev(DevPara
         for (int i = 0; i < N; i++) act[i] = act_next[i];
         const size_t slot = (size_t)s * p.B + arow;
         LANE_STAMP(0);
+        LV_COUNT(0);
         REAL_STAMP(8);
         bool done = live && (e.target_find >= p.n_targets || e.time_step >= p.time_limit);
         // ---- auto-reset (flight_env_easy.py:79-182): the four 16-lane groups of the wavefront each take one resetting env per
         //      round (lane = polar attempt / target); the new targets come back through LDS, the counters by shuffle
         const unsigned long long need = __ballot(done && auto_reset);
         if (__builtin_expect(need != 0ull, 0)) {
+            LV_COUNT(1);
             const DevParams &cp = cold_params();
             const CS_AS4 DevParams *q4 = cold_params4();
             const bool mine = (need >> lane) & 1ull;
@@ -275,6 +297,7 @@ __global__ __launch_bounds__(LV_BLOCK, lv_waves(N)) void k_rollout_lanev(DevPara
             const unsigned fm = tm == 0 ? ~q4->deter_mask & tmk : 0u;
             unsigned long long pend = need;
             for (int round = 0; pend; round++) {
+                LV_COUNT(2);
                 unsigned long long m = pend;
                 for (int q = 0; q < grp; q++) m &= m ? m - 1 : 0ull;   // this group's env: the grp-th pending one
                 const int src = m ? __ffsll((long long)m) - 1 : -1;
@@ -303,6 +326,7 @@ __global__ __launch_bounds__(LV_BLOCK, lv_waves(N)) void k_rollout_lanev(DevPara
                         }
                     }
                     if (!lean) {   // several batches, or words twisted on the fly: the generic placement from the untouched cursor
+                        LV_COUNT(3);
                         unsigned long long wt = 0ull;
                         reset_targets(cp, cp.mt + (size_t)br * MT_STRIDE, t16, gshift, g_pos, wt, g_ahead, mx, my);
                         g_words = (int)wt;
@@ -318,6 +342,7 @@ __global__ __launch_bounds__(LV_BLOCK, lv_waves(N)) void k_rollout_lanev(DevPara
                         near = near | ((t16 < nt) & (ddx * ddx + ddy * ddy <= vr2));
                     }
                     if (__builtin_expect(((__ballot(near) >> gshift) & 0xffffull) != 0ull, 0)) {   // group-uniform
+                        LV_COUNT(4);
                         Env<N> g;
 #pragma unroll
                         for (int i = 0; i < N; i++) {
@@ -420,7 +445,7 @@ __global__ __launch_bounds__(LV_BLOCK, lv_waves(N)) void k_rollout_lanev(DevPara
         RowRegs rr;
         int cand;
         auto request_row = [&]() __attribute__((always_inline)) {
-            constexpr int URGENT = LOW + 64, NORMAL = 352 > LOW + 128 ? 352 : LOW + 128;
+            constexpr int URGENT = LOW + 64, NORMAL = CS_LV_NORMAL > LOW + 128 ? CS_LV_NORMAL : LOW + 128;
             const unsigned long long urgent = __ballot(e.ahead < URGENT), normal = __ballot(e.ahead < NORMAL);
             cand = urgent ? __ffsll((long long)urgent) - 1 : (normal ? __ffsll((long long)normal) - 1 : -1);
             if (cand >= 0) row_load(p.mt + (size_t)(b0 + cand) * MT_STRIDE, lane, rr);
@@ -456,6 +481,7 @@ __global__ __launch_bounds__(LV_BLOCK, lv_waves(N)) void k_rollout_lanev(DevPara
                 unsigned m = sure & tmask;
                 unsigned fz = maybe & ~sure & tmask;
                 while (fz) {  // (t_x-x)**2 + (t_y-y)**2 <= view_range**2 on the fp64 values
+                    LV_COUNT(10);
                     const int j = __ffs((int)fz) - 1;
                     fz &= fz - 1;
                     const double2 tt = reinterpret_cast<const double2 *>(p.tgt + (size_t)b * G * 2)[j];
@@ -495,6 +521,7 @@ __global__ __launch_bounds__(LV_BLOCK, lv_waves(N)) void k_rollout_lanev(DevPara
             for (int k = 1; k < NW; k++) any |= z[k];
             unsigned long long mlo = 0ull, mhi = 0ull;   // the pairs that missed
             if (__builtin_expect(__ballot(any != 0u) != 0ull, 0)) {
+                LV_COUNT(8);
                 // in-range pairs before agent i's (agent-major order): base[i]
                 int base[N + 1];
                 base[0] = 0;
@@ -502,6 +529,7 @@ __global__ __launch_bounds__(LV_BLOCK, lv_waves(N)) void k_rollout_lanev(DevPara
                 for (int i = 0; i < N; i++)
                     base[i + 1] = base[i] + __popc((unsigned)((i < 4 ? lo >> (16 * i) : hi >> (16 * (i - 4))) & 0xffffull));
                 while (__ballot(any != 0u)) {   // wave-uniform
+                    LV_COUNT(9);
                     if (any != 0u) {
                         int r = 0;
                         bool got = false;
@@ -562,7 +590,10 @@ __global__ __launch_bounds__(LV_BLOCK, lv_waves(N)) void k_rollout_lanev(DevPara
         }
         LANE_STAMP(5);
         // ---- in-loop refresh, second half (wave-uniform): the row has long arrived; its new tape goes to the env's lane
-        if (cand >= 0) lv_advance_finish(p, b0, lane, cand, rr, rowbuf, e, tl, tpos);
+        if (cand >= 0) {
+            LV_COUNT(5);
+            lv_advance_finish(p, b0, lane, cand, rr, rowbuf, e, tl, tpos);
+        }
         {   // a lane that cannot wait for its turn (several running low at once): on the spot
             const unsigned long long low = __ballot(e.ahead < LOW);
             if (__builtin_expect(low != 0ull, 0)) lv_advance_now(p, b0, lane, low, rowbuf, e, tl, tpos);
@@ -602,6 +633,11 @@ __global__ __launch_bounds__(LV_BLOCK, lv_waves(N)) void k_rollout_lanev(DevPara
         if (VEC || io.state) {   // get_state rows (flight_env_easy.py:190-216), half a wavefront at a time through the staging piece
 #pragma unroll
             for (int h = 0; h < 2; h++) {   // (unrolled: every store of the step in one straight line)
+                // (the target count as an opaque scalar: left to itself the compiler hoists the sixteen `j < n_targets` tests out of the
+                // step loop as sixteen 64-bit lane masks -- 32 SGPRs of a kernel at its SGPR ceiling, i.e. ~60 v_readlane reloads per
+                // wavefront-step in this block alone, tools/spill_exec.py; recomputed here they are one s_cmp each)
+                int nt = p.n_targets;
+                asm volatile("" : "+s"(nt));
                 if ((lane >> 5) == h && live) {
                     float *row = piece + (size_t)(lane & (LV_PIECE - 1)) * W;
 #pragma unroll
@@ -613,7 +649,7 @@ __global__ __launch_bounds__(LV_BLOCK, lv_waves(N)) void k_rollout_lanev(DevPara
                     }
 #pragma unroll
                     for (int j = 0; j < CS_MAX_TARGETS; j++) {
-                        if (j < p.n_targets) {
+                        if (j < nt) {
                             row[4 * N + 3 * j + 0] = e.ntx[j];
                             row[4 * N + 3 * j + 1] = e.nty[j];
                             row[4 * N + 3 * j + 2] = ((e.found >> j) & 1u) ? 1.0f : 0.0f;
