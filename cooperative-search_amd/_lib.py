@@ -16,7 +16,7 @@ H_WORDS_LO, H_WORDS_HI, H_CURR_REWARD, H_NEWLY_RESET = 8, 9, 10, 11
 SELECT_SOFTMAX, SELECT_SAMPLE = 1, 2
 FREEZE_DONE, AUTO_RESET, ACTIONS_I64, KERNEL_GROUP, KERNEL_LANE, KERNEL_SOLO, KERNEL_DUO, KERNEL_OCT, KERNEL_OD, KERNEL_ODE, KERNEL_LANEV, CHECK_ACTIONS = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048
 
-EXPORTS = ["cs_abi_version", "cs_source_hash", "cs_last_error", "cs_state_layout", "cs_init", "cs_seed", "cs_reset", "cs_step",
+EXPORTS = ["cs_abi_version", "cs_source_hash", "cs_has_legacy_kernels", "cs_last_error", "cs_state_layout", "cs_init", "cs_seed", "cs_reset", "cs_step",
            "cs_rollout", "cs_rollout_policy", "cs_rollout_policy_flight", "cs_emit", "cs_metrics", "cs_mt_canonical", "cs_mt_advance", "cs_policy_packed_floats", "cs_policy_pack", "cs_policy_forward",
            "cs_policy_conv_features", "cs_policy_last_error", "cs_store_episodes", "cs_episodes_last_error", "cs_epsilon_step"]
 
@@ -111,7 +111,7 @@ def load():
     L.cs_policy_conv_features.argtypes = [vp] * 7 + [C.c_int64, C.c_int, vp, vp]
     for name in EXPORTS:
         fn = getattr(L, name)
-        if name not in ("cs_abi_version", "cs_source_hash", "cs_last_error", "cs_policy_packed_floats", "cs_policy_last_error",
+        if name not in ("cs_abi_version", "cs_source_hash", "cs_has_legacy_kernels", "cs_last_error", "cs_policy_packed_floats", "cs_policy_last_error",
                         "cs_episodes_last_error"):
             fn.restype = C.c_int
     if L.cs_abi_version() != ABI_VERSION:
@@ -187,6 +187,13 @@ def pick_binding(binding=None):
         warnings.warn(f"torch.ops.coopsearch is unavailable ({type(exc).__name__}: {exc}); using the ctypes binding of the "
                       "same library", RuntimeWarning, stacklevel=3)
         return "ctypes", None
+
+
+def has_legacy_kernels():
+    """The 16-lane rollout kernels of rounds 1-2 ("solo" / "duo") are in the loaded library (-DCS_LEGACY_KERNELS=1 builds only)."""
+    L = load()
+    L.cs_has_legacy_kernels.restype = C.c_int
+    return bool(L.cs_has_legacy_kernels())
 
 
 def check(rc):

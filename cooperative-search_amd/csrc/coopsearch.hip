@@ -1216,7 +1216,7 @@ __device__ __forceinline__ void emit(const DevParams &p, int t, const Env<N> &e,
 }
 
 #ifdef CS_TIMELINE
-// debug build only: per-stage s_memtime stamps of wavefront 0 / block 0 (tools/exp_timeline.py)
+// debug build only: per-stage s_memtime stamps of wavefront 0 / block 0 (read by tools/exp_*timeline.py of rounds 1-4: git history)
 __device__ unsigned long long g_stamps[64][16];
 #define CS_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && g_tl_step >= 0 && g_tl_step < 64) g_stamps[g_tl_step][k] = __builtin_readcyclecounter(); } while (0)
 __device__ int g_tl_step_dummy;
@@ -3831,6 +3831,12 @@ __global__ __launch_bounds__(OCT_BLOCK, CS_OCT_WAVES) void k_rollout_oct(DevPara
 #ifndef CS_OD_RING_E3
 #define CS_OD_RING_E3 8   /* ring depth of the three-wavefront variant (measured at c2: 2 -> 2.74e9, 4 -> 3.07e9, 8 -> 3.15e9) */
 #endif
+// The 16-lanes-per-env ROLLOUT kernels of rounds 1-2 (k_rollout "solo", k_rollout_duo) are selected by no dispatch row any more
+// (DESIGN.md section 4); they stay in the source behind this switch for cross-kernel comparisons (CS_KERNEL_SOLO / CS_KERNEL_DUO then
+// work again) and cost 16 kernel instantiations of compile time.  Without them CS_KERNEL_GROUP rollouts are T launches of k_step.
+#ifndef CS_LEGACY_KERNELS
+#define CS_LEGACY_KERNELS 0
+#endif
 constexpr int OD_BLOCK = 128;
 // Envs per workgroup of the pair kernels.  8 = every octet of the wavefronts holds an env.  4 (experiment, VERDICT r4 #7: twice the
 // workgroups at 4096 envs, so that a workgroup with a close agent pair delays a smaller share of a short launch): octets 4..7 are dead
@@ -5538,6 +5544,7 @@ int cs_abi_version(void) { return CS_ABI_VERSION; }
 #define CS_SOURCE_HASH ""
 #endif
 const char *cs_source_hash(void) { return CS_SOURCE_HASH; }
+int cs_has_legacy_kernels(void) { return CS_LEGACY_KERNELS; }
 const char *cs_last_error(void) { return g_err; }
 
 int cs_state_layout(const cs_config *cfg, cs_layout *out) {
@@ -5712,6 +5719,7 @@ int cs_rollout(const cs_config *cfg, void *state_dev, const void *actions_dev, i
                       state_out_dev ? state_out_dev + (size_t)t0 * B * W : nullptr, flags, tc};
             CS_DISPATCH_N(cfg->n_agents, launch_lane<N>(cfg, p, it, lane_smem(cfg), s));
         }
+#if CS_LEGACY_KERNELS
     } else if ((flags & CS_KERNEL_SOLO) || ((flags & CS_KERNEL_DUO) == 0 && !duo_pays(cfg))) {
         io.min_ahead = prepass_min_ahead(cfg, T);   // rows are topped up in the kernels' prologue: no pre-pass launch
         CS_DISPATCH_N(cfg->n_agents,
@@ -5722,6 +5730,23 @@ int cs_rollout(const cs_config *cfg, void *state_dev, const void *actions_dev, i
         CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_rollout_duo<N>, dim3((unsigned)((p.B + DUO_ENVS - 1) / DUO_ENVS)), dim3(DUO_BLOCK),
                                                         0, (hipStream_t)stream, p, io));
     }
+#else
+    } else if (flags & (CS_KERNEL_SOLO | CS_KERNEL_DUO)) {
+        return fail(CS_E_CONFIG, "k_rollout / k_rollout_duo (the 16-lanes-per-env rollout kernels of rounds 1-2) are not in this build: "
+                                 "compile with -DCS_LEGACY_KERNELS=1");
+    } else {
+        // CS_KERNEL_GROUP without the round-2 rollout kernels: T launches of the 16-lane step kernel, each on its own [t] slice
+        hipStream_t s = (hipStream_t)stream;
+        const size_t n = (size_t)cfg->n_agents, W = 4 * n + 3 * (size_t)cfg->n_targets, B = (size_t)p.B;
+        const size_t act_w = n * ((flags & CS_ACTIONS_I64) ? 8 : 4);
+        for (int t = 0; t < T; t++) {
+            StepIO it{(const char *)actions_dev + (size_t)t * B * act_w, reward_dev + (size_t)t * B, terminated_dev + (size_t)t * B,
+                      win_dev + (size_t)t * B, obs_dev ? obs_dev + (size_t)t * B * n * 4 : nullptr,
+                      state_out_dev ? state_out_dev + (size_t)t * B * W : nullptr, flags, 1};
+            CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL((k_step<N, 0>), dim3(env_blocks(p)), dim3(BLOCK), 0, s, p, it));
+        }
+    }
+#endif
     return launched("cs_rollout");
 }
 

@@ -50,7 +50,7 @@ struct PolicyParams {
 };
 
 #ifdef POL_TIMELINE
-// debug build only: per-phase s_memtime stamps of thread 0 / block 0 (tools/exp_policy_timeline.py)
+// debug build only: per-phase s_memtime stamps of thread 0 / block 0 (read by tools/exp_policy_timeline.py of round 4: git history)
 __device__ unsigned long long g_pstamps[32][8];
 #define POL_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && iter < 32) g_pstamps[iter][k] = __builtin_readcyclecounter(); } while (0)
 #else

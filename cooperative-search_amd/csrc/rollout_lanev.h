@@ -50,7 +50,8 @@
 // traffic: at 352 some env always qualifies and every env comes round every 64 steps (42 B read + 39 B written per env-step,
 // profiles/r05_lanev_traffic.md); lower thresholds refresh by need.
 #ifndef CS_LV_NORMAL
-#define CS_LV_NORMAL 352
+#define CS_LV_NORMAL 0   /* NORMAL = LOW + 128.  Measured A/B on one box, two passes (round 5): 3 agents 352 -> 224: 2^18 envs 21.7 -> 21.3 us
+                            per step, 65536 envs 8.3 -> 8.05; 5 agents 352 -> 288: no difference */
 #endif
 #ifndef CS_LV_BLOCK
 #define CS_LV_BLOCK 256   /* threads per workgroup of k_rollout_lanev (>= 128: load_trig_to_lds) */
@@ -693,14 +694,17 @@ __global__ __launch_bounds__(LV_BLOCK, lv_waves(N)) void k_rollout_lanev(DevPara
         LANE_STAMP(7);
     }
     if (live) {
-        int4 *h4 = reinterpret_cast<int4 *>(p.hdr + (size_t)b * CS_H_WORDS);
+        // (the state blob's tables through cold_params(): read from the kernarg segment here, so that their six pointers are not
+        // held -- i.e. spilled and reloaded -- across the step loop of a kernel at its SGPR ceiling)
+        const DevParams &cp = cold_params();
+        int4 *h4 = reinterpret_cast<int4 *>(cp.hdr + (size_t)b * CS_H_WORDS);
         h4[0] = make_int4((int)e.found, (int)e.newly, e.target_find, e.flags);
         h4[1] = make_int4(e.time_step, e.total_reward, e.mt_pos, e.episodes);
-        int *h2 = p.hdr + (size_t)b * CS_H_WORDS + 8;   // (word 11, CS_H_NEWLY_RESET, is flight's: left as it is)
+        int *h2 = cp.hdr + (size_t)b * CS_H_WORDS + 8;   // (word 11, CS_H_NEWLY_RESET, is flight's: left as it is)
         *reinterpret_cast<int2 *>(h2) = make_int2((int)(unsigned)(e.words & 0xffffffffull), (int)(unsigned)(e.words >> 32));
         h2[2] = e.curr_reward;
-        p.ahead[b] = e.ahead;
-        double4 *a4 = reinterpret_cast<double4 *>(p.agent + (size_t)b * CS_MAX_AGENTS * 4);
+        cp.ahead[b] = e.ahead;
+        double4 *a4 = reinterpret_cast<double4 *>(cp.agent + (size_t)b * CS_MAX_AGENTS * 4);
 #pragma unroll
         for (int i = 0; i < N; i++) a4[i] = make_double4(e.ax[i], e.ay[i], e.yaw[i], 0.0);
         // the tape goes back to the state blob rebased to the cursor, for the next launch
@@ -708,10 +712,10 @@ __global__ __launch_bounds__(LV_BLOCK, lv_waves(N)) void k_rollout_lanev(DevPara
 #pragma unroll
         for (int k = 0; k < TAPE_DW; k++) tape[k] = tl[k * 64 + lane];
         tape_shift<8>(tape, tpos);
-        U4 *tp = reinterpret_cast<U4 *>(p.tape + (size_t)b * TAPE_STRIDE);
+        U4 *tp = reinterpret_cast<U4 *>(cp.tape + (size_t)b * TAPE_STRIDE);
         tp[0] = U4{tape[0], tape[1], tape[2], tape[3]};
         tp[1] = U4{tape[4], tape[5], tape[6], tape[7]};
         tp[2] = U4{tape[8], tape[9], (unsigned)(e.words & 0xffffffffull), (unsigned)(e.words >> 32)};
-        tp[3] = U4{(unsigned)(p.detect_K & 0xffffffffull), (unsigned)(p.detect_K >> 32), 0u, 0u};
+        tp[3] = U4{(unsigned)(cp.detect_K & 0xffffffffull), (unsigned)(cp.detect_K >> 32), 0u, 0u};
     }
 }

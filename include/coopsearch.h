@@ -35,7 +35,7 @@ extern "C" {
 
 #define CS_ABI_VERSION 7   /* 2: cs_layout.ahead_off (pre-twisted MT words), cs_mt_canonical; 3: cs_layout.job_off;
                               4: cs_source_hash, CS_KERNEL_OCT; 5: CS_KERNEL_ODE; 6: cs_epsilon (exploration schedule),
-                              cs_epsilon_step, CS_KERNEL_LANEV; 7: CS_CHECK_ACTIONS */
+                              cs_epsilon_step, CS_KERNEL_LANEV; 7: CS_CHECK_ACTIONS, cs_has_legacy_kernels */
 #define CS_MAX_AGENTS 8
 #define CS_MAX_TARGETS 16
 #define CS_MAX_MAP 64
@@ -174,6 +174,10 @@ int cs_abi_version(void);
 /* Hash of the sources this library was compiled from (cooperative-search_amd/build.py:source_hash; "" for a build that
  * did not pass it): how the loader tells a library built from other sources, instead of comparing file mtimes. */
 const char *cs_source_hash(void);
+/* 1 when the library holds the 16-lanes-per-env ROLLOUT kernels of rounds 1-2 (CS_KERNEL_SOLO / CS_KERNEL_DUO; built with
+ * -DCS_LEGACY_KERNELS=1).  The default build does not: no dispatch row selects them, those two flags then make cs_rollout return
+ * CS_E_CONFIG, and a CS_KERNEL_GROUP rollout is T launches of the 16-lane step kernel (same results). */
+int cs_has_legacy_kernels(void);
 const char *cs_last_error(void);
 
 /* Fills `out` with the state-blob layout for cfg (cfg->batch envs).  Host only. */

@@ -45,8 +45,12 @@ def run(kernel, args, B, lengths, mode):
 
 def main():
     name = os.path.basename(cs.lib.library_path())
-    assert name in ("jitter_n3.so", "odsafe_n3.so", "odsync_n3.so") or os.environ.get("CS_CHILD_ANY_LIB") == "1", cs.lib.library_path()
-    for kernel in ("od", "ode"):
+    assert name in ("jitter_n3.so", "odsafe_n3.so", "odsync_n3.so", "legacy_n3.so") or os.environ.get("CS_CHILD_ANY_LIB") == "1", cs.lib.library_path()
+    # legacy_n3.so (-DCS_LEGACY_KERNELS=1): the 16-lane rollout kernels of rounds 1-2, which the default build no longer holds
+    kernels = ("solo", "duo") if name == "legacy_n3.so" else ("od", "ode")
+    if name == "legacy_n3.so":
+        assert cs.lib.has_legacy_kernels()
+    for kernel in kernels:
         w = run(kernel, custom(target_num=2, target_mode=1, detect_prob=1.0, view_range=25), 1000, (7, 64, 3, 100, 26),
                 dict(freeze_done=False, auto_reset=True))
         assert w > 5000, w   # tens of unpredicted wins per env

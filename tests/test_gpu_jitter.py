@@ -10,7 +10,9 @@
   odsync_n3   -DCS_OD_ASYNC=0    no requests ahead of time at all: every row and every attempt batch is loaded where it is used.
 If the shipped kernel ever read LDS before a request had landed, it would differ from the step kernel where these two do not.
 The three-wavefront variant's row refreshes run in its emitting wavefront (request / old tape meanwhile / adoption, CS_OD_E_REFRESH):
-the jitter build pauses at those hand-shakes too, and the child's last scenario makes every env refresh its row every few steps."""
+the jitter build pauses at those hand-shakes too, and the child's last scenario makes every env refresh its row every few steps.
+  legacy_n3   -DCS_LEGACY_KERNELS=1  (round 5) k_rollout ("solo") and k_rollout_duo, the 16-lane rollout kernels of rounds 1-2 that no dispatch
+                                 row selects and the default build leaves out: the same scenarios, so they stay compiling and bit-exact."""
 import concurrent.futures
 import os
 import subprocess
@@ -20,7 +22,9 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-VARIANTS = {"jitter_n3": ["-DCS_JITTER"], "odsafe_n3": ["-DCS_OD_SAFE_WAIT"], "odsync_n3": ["-DCS_OD_ASYNC=0"]}
+VARIANTS = {"jitter_n3": ["-DCS_JITTER"], "odsafe_n3": ["-DCS_OD_SAFE_WAIT"], "odsync_n3": ["-DCS_OD_ASYNC=0"],
+            # (round 5) the 16-lane rollout kernels of rounds 1-2, retired from the default build: kept compiling and bit-exact here
+            "legacy_n3": ["-DCS_LEGACY_KERNELS=1"]}
 
 
 def variant_path(name):

@@ -50,6 +50,14 @@ def words(h):
             | (h[:, _lib.H_WORDS_HI].astype(np.uint32).astype(np.uint64) << np.uint64(32)))
 
 
+
+def _need_kernel(kernel):
+    """"solo" / "duo" are the 16-lane rollout kernels of rounds 1-2: in the library only when it was built with
+    -DCS_LEGACY_KERNELS=1 (no dispatch row selects them; include/coopsearch.h: cs_has_legacy_kernels)."""
+    if kernel in ("solo", "duo") and not _lib.has_legacy_kernels():
+        pytest.skip("built without the round-2 rollout kernels (-DCS_LEGACY_KERNELS=1)")
+
+
 GOLDEN_CASES = [(n, k) for n in trace_names() for k in (("group", "lane") if n.startswith("easy") else ("group",))]
 
 
@@ -216,6 +224,7 @@ def compare_with_oracle(env, ob, B, n, m, tag, check_pos=True):
 def test_batched_step_matches_oracle_bit_exact(variant, n, agent_mode, target_mode, B, T, kernel):
     """Frozen-when-done batch against B oracle envs, every step: outputs exact, raw state bit-identical.
     "group-ondemand": no periodic tape refresh, the step kernel twists every word it draws itself."""
+    _need_kernel(kernel)
     m = 15
     seeds = (777 + 13 * np.arange(B)).astype(np.uint32)
     args = cs.make_env_args(variant, n_agents=n, agent_mode=agent_mode, target_mode=target_mode)
@@ -244,6 +253,7 @@ def test_batched_step_matches_oracle_bit_exact(variant, n, agent_mode, target_mo
 
 @pytest.mark.parametrize("kernel", ["group", "group-ondemand", "solo", "duo", "lane", "lanev"])
 def test_auto_reset_and_unfrozen_modes_match_oracle(kernel):
+    _need_kernel(kernel)
     B, n, m, T = 128, 5, 15, 420   # > 2 episodes per env
     seeds = np.arange(B, dtype=np.uint32) + 5
     args = cs.make_env_args("flight_easy", n_agents=n)
@@ -393,6 +403,7 @@ def test_octet_rollout_matches_oracle_bit_exact(variant, n, agent_mode, target_m
 
 @pytest.mark.parametrize("kernel", ["group", "solo", "duo", "lane", "lanev", "oct", "od", "ode"])
 def test_rollout_kernel_equals_stepwise(kernel):
+    _need_kernel(kernel)
     B, n, T = 1000, 3, 200   # not a multiple of 64: exercises the partial last wavefront
     args = cs.make_env_args("flight_easy", n_agents=n)
     seeds = np.arange(B, dtype=np.uint32) + 99
@@ -678,6 +689,7 @@ def _custom_args(variant, **kw):
     ("flight_easy", dict(n_agents=3, time_limit=7)),                             # many episode boundaries
 ])
 def test_unusual_configurations_match_oracle(variant, kw, kernel):
+    _need_kernel(kernel)
     B, T, kw = 96, 90, dict(kw)
     args = _custom_args(variant, **kw)
     n, m = args.n_agents, args.target_num
@@ -871,6 +883,7 @@ def test_long_horizon_matches_oracle(kernel):
     """20 000 steps per env with auto-reset: ~100+ episodes, the circular MT19937 state wraps ~70 times (cursor,
     mirrored head, reset-time batches landing anywhere in the ring).  Rewards are compared every step (in rollout
     chunks), the full raw state at the end."""
+    _need_kernel(kernel)
     B, n, m, chunk, chunks = 64, 3, 15, 250, 80
     seeds = np.arange(B, dtype=np.uint32) * 7 + 5
     env = cs.BatchedFlightEnv(cs.make_env_args("flight_easy", n_agents=n), batch=B, seeds=seeds, freeze_done=False,

@@ -7,14 +7,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rows = []
 for n in (3, 5):
     for B in (1024, 2048, 4096, 8192, 16384, 32768, 65536, 262144, 1048576, 4194304):
-        for kernel in ("solo", "duo", "ode", "od", "oct", "lane", "lanev"):
+        for kernel in ("ode", "od", "oct", "lane", "lanev"):   # (solo / duo, rounds 1-2: -DCS_LEGACY_KERNELS=1 builds only; profiles/r04_batch_sweep.md has them)
             if kernel in ("lane", "lanev") and B < 16384:
                 continue
-            if kernel in ("solo", "duo") and B > (1 << 16):
-                continue
             if kernel in ("od", "oct") and B > (1 << 20):
-                continue
-            if kernel == "duo" and B > (1 << 14):
                 continue
             if kernel == "ode" and B > (1 << 15):
                 continue
