@@ -610,6 +610,21 @@ int cs_policy_pack(const float *fc1_w, const float *fc1_b, const float *w_ih, co
     }
     for (int i = 0; i < PACKED_FLOATS; i++) packed[i] = 0.0f;
 #if CS_POLICY_F16
+    // split_f16 carries a value as hi = fp16(v), lo = fp16((v - hi) * 2048): above fp16's range hi is inf and lo NaN.  A weight
+    // there is refused here; activations are bounded by the weights and the inputs (|obs| <= 1, |h| < 1): the bound
+    // an activation must keep is documented in include/coopsearch.h.
+    {
+        const struct { const float *w; int n; const char *name; } ws[] = {
+            {fc1_w, 64 * in_dim, "fc1.weight"}, {w_ih, 192 * 64, "rnn.weight_ih"}, {w_hh, 192 * 64, "rnn.weight_hh"},
+            {fc2a_w, 64 * 64, "fc2.0.weight"}, {fc2b_w, n_actions * 64, "fc2.2.weight"}};
+        for (const auto &t : ws)
+            for (int i = 0; i < t.n; i++)
+                if (!(fabsf(t.w[i]) <= 65504.0f)) {
+                    snprintf(g_perr, sizeof(g_perr), "cs_policy_pack: %s[%d] = %g is outside the fp16 range (+-65504) of the split-fp16 matrix path",
+                             t.name, i, (double)t.w[i]);
+                    return CS_E_ARG;
+                }
+    }
     // split-fp16 fragments (policy_dev.h): fragment (column tile nt, k-step ks of 32) = hi plane | lo plane, each [64 lanes][8 halves];
     // lane l, j: W[16 nt + (l & 15)][k0 + 32 ks + 8 (l >> 4) + j] for k-blocks (l >> 4) < kblocks, zero beyond
     auto hfrag = [&](int off, int frag, const float *w, int n_out, int k_in, int nt, int k0, int kblocks) {

@@ -244,6 +244,15 @@ def test_policy_pack_layout_host_only():
     assert off == n
     assert L.cs_policy_pack(*[C.c_void_p(w.ctypes.data) for w in ws], 33, nA, C.c_void_p(packed.ctypes.data)) != 0
     assert b"in_dim" in L.cs_policy_last_error()
+    # a weight above fp16's range would travel as hi = inf, lo = NaN: refused, by name; the largest half itself passes
+    for bad in (70000.0, -1e9, float("inf"), float("nan")):
+        w2 = [w.copy() for w in ws]
+        w2[4][17, 5] = bad
+        assert L.cs_policy_pack(*[C.c_void_p(w.ctypes.data) for w in w2], in_dim, nA, C.c_void_p(packed.ctypes.data)) != 0
+        assert b"rnn.weight_hh" in L.cs_policy_last_error() and b"65504" in L.cs_policy_last_error()
+    w2 = [w.copy() for w in ws]
+    w2[0][3, 1] = -65504.0
+    assert L.cs_policy_pack(*[C.c_void_p(w.ctypes.data) for w in w2], in_dim, nA, C.c_void_p(packed.ctypes.data)) == 0
 
 
 def test_torch_op_library_builds_loads_and_registers_every_op():
