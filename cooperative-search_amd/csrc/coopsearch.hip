@@ -5395,6 +5395,9 @@ inline size_t lane_smem(const cs_config *c) {
 #endif
         ;
 }
+#ifndef CS_LV_W_FROM
+#define CS_LV_W_FROM 524288   /* envs from which teams of up to 3 take the three-wavefronts-per-SIMD build of k_rollout_lanev (round 5, A/B on one box, two passes, % of the HBM roofline: 2^18 envs 44.6 / 44.0 two / three wavefronts, 2^19 46.5 / 49.9, 2^20 46.8 / 51.3, 2^22 50.2 / 54.5) */
+#endif
 // k_rollout_lanev launch(es): a VEC launch over the full wavefronts when obs and state are both written and every step's
 // block of get_state rows is 16-byte aligned, a plain launch for the remaining < 64 envs (or for everything otherwise).
 template <int N>
@@ -5407,7 +5410,14 @@ void launch_lanev(const cs_config *cfg, const DevParams &p, StepIO io, hipStream
     if (full > 0) {
         io.env0 = 0;
         io.env_n = full;
-        hipLaunchKernelGGL((k_rollout_lanev<N, true>), dim3((unsigned)((full + LV_BLOCK - 1) / LV_BLOCK)), dim3(LV_BLOCK), smem, s, p, io);
+        if constexpr (N <= 3) {
+            if (full >= CS_LV_W_FROM)   // three wavefronts per SIMD (see k_rollout_lanev)
+                hipLaunchKernelGGL((k_rollout_lanev<N, true, 3>), dim3((unsigned)((full + LV_BLOCK - 1) / LV_BLOCK)), dim3(LV_BLOCK), smem, s, p, io);
+            else
+                hipLaunchKernelGGL((k_rollout_lanev<N, true>), dim3((unsigned)((full + LV_BLOCK - 1) / LV_BLOCK)), dim3(LV_BLOCK), smem, s, p, io);
+        } else {
+            hipLaunchKernelGGL((k_rollout_lanev<N, true>), dim3((unsigned)((full + LV_BLOCK - 1) / LV_BLOCK)), dim3(LV_BLOCK), smem, s, p, io);
+        }
     }
     if (p.B - full > 0) {
         io.env0 = full;

@@ -189,8 +189,11 @@ __device__ __forceinline__ void lv_advance_now(const DevParams &p, int b0, int l
     drain_vmem();   // rare path: joins the steady-state path with nothing of its own in flight
 }
 
-template <int N, bool VEC>
-__global__ __launch_bounds__(LV_BLOCK, lv_waves(N)) void k_rollout_lanev(DevParams p, StepIO io) {
+// WV: wavefronts per SIMD the register budget allows.  lv_waves(N) = 2 everywhere; teams of up to 3 also exist with 3 (168 VGPRs, a handful
+// of spilled registers): slower while a batch is one or two resident rounds (2^18 envs: 4096 wavefronts = 1.33 rounds of 3072), faster once
+// the rounds stop mattering -- launch_lanev takes it from CS_LV_W_FROM envs (measured in DESIGN.md section 9).
+template <int N, bool VEC, int WV = lv_waves(N)>
+__global__ __launch_bounds__(LV_BLOCK, WV) void k_rollout_lanev(DevParams p, StepIO io) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *T = reinterpret_cast<double *>(smem);                                   // trig table (2072 B)
     double *rtab = reinterpret_cast<double *>(smem + LV_HEAD_BYTES - 4 * G * sizeof(double));   // the reset's target tables

@@ -302,7 +302,7 @@ def test_dispatch_table_matches_the_code():
     design = open(os.path.join(ROOT, "DESIGN.md")).read()
     table = design[design.index("<!-- dispatch:begin -->"):design.index("<!-- dispatch:end -->")]
     doc = {m.group(1): int(m.group(2)) for m in re.finditer(r"`(CS_[A-Z_]+)` = (\d+)", table)}
-    assert set(doc) == {"CS_ODE_UPTO", "CS_OD_UPTO", "CS_OCT_FROM", "CS_LANEV_FROM", "CS_LANE_FROM_LARGE_TEAMS"}
+    assert set(doc) == {"CS_ODE_UPTO", "CS_OD_UPTO", "CS_OCT_FROM", "CS_LANEV_FROM", "CS_LV_W_FROM", "CS_LANE_FROM_LARGE_TEAMS"}
     src = open(os.path.join(ROOT, "cooperative-search_amd", "csrc", "coopsearch.hip")).read()
     for name, value in doc.items():
         m = re.search(r"#ifndef " + name + r"\s*\n#define " + name + r"\s+(\d+)", src)

@@ -1082,3 +1082,27 @@ def test_b1_adapter_action_indices_follow_python_list_indexing():
         a.step([0, 3, 1])
     ra, rb = a.step([-1, -2, -3]), b.step([2, 1, 0])
     assert ra == rb and np.array_equal(a.get_state(), b.get_state())
+
+
+@pytest.mark.parametrize("n,B", [(3, 524288 + 37), (2, 524288), (1, 524288 + 64)])
+def test_three_wavefront_lane_kernel_at_its_batch_equals_the_octet_kernel(n, B):
+    """From CS_LV_W_FROM = 524288 envs teams of up to 3 run k_rollout_lanev compiled for three wavefronts per SIMD (168 VGPRs, a few
+    spilled registers: another binary of the same source).  No small-batch test reaches it, so: the default dispatch at that batch
+    (the full wavefronts through the three-wavefront build, a ragged tail through the plain one) against the one-wavefront octet
+    kernel on the same seeds and actions -- every reward / flag / observation / state row of every step, the raw state and the
+    canonical MT rows, bit for bit; two launches back to back, auto-reset."""
+    T = 24
+    args = cs.make_env_args("flight_easy", n_agents=n)
+    seeds = (np.arange(B, dtype=np.uint64) * 2654435761 % (1 << 32)).astype(np.uint32)
+    g = torch.Generator("cuda").manual_seed(n)
+    e1 = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, kernel="oct", freeze_done=False, auto_reset=True)
+    e2 = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, kernel="auto", freeze_done=False, auto_reset=True)
+    for launch in range(2):
+        acts = torch.randint(0, 3, (T, B, n), dtype=torch.int32, device="cuda", generator=g)
+        o1, o2 = e1.rollout(acts), e2.rollout(acts)
+        for k in ("reward", "terminated", "win", "obs", "state"):
+            assert torch.equal(o1[k], o2[k]), (launch, k)
+        del o1, o2
+    r1, r2 = raw_state(e1), raw_state(e2)
+    for k in ("tgt", "agent", "hdr", "mt"):
+        assert torch.equal(r1[k], r2[k]), k

@@ -27,9 +27,9 @@ LABELS = [
     ("k_rollout_oct<5>@100", "oct5_32768", ["k_rollout_oct<5, true, true>"], 100),
     # (one label per kernel: the FIRST workload listed here that was measured; bytes per env-step of the lane-per-env kernel are
     # batch independent above its dispatch threshold)
-    ("k_rollout_lanev<5>@100", "lane5_rollout", ["k_rollout_lanev<5, true>", "k_rollout_lanev<5, false>"], 100),
-    ("k_rollout_lanev<5>@100", "c5s_rollout", ["k_rollout_lanev<5, true>", "k_rollout_lanev<5, false>"], 100),
-    ("k_rollout_lanev<3>@100", "lane3_rollout", ["k_rollout_lanev<3, true>", "k_rollout_lanev<3, false>"], 100),
+    ("k_rollout_lanev<5>@100", "lane5_rollout", ["k_rollout_lanev<5, true, 2>", "k_rollout_lanev<5, false, 2>", "k_rollout_lanev<5, true>", "k_rollout_lanev<5, false>"], 100),
+    ("k_rollout_lanev<5>@100", "c5s_rollout", ["k_rollout_lanev<5, true, 2>", "k_rollout_lanev<5, false, 2>", "k_rollout_lanev<5, true>", "k_rollout_lanev<5, false>"], 100),
+    ("k_rollout_lanev<3>@100", "lane3_rollout", ["k_rollout_lanev<3, true, 2>", "k_rollout_lanev<3, false, 2>", "k_rollout_lanev<3, true>", "k_rollout_lanev<3, false>"], 100),
     ("k_rollout_lane<5>@100", "c5s_rollout", ["k_rollout_lane<5, true>", "k_rollout_lane<5, false>"], 100),
     ("k_rollout_lane<3>@100", "lane3_rollout", ["k_rollout_lane<3, true>", "k_rollout_lane<3, false>"], 100),
     ("k_step<3,1> + k_map<3>@1", "c4_step", ["k_map<3>", "k_step<3, 1>"], 1),

@@ -51,7 +51,7 @@ def line_regions():
     out.append((a, b - 1, "repulsion"))
     a = find("__device__ __forceinline__ void lv_advance_finish("); b = find("__device__ __forceinline__ void lv_advance_now(", a)
     out.append((a - 1, b - 2, "refresh"))
-    a = b; b = find("template <int N, bool VEC>", a)
+    a = b; b = find("template <int N, bool VEC, int WV", a)
     out.append((a - 1, b - 1, "advance_now"))
     return k0, out
 
@@ -63,7 +63,7 @@ def static(n):
         text = None
         for co in sr.code_objects(so, tmp):
             out = subprocess.run([f"{sr.LLVM}/llvm-objdump", "-d", "-l", "--demangle", co], capture_output=True, text=True).stdout
-            m = re.search(r"^[0-9a-f]{16} <void \(anonymous namespace\)::k_rollout_lanev<%d, true>.*?(?=^[0-9a-f]{16} <)" % n, out, re.S | re.M)
+            m = re.search(r"^[0-9a-f]{16} <void \(anonymous namespace\)::k_rollout_lanev<%d, true(?:, 2)?>.*?(?=^[0-9a-f]{16} <)" % n, out, re.S | re.M)
             if m:
                 text = m.group(0)
     ins, cur = [], None   # (addr, mnemonic, branch target, (file, line))

@@ -28,7 +28,7 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 STEP_LOOP_MIN = 4096   # bytes: anything shorter is an inner loop (waits, attempt rounds, twist batches)
 DEFAULT = ["k_rollout_od<3, true, true, true>", "k_rollout_od<5, true, true, true>", "k_rollout_od<5, true, true, false>",
            "k_rollout_od<3, true, true, false>", "k_rollout_oct<3, true, true>", "k_rollout_oct<5, true, true>",
-           "k_rollout_lanev<3, true>", "k_rollout_lanev<5, true>", "k_rollout_lane<3, true>", "k_rollout_lane<5, true>",
+           "k_rollout_lanev<3, true, 2>", "k_rollout_lanev<3, true, 3>", "k_rollout_lanev<5, true, 2>", "k_rollout_lane<3, true>", "k_rollout_lane<5, true>",
            "k_step<3, 0>", "k_step<3, 1>", "k_flight_pipe<3>", "k_rollout_policy<3>"]
 
 
