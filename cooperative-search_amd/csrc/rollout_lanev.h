@@ -73,11 +73,14 @@ __device__ unsigned long long g_region[16];
 #define LV_COUNT(k) do {} while (0)
 #endif
 
+typedef float v2f __attribute__((ext_vector_type(2)));
 template <int N>
 struct EnvV {
     double ax[N], ay[N], yaw[N];
     float csf[N], snf[N];                          // cos / sin of the CURRENT yaw as get_obs emits them
-    float ntx[CS_MAX_TARGETS], nty[CS_MAX_TARGETS]; // targets' normalised coordinates as get_state emits them (norm_target)
+    // targets' normalised coordinates as get_state emits them (norm_target), two targets per register pair: (x of 2k, x of 2k + 1),
+    // (y of 2k, y of 2k + 1) -- the sensor tests run on the packed fp32 pipe, two targets per instruction
+    v2f tnx[CS_MAX_TARGETS / 2], tny[CS_MAX_TARGETS / 2];
     unsigned found, newly;
     int target_find, flags, time_step, total_reward, mt_pos, episodes, curr_reward, ahead;
     unsigned long long words;
@@ -246,8 +249,8 @@ __global__ __launch_bounds__(LV_BLOCK, WV) void k_rollout_lanev(DevParams p, Ste
 #pragma unroll
         for (int j = 0; j < CS_MAX_TARGETS; j++) {
             const double2 tt = t2[j];   // (rows are 16 targets wide: entries past n_targets are zero and never used)
-            e.ntx[j] = (float)((tt.x - p.mid) * p.inv_half);   // what get_state emits (norm_target)
-            e.nty[j] = (float)((tt.y - p.mid) * p.inv_half);
+            e.tnx[j >> 1][j & 1] = (float)((tt.x - p.mid) * p.inv_half);   // what get_state emits (norm_target)
+            e.tny[j >> 1][j & 1] = (float)((tt.y - p.mid) * p.inv_half);
         }
 #pragma unroll
         for (int i = 0; i < N; i++) {
@@ -395,8 +398,8 @@ __global__ __launch_bounds__(LV_BLOCK, WV) void k_rollout_lanev(DevParams p, Ste
 #pragma unroll
                     for (int j = 0; j < CS_MAX_TARGETS; j++) {
                         const float2 v = slots[q * G + j];
-                        e.ntx[j] = v.x;
-                        e.nty[j] = v.y;
+                        e.tnx[j >> 1][j & 1] = v.x;
+                        e.tny[j >> 1][j & 1] = v.y;
                     }
                     // the reset consumed r_words stream words, twisted ones first: their draw slots leave the tape
                     tpos += r_words >> 1;
@@ -476,11 +479,14 @@ __global__ __launch_bounds__(LV_BLOCK, WV) void k_rollout_lanev(DevParams p, Ste
                 // v_alignbit each): bit j of `sure` = (d2 < thr - eps), of `maybe` = (d2 < thr + eps)
                 unsigned sure = 0, maybe = 0;
 #pragma unroll
-                for (int j = CS_MAX_TARGETS - 1; j >= 0; j--) {
-                    const float dx = e.ntx[j] - fx[i], dy = e.nty[j] - fy[i];
-                    const float d2 = __builtin_fmaf(dx, dx, dy * dy);
-                    sure = __builtin_amdgcn_alignbit(sure, __float_as_uint(d2 - thr_lo), 31);
-                    maybe = __builtin_amdgcn_alignbit(maybe, __float_as_uint(d2 - thr_hi), 31);
+                for (int k = CS_MAX_TARGETS / 2 - 1; k >= 0; k--) {   // targets 2k + 1, 2k: one packed instruction per operation
+                    const v2f dx = e.tnx[k] - v2f{fx[i], fx[i]}, dy = e.tny[k] - v2f{fy[i], fy[i]};
+                    const v2f d2 = __builtin_elementwise_fma(dx, dx, dy * dy);   // per element fma(dx, dx, dy * dy), as before
+                    const v2f a = d2 - v2f{thr_lo, thr_lo}, c = d2 - v2f{thr_hi, thr_hi};
+                    sure = __builtin_amdgcn_alignbit(sure, __float_as_uint(a[1]), 31);
+                    sure = __builtin_amdgcn_alignbit(sure, __float_as_uint(a[0]), 31);
+                    maybe = __builtin_amdgcn_alignbit(maybe, __float_as_uint(c[1]), 31);
+                    maybe = __builtin_amdgcn_alignbit(maybe, __float_as_uint(c[0]), 31);
                 }
                 unsigned m = sure & tmask;
                 unsigned fz = maybe & ~sure & tmask;
@@ -654,8 +660,8 @@ __global__ __launch_bounds__(LV_BLOCK, WV) void k_rollout_lanev(DevParams p, Ste
 #pragma unroll
                     for (int j = 0; j < CS_MAX_TARGETS; j++) {
                         if (j < nt) {
-                            row[4 * N + 3 * j + 0] = e.ntx[j];
-                            row[4 * N + 3 * j + 1] = e.nty[j];
+                            row[4 * N + 3 * j + 0] = e.tnx[j >> 1][j & 1];
+                            row[4 * N + 3 * j + 1] = e.tny[j >> 1][j & 1];
                             row[4 * N + 3 * j + 2] = ((e.found >> j) & 1u) ? 1.0f : 0.0f;
                         }
                     }

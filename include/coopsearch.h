@@ -65,7 +65,8 @@ enum {
     CS_KERNEL_GROUP = 8, /* flight_easy: force the 16-lanes-per-env kernels (the default of cs_step up to the lane kernels' range) */
     CS_KERNEL_LANE = 16, /* flight_easy: force the first-generation lane-per-env kernel (the default for teams of 6 to 8 at very
                             large batches; smaller teams get CS_KERNEL_LANEV's kernel); same results */
-    CS_KERNEL_SOLO = 32, /* cs_rollout, 16-lanes-per-env path: one wavefront per four envs does the whole step */
+    CS_KERNEL_SOLO = 32, /* cs_rollout, 16-lanes-per-env path: one wavefront per four envs does the whole step (this flag and the next:
+                            libraries built with -DCS_LEGACY_KERNELS=1 only, cs_has_legacy_kernels(); CS_E_CONFIG otherwise) */
     CS_KERNEL_DUO = 64,  /* ... a kinematics wavefront and a detection wavefront per four envs (default up to 4096 envs
                             of at most 6 agents, where the batch leaves a wave slot per SIMD empty); same results */
     CS_KERNEL_OCT = 128, /* cs_rollout, flight_easy: force the 8-lanes-per-env kernel (lane t owns agent t and targets t, t + 8;
