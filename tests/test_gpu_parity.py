@@ -1106,3 +1106,35 @@ def test_three_wavefront_lane_kernel_at_its_batch_equals_the_octet_kernel(n, B):
     r1, r2 = raw_state(e1), raw_state(e2)
     for k in ("tgt", "agent", "hdr", "mt"):
         assert torch.equal(r1[k], r2[k]), k
+
+
+@pytest.mark.parametrize("kernel", ["oct", "od", "ode", "lanev", "lane"])
+@pytest.mark.parametrize("n", [5, 8])
+def test_every_target_in_view_of_every_agent_draws_past_slot_63(kernel, n):
+    """view_range = 70 on the 50 x 50 map: all 15 targets are within every agent's sensor range in every step, so a step makes
+    15 n draws -- 75 at 5 agents, 120 at 8: past the first 64-bit window of the hit tape, the side path the octet kernels'
+    detection pass takes when an env has more than 64 pairs in range (round 5) -- and a row of 624 stream words lasts four
+    steps (two at 8 agents): the row refresh machinery of every kernel runs flat out.  detect_prob 0.3 keeps episodes long.
+    Against the 16-lane step kernel, step by step: rewards, flags, obs / state rows, raw state, canonical MT rows."""
+    if kernel == "lanev" and n > 5:
+        pytest.skip("k_rollout_lanev serves teams of up to 5")
+    B, T = 200, 48
+    args = cs.make_env_args("flight_easy", n_agents=n)
+    args.view_range, args.detect_prob = 70, 0.3
+    seeds = np.arange(B, dtype=np.uint32) + 4242
+    acts = torch.randint(0, 3, (T, B, n), dtype=torch.int32, device="cuda", generator=torch.Generator("cuda").manual_seed(n))
+    e1 = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, kernel="group", freeze_done=False, auto_reset=True)
+    e2 = cs.BatchedFlightEnv(args, batch=B, seeds=seeds, kernel=kernel, freeze_done=False, auto_reset=True)
+    out = e2.rollout(acts)
+    drew = 0
+    for t in range(T):
+        w0 = words(hdr(e1))
+        r, term, win = e1.step(acts[t])
+        drew = max(drew, int((words(hdr(e1)) - w0).max()))
+        assert torch.equal(r, out["reward"][t]) and torch.equal(term, out["terminated"][t]) and torch.equal(win, out["win"][t]), t
+        if t % 6 == 0 or t == T - 1:
+            assert torch.equal(e1.get_obs(), out["obs"][t]) and torch.equal(e1.get_state(), out["state"][t]), t
+    assert drew >= 2 * 15 * n          # every (agent, target) pair drew in some step: 150 / 240 stream words in one step
+    r1, r2 = raw_state(e1), raw_state(e2)
+    for k in ("tgt", "agent", "hdr", "mt"):
+        assert torch.equal(r1[k], r2[k]), k
