@@ -4172,7 +4172,6 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
             // slot rule holds as before: K overwrites slot s after ONE read that showed d_steps (e_steps) > s - RING, and that read
             // also returned every fix_req posted before that progress word)
             if (!CS_OD_EARLY_PEEK || s == 0) pv = E3 ? lds_peek2<OFF_E, OFF_FIX>(&sh.d_steps) : lds_peek2<0, OFF_FIX>(&sh.d_steps);
-            else lds_peek2_wait(pv);
             if (__builtin_expect(pv.x <= s - OD_RING || pv.y != fix_seen, 0)) {
                 for (;;) {
                     // progress word FIRST, fix request second: the request that belongs to a progress value was posted before it,
@@ -4192,6 +4191,10 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
             DUO_STAMP(1);
             OD_JITTER(2);
             post(&sh.k_steps, s + 1);
+            // the words requested in the middle of this step arrived long ago: the wait is free here, and it sits INSIDE the iteration
+            // that issued the read -- between the two asm statements the compiler believes the registers already hold the words, so
+            // nothing but straight-line code may lie there (a copy at the loop's back edge, say, would copy them too early)
+            if (CS_OD_EARLY_PEEK) lds_peek2_wait(pv);
             act = act_next;
             act_next = act_after;
         }
