@@ -3838,13 +3838,6 @@ __global__ __launch_bounds__(OCT_BLOCK, CS_OCT_WAVES) void k_rollout_oct(DevPara
 #define CS_LEGACY_KERNELS 0
 #endif
 constexpr int OD_BLOCK = 128;
-// Envs per workgroup of the pair kernels.  8 = every octet of the wavefronts holds an env.  4 (experiment, VERDICT r4 #7: twice the
-// workgroups at 4096 envs, so that a workgroup with a close agent pair delays a smaller share of a short launch): octets 4..7 are dead
-// lanes.  Measured in DESIGN.md section 9.
-#ifndef CS_OD_ENVS
-#define CS_OD_ENVS 8
-#endif
-constexpr int OD_ENVS = CS_OD_ENVS;
 // Teams from this size on divide the two components of a repulsion term with ONE reciprocal in K (div2_same_denominator: the same
 // quotients bit for bit).  Small teams keep the plain divisions: K is alone on its SIMD there and the range check in front of the
 // shared sequence lengthens its chain (c2: -1.9 %, round 4); large teams run four wavefronts per SIMD at the VALU issue limit,
@@ -3852,7 +3845,6 @@ constexpr int OD_ENVS = CS_OD_ENVS;
 #ifndef CS_OD_SHARED_DIV_FROM_N
 #define CS_OD_SHARED_DIV_FROM_N 99
 #endif
-static_assert(OD_ENVS == 8 || OD_ENVS == 4, "envs per workgroup of k_rollout_od");
 // steps K may be ahead of D (power of two).  The pair variant serves up to 16384 envs with eight workgroups per CU: 20 KB of LDS each,
 // four slots.  The three-wavefront variant stops at 8192 envs = four workgroups per CU, so its ring can be eight deep (30 KB + E's row buffer):
 // K absorbs more of D's events before it has to wait for a slot.
@@ -4010,12 +4002,12 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
     SPIN_DECL;
     const int o = lane >> 3, sh8 = lane & ~(OG - 1);
     int t = lane & (OG - 1);   // (made opaque once per step: lane predicates are recomputed, not held in SGPR pairs)
-    const int wave_b0 = io.env0 + blockIdx.x * OD_ENVS;
+    const int wave_b0 = io.env0 + blockIdx.x * OCT_ENVS;
     const int b_end = io.env0 + io.env_n;
     const int b = wave_b0 + o;
-    const bool live = (VEC || b < b_end) && (OD_ENVS == OCT_ENVS || o < OD_ENVS);
+    const bool live = VEC || b < b_end;
     if (role < 2) BLK_STAMP(is_k ? 0 : 4);
-    const int nvalid = b_end - wave_b0 < OD_ENVS ? b_end - wave_b0 : OD_ENVS;   // >= 1: the grid covers env_n exactly
+    const int nvalid = b_end - wave_b0 < OCT_ENVS ? b_end - wave_b0 : OCT_ENVS;   // >= 1: the grid covers env_n exactly
     const int W = 4 * N + 3 * p.n_targets;
     bool ag = t < N;
     const bool auto_reset = io.flags & CS_AUTO_RESET, freeze = io.flags & CS_FREEZE_DONE;
@@ -4230,18 +4222,18 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
         }
         auto peek = [](const int *w) __attribute__((always_inline)) { return lds_peek(w); };
         constexpr int W_MAX = 4 * N + 3 * CS_MAX_TARGETS;
-        constexpr int Q = (OD_ENVS * W_MAX / 4 + 63) / 64;   // float4 chunks per lane of the largest tile
-        const int ol = lane < OD_ENVS * N ? lane : OD_ENVS * N - 1;
+        constexpr int Q = (OCT_ENVS * W_MAX / 4 + 63) / 64;   // float4 chunks per lane of the largest tile
+        const int ol = lane < OCT_ENVS * N ? lane : OCT_ENVS * N - 1;
         const int orow = ol / N, oag = ol - orow * N;
         const int obs_lds = orow * W + 4 * oag;
-        const int rtw = (lane & 7) < OD_ENVS ? (lane & 7) : OD_ENVS - 1;
+        const int rtw = lane & 7;
         float *p_rew = io.reward + wave_b0 + rtw;
         uint8_t *p_term = io.terminated + wave_b0 + rtw, *p_win = io.win + wave_b0 + rtw;
         v4f *p_obs = reinterpret_cast<v4f *>(io.obs + (size_t)wave_b0 * N * 4) + ol;
         v4f *p_st = reinterpret_cast<v4f *>(io.state + (size_t)wave_b0 * W);
         int chunk[Q];
 #pragma unroll
-        for (int q = 0; q < Q; q++) chunk[q] = lane + 64 * q < OD_ENVS * W / 4 - 1 ? lane + 64 * q : OD_ENVS * W / 4 - 1;
+        for (int q = 0; q < Q; q++) chunk[q] = lane + 64 * q < OCT_ENVS * W / 4 - 1 ? lane + 64 * q : OCT_ENVS * W / 4 - 1;
         int rf_served = 0;
         auto rf_serve = [&]() __attribute__((always_inline)) {   // EREF: a row refresh for D, if one is asked for
             const int seq = peek(&rf.rf_req);
@@ -4427,7 +4419,7 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
     //  * -DCS_OD_SAFE_WAIT turns the counted wait into a full drain and -DCS_OD_ASYNC=0 removes the requests altogether: both builds
     //    must reproduce the shipped one bit for bit (tests/test_gpu_jitter.py builds and compares them).
     constexpr int W_MAX = 4 * N + 3 * CS_MAX_TARGETS;
-    constexpr int Q = (OD_ENVS * W_MAX / 4 + 63) / 64;   // float4 chunks per lane of the largest tile = state stores per step
+    constexpr int Q = (OCT_ENVS * W_MAX / 4 + 63) / 64;   // float4 chunks per lane of the largest tile = state stores per step
     constexpr int STEP_STORES = 3 + 1 + Q;                // reward, terminated, win | obs | state
     static_assert(Q >= 1 && STEP_STORES == 4 + Q, "STEP_STORES counts the stores of the VEC && EMIT step: keep it next to them");
     auto wait_for_requests = [&]() __attribute__((always_inline)) {
@@ -4486,7 +4478,7 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
     v4f *p_st = reinterpret_cast<v4f *>(io.state + (size_t)wave_b0 * W);
     int chunk[Q];
 #pragma unroll
-    for (int q = 0; q < Q; q++) chunk[q] = lane + 64 * q < OD_ENVS * W / 4 - 1 ? lane + 64 * q : OD_ENVS * W / 4 - 1;
+    for (int q = 0; q < Q; q++) chunk[q] = lane + 64 * q < OCT_ENVS * W / 4 - 1 ? lane + 64 * q : OCT_ENVS * W / 4 - 1;
     BLK_STAMP(5);
     for (int s = 0; s < io.T; s++) {
         asm volatile("" : "+v"(t));
@@ -5463,12 +5455,12 @@ template <int N>
 void launch_od(const cs_config *cfg, const DevParams &p, StepIO io, hipStream_t s) {
     const size_t W = 4 * (size_t)cfg->n_agents + 3 * (size_t)cfg->n_targets;
     const bool aligned = !io.state || ((reinterpret_cast<size_t>(io.state) & 15) == 0 && ((size_t)p.B * W) % 4 == 0);
-    const int full = aligned ? (p.B / OD_ENVS) * OD_ENVS : 0;
+    const int full = aligned ? (p.B / OCT_ENVS) * OCT_ENVS : 0;
     io.min_ahead = 2 * cfg->n_agents * CS_MAX_TARGETS;  // rows are topped up in place whenever one runs low
     if (full > 0) {
         io.env0 = 0;
         io.env_n = full;
-        const dim3 grid((unsigned)(full / OD_ENVS));
+        const dim3 grid((unsigned)(full / OCT_ENVS));
         // three wavefronts per 8 envs (K, D and the emitting E) while five such workgroups per CU hold the batch in one round
         const bool e3 = (io.flags & CS_KERNEL_ODE) || (!(io.flags & CS_KERNEL_OD) && p.B <= CS_ODE_UPTO);
         if (io.obs && io.state && e3) hipLaunchKernelGGL((k_rollout_od<N, true, true, true>), grid, dim3(OD_BLOCK + 64), 0, s, p, io);
@@ -5478,7 +5470,7 @@ void launch_od(const cs_config *cfg, const DevParams &p, StepIO io, hipStream_t 
     if (p.B - full > 0) {   // the tail (or an unaligned output tensor): plain stores, runtime checks
         io.env0 = full;
         io.env_n = p.B - full;
-        hipLaunchKernelGGL((k_rollout_od<N, false, false, false>), dim3((unsigned)((p.B - full + OD_ENVS - 1) / OD_ENVS)), dim3(OD_BLOCK), 0, s, p, io);
+        hipLaunchKernelGGL((k_rollout_od<N, false, false, false>), dim3((unsigned)((p.B - full + OCT_ENVS - 1) / OCT_ENVS)), dim3(OD_BLOCK), 0, s, p, io);
     }
 }
 // cs_rollout: the first-generation lane kernel's lower bound, by bench.py's protocol (round 3): 3 agents 65536 envs octet 7.8e9 against
