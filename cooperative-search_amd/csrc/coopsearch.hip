@@ -2969,17 +2969,54 @@ struct __attribute__((aligned(16))) OctShared {
     unsigned rowbuf[MT_N];                 // one MT19937 row (top-ups)
 };
 
-template <int N>
+// Lanes per env of the "octet" kernels.  LG = 8 is the octet: 8 envs per wavefront, lane t owns agent t and targets t, t + 8.
+// LG = 5 (round 5, teams of exactly 5 with at most 15 targets, k_rollout_od only; built with -DCS_OD_PENT=1 -- measured slower than the
+// octet at the batches the pair kernels serve, see CS_OD_PENT): the same roles, protocol and arithmetic with FIVE
+// lanes per env -- three envs per 16-lane DPP row (lanes 0-4, 5-9, 10-14; lane 15 of every row holds nothing), TWELVE envs per
+// wavefront, lane t owns agent t and targets t, t + 5, t + 10.  Nothing about the octet is left idle by a team of 5 then: the
+// kinematics wavefront does the work of twelve envs in the instructions it spent on eight, the detection pass tests three targets per
+// lane instead of two for half again as many envs.  A lane that holds nothing reports t = 16 (no agent, no target below 16, never
+// "lane 0 of its env"), aliases the last env of its row for reads and is never `live`.
+template <int LG>
+struct OctLay;
+template <>
+struct OctLay<8> {
+    static constexpr int ENVS = 8, TPL = 2;   // envs per wavefront, targets per lane
+    static constexpr unsigned SLICE = 0xffu;
+    static __device__ __forceinline__ bool valid(int) { return true; }
+    static __device__ __forceinline__ int env(int lane) { return lane >> 3; }
+    static __device__ __forceinline__ int t(int lane) { return lane & 7; }
+    static __device__ __forceinline__ int first(int lane) { return lane & ~7; }          // first lane of the lane's env = shift of its ballot slice
+    static __device__ __forceinline__ int first_of(int o) { return 8 * o; }
+    static __device__ __forceinline__ int env_of_first(int f) { return f >> 3; }
+    static constexpr unsigned long long lanes_t(int I) { return 0x0101010101010101ull << I; }   // the lanes with t == I
+};
+template <>
+struct OctLay<5> {
+    static constexpr int ENVS = 12, TPL = 3;
+    static constexpr unsigned SLICE = 0x1fu;
+    static __device__ __forceinline__ int grp(int lane) { return ((lane & 15) * 13) >> 6; }   // 0, 1, 2; 3 for lane 15 of a row
+    static __device__ __forceinline__ bool valid(int lane) { return (lane & 15) != 15; }
+    static __device__ __forceinline__ int env(int lane) { const int g = grp(lane); return 3 * (lane >> 4) + (g < 3 ? g : 2); }
+    static __device__ __forceinline__ int t(int lane) { const int g = grp(lane); return g < 3 ? (lane & 15) - 5 * g : 16; }
+    static __device__ __forceinline__ int first(int lane) { const int g = grp(lane); return (lane & ~15) + 5 * (g < 3 ? g : 2); }
+    static __device__ __forceinline__ int first_of(int o) { return 16 * (o / 3) + 5 * (o % 3); }
+    static __device__ __forceinline__ int env_of_first(int f) { return 3 * (f >> 4) + (((f & 15) * 13) >> 6); }
+    static constexpr unsigned long long lanes_t(int I) { return 0x0421042104210421ull << I; }
+};
+
+template <int N, int LG = OG>
 struct EnvO {
     double x, y, yaw, cs, sn;              // this lane's agent (lanes t < N)
-    double tx[2], ty[2];                   // targets t and t + 8
+    double tx[OctLay<LG>::TPL], ty[OctLay<LG>::TPL];   // targets t + LG k
     unsigned found, newly, newly_reset;    // octet-uniform from here on
     int target_find, flags, time_step, total_reward, mt_pos, episodes, curr_reward, ahead;
     unsigned long long words;
 };
 
-// The octet's slice of a wavefront ballot (bit k = lane 8 o + k)
-__device__ __forceinline__ unsigned oct_slice(unsigned long long ballot, int sh8) { return (unsigned)(ballot >> sh8) & 0xffu; }
+// The env's slice of a wavefront ballot (bit k = lane first + k)
+template <int LG = OG>
+__device__ __forceinline__ unsigned oct_slice(unsigned long long ballot, int sh8) { return (unsigned)(ballot >> sh8) & OctLay<LG>::SLICE; }
 
 // trig_heading for TWO headings at once (a step's new heading and its wall reflection).  Same arithmetic per heading, value for
 // value; the difference is control flow: trig_heading ends in a branch for off-grid headings (only reachable by editing the raw
@@ -3037,12 +3074,12 @@ __device__ __forceinline__ double dpp_f64(double v) {
 // lane I of every octet receives the value of lane J of the same octet (octets are aligned halves of the 16-lane DPP rows)
 template <int I, int J>
 __device__ __forceinline__ double oct_from(double v) {
-    static_assert(I != J && I >= 0 && J >= 0 && I < OG && J < OG, "lanes of one octet");
+    static_assert(I != J && I >= 0 && J >= 0 && I < OG && J < OG, "lanes of one env (which never straddles a 16-lane row)");
     return dpp_f64<(I > J) ? (0x110 | (I - J)) : (0x100 | (J - I))>(v);   // row_shr : row_shl
 }
 // fx, fy in lane I = sum over the neighbours J != I, ASCENDING J like the reference's loop (flight_env_easy.py:296-300), of
 // the contributions (tx, ty) lane J computed.  Contributions of neighbours out of range are +0.0, which never changes a
-// partial sum (no term and no partial sum is ever -0.0: force_k > 0, x - x = +0.0), so padding with them is exact.
+// partial sum (no partial sum is ever -0.0: they start from +0.0, and +0.0 + -0.0 = +0.0 = x - x), so padding with them is exact.
 template <int N, int I, int J = 0>
 struct OctForceSum {
     static __device__ __forceinline__ void run(double tx, double ty, double &fx, double &fy) {
@@ -3101,7 +3138,7 @@ __device__ __forceinline__ void div2_same_denominator(double nx, double ny, doub
 // already-moved one if J < I -- and, if it is within force_dist, computes its term of I's repulsion (:293-301); the terms
 // meet in lane I (ordered DPP sum); lane I moves its agent, applies the wall rule and becomes "already moved" for the
 // later stages.  The two fp64 divisions run only if SOME env of the wavefront has such a neighbour in this stage.
-template <int N, int I, bool SHARED_DIV>
+template <int N, int I, bool SHARED_DIV, int LG = OG>
 struct OctStage {
     static __device__ __forceinline__ void run(const DevParams &p, const double2 (&pre)[N], int t, bool act_lane,
                                                unsigned long long act_mask, OctKin &k) {
@@ -3109,14 +3146,19 @@ struct OctStage {
             const double2 pi = pre[I];   // agent I's position BEFORE its move (read from the team's LDS row ahead of the trig evaluation)
             const double xi = pi.x, yi = pi.y;
             const double dx = k.cx - xi, dy = k.cy - yi;
-            const bool c_lt = dx * dx + dy * dy < p.force_d2, c_nx = k.cx != xi, c_ny = k.cy != yi;
+            const double d2 = dx * dx + dy * dy;
+            const bool c_lt = d2 < p.force_d2, c_nx = k.cx != xi, c_ny = k.cy != yi;
             const bool inr = act_lane & (t != I) & c_lt & (c_nx | c_ny);
             // "some lane is in range", from the three comparisons' own lane masks (a ballot of a bare comparison IS its result register;
             // a ballot of the combined predicate costs a select and a compare to rebuild that mask) and the step's mask of agent lanes
-            const unsigned long long not_i = ~(0x0101010101010101ull << I);
+            const unsigned long long not_i = ~OctLay<LG>::lanes_t(I);
             if (__ballot(c_lt) & (__ballot(c_nx) | __ballot(c_ny)) & act_mask & not_i) {   // wave-uniform
-                const double ex = xi - k.cx, ey = yi - k.cy;
-                const double den = ex * ex + ey * ey;
+                // x_a - x = -(x - x_a) exactly (a difference and its mirror round alike; a zero difference comes out as -0.0 here where
+                // the reference has +0.0: its square is +0.0 all the same, and its term, -0.0, leaves every sum it is added to as it
+                // was -- the sums start from +0.0).  So the squared distance of the term IS the one the range test computed, and the
+                // mirrored differences cost a sign bit in the multiplications instead of two subtractions, two products and a sum.
+                const double ex = -dx, ey = -dy;
+                const double den = d2;
                 double qx, qy;   // force_k*(x-x_a)/den: product first, then the division
                 if constexpr (SHARED_DIV) {
                     div2_same_denominator(p.force_k * ex, p.force_k * ey, inr ? den : 1.0, qx, qy);
@@ -3141,7 +3183,7 @@ struct OctStage {
                 k.cy = k.yf;
                 k.hit = k.hitf;
             }
-            OctStage<N, I + 1, SHARED_DIV>::run(p, pre, t, act_lane, act_mask, k);
+            OctStage<N, I + 1, SHARED_DIV, LG>::run(p, pre, t, act_lane, act_mask, k);
         }
     }
 };
@@ -3152,9 +3194,10 @@ struct OctStage {
 // fewer per stage that runs).  Measured (tools/gpu_r4_f.sh, 3 agents): the one-wavefront octet kernel at 32768 envs +8 %, the pair
 // kernel at 8192 / 16384 envs +2 %, but the c2 pair (4096 envs, K alone on its SIMD and bound by its dependent chain) -1.9 %: the
 // range check in front of the shared sequence lengthens the chain.  So: the one-wavefront kernel only.
-template <int N, bool SHARED_DIV = false>
-__device__ __forceinline__ unsigned oct_kinematics(const DevParams &p, const double *T, const double2 (*pos)[OCT_PAD], int o, int t,
-                                                   int sh8, bool stepping, int act, EnvO<N> &e, int tl_step = -1) {
+template <int N, bool SHARED_DIV = false, int LG = OG, int AP = OCT_PAD>
+__device__ __forceinline__ unsigned oct_kinematics(const DevParams &p, const double *T, const double2 (*pos)[AP], int o, int t,
+                                                   int sh8, bool stepping, int act, EnvO<N, LG> &e, int tl_step = -1) {
+    static_assert(LG == OG || (N == LG), "the 5-lane packing is for teams of exactly 5");
     const double PI = 3.141592653589793, TWO_PI = 2.0 * 3.141592653589793, THREE_PI = 3.0 * 3.141592653589793;
     const double DYAW = 3.141592653589793 / 18.0;
     const bool upd = (t < N) & stepping;
@@ -3215,7 +3258,7 @@ __device__ __forceinline__ unsigned oct_kinematics(const DevParams &p, const dou
     }
     const unsigned long long upd_mask = __ballot(upd);
     if (FASTPATH ? __ballot(any_pair & upd) != 0ull : upd_mask != 0ull) {
-        OctStage<N, 0, SHARED_DIV>::run(p, pre, t, upd, upd_mask, k);
+        OctStage<N, 0, SHARED_DIV, LG>::run(p, pre, t, upd, upd_mask, k);
     } else {
         k.cx = k.xf;
         k.cy = k.yf;
@@ -3227,67 +3270,105 @@ __device__ __forceinline__ unsigned oct_kinematics(const DevParams &p, const dou
     e.yaw = upd ? (k.hit ? yr : yw) : e.yaw;
     e.cs = upd ? (k.hit ? c2 : c1) : e.cs;
     e.sn = upd ? (k.hit ? s2 : s1) : e.sn;
-    return oct_slice(__ballot(k.hit & upd), sh8);
+    return oct_slice<LG>(__ballot(k.hit & upd), sh8);
 }
 
 // Detection pass + reward (flight_env_easy.py:223-253) for the octet's env on the positions in sh.pos; draws from the hit
 // tape, which the caller guarantees to cover a step's worst case.  Returns curr_reward.
-template <int N>
-__device__ __forceinline__ int oct_detect(const DevParams &p, const double2 (*pos)[OCT_PAD], int o, int t, int sh8, bool stepping,
-                                          EnvO<N> &e, unsigned (&tape)[TAPE_DW]) {
+// LAZY (k_rollout_od's step): the tape is NOT shifted by the step's draws.  `tcur` (< 32 on entry and on return) is the bit of
+// tape[0] at which the env's cursor stands: the pass reads its slots from a 64-bit window taken at that bit (two v_alignbit), adds
+// its draws to tcur and lets whole dwords fall out of the tape only when tcur passes 32 -- a wave-uniform test, true in a minority of
+// steps, in front of the ten selects.  The shift of EVERY step it replaces was ten v_alignbit and ten selects per 32 possible draws
+// (teams of 5: 33 VALU instructions per step).  tape_canon() restores the canonical form (cursor at bit 0 of tape[0]), which every
+// other user of the tape expects.
+__device__ __forceinline__ void tape_canon(unsigned (&t)[TAPE_DW], int &tcur) {
+#pragma unroll
+    for (int k = 0; k < TAPE_DW; k++) t[k] = __builtin_amdgcn_alignbit(k + 1 < TAPE_DW ? t[k + 1] : 0u, t[k], (unsigned)tcur);
+    tcur = 0;
+}
+template <int N, int LG, int AP, bool LAZY>
+__device__ __forceinline__ int oct_detect_impl(const DevParams &p, const double2 (*pos)[AP], int o, int t, int sh8, bool stepping,
+                                               EnvO<N, LG> &e, unsigned (&tape)[TAPE_DW], int &tcur) {
     constexpr int MAXDW = (N * CS_MAX_TARGETS) / 32 < 1 ? 1 : (N * CS_MAX_TARGETS) / 32;   // draws of one pass, in dwords
-    const bool has0 = stepping & (t < p.n_targets), has1 = stepping & (t + OG < p.n_targets);
-    bool inr0[N], inr1[N];
-    int rank0[N], rank1[N];
+    constexpr int TPL = OctLay<LG>::TPL;   // this lane's targets: t, t + LG, ...
+    bool has[TPL], inr[N][TPL];
+    unsigned below[TPL];
+    unsigned long long hasm[TPL];
+    int rank[N][TPL];
     int base = 0;
-    const unsigned below0 = (1u << t) - 1u, below1 = (1u << (t + OG)) - 1u;
     // (a ballot of a bare comparison is the comparison's own result register; the lanes that hold a target of a stepping env are
     // the same for every agent: their mask is taken once and applied on the scalar side)
-    const unsigned long long has0m = __ballot(has0), has1m = __ballot(has1);
+#pragma unroll
+    for (int k = 0; k < TPL; k++) {
+        has[k] = stepping & (t + LG * k < p.n_targets);
+        below[k] = (1u << (t + LG * k)) - 1u;
+        hasm[k] = __ballot(has[k]);
+    }
 #pragma unroll
     for (int i = 0; i < N; i++) {
         const double2 a = pos[o][i];
-        const double dx0 = e.tx[0] - a.x, dy0 = e.ty[0] - a.y, dx1 = e.tx[1] - a.x, dy1 = e.ty[1] - a.y;
-        const bool c0 = dx0 * dx0 + dy0 * dy0 <= p.view_r2;   // (t_x-x)**2 + (t_y-y)**2 <= view_range**2
-        const bool c1 = dx1 * dx1 + dy1 * dy1 <= p.view_r2;
-        inr0[i] = has0 & c0;
-        inr1[i] = has1 & c1;
-        const unsigned gm = oct_slice(__ballot(c0) & has0m, sh8) | (oct_slice(__ballot(c1) & has1m, sh8) << OG);
-        rank0[i] = base + __popc(gm & below0);   // agent-major order of the reference's double loop
-        rank1[i] = base + __popc(gm & below1);
+        unsigned gm = 0u;
+#pragma unroll
+        for (int k = 0; k < TPL; k++) {
+            const double dx = e.tx[k] - a.x, dy = e.ty[k] - a.y;
+            const bool c = dx * dx + dy * dy <= p.view_r2;   // (t_x-x)**2 + (t_y-y)**2 <= view_range**2
+            inr[i][k] = has[k] & c;
+            gm |= oct_slice<LG>(__ballot(c) & hasm[k], sh8) << (LG * k);
+        }
+#pragma unroll
+        for (int k = 0; k < TPL; k++) rank[i][k] = base + __popc(gm & below[k]);   // agent-major order of the reference's double loop
         base += __popc(gm);
     }
     // draw slot r = bit r of the tape: one 64-bit shift (teams of up to 4 never reach slot 64; up to 8: slot 127)
-    const unsigned long long t64a = (unsigned long long)tape[0] | ((unsigned long long)tape[1] << 32);
-    const unsigned long long t64b = (unsigned long long)tape[2] | ((unsigned long long)tape[3] << 32);
+    unsigned w4[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) w4[k] = LAZY ? __builtin_amdgcn_alignbit(tape[k + 1], tape[k], (unsigned)tcur) : tape[k];
+    const unsigned long long t64a = (unsigned long long)w4[0] | ((unsigned long long)w4[1] << 32);
+    const unsigned long long t64b = (unsigned long long)w4[2] | ((unsigned long long)w4[3] << 32);
     auto slot = [&](int r) __attribute__((always_inline)) {
         if (N * CS_MAX_TARGETS <= 64) return (bool)((t64a >> r) & 1ull);
         return (bool)(((r >= 64 ? t64b : t64a) >> (r & 63)) & 1ull);
     };
-    bool hit0 = false, hit1 = false;
+    bool hit[TPL];
+#pragma unroll
+    for (int k = 0; k < TPL; k++) hit[k] = false;
     // teams of 5 and more can draw past slot 63 -- an env with more than 64 (agent, target) pairs in range in ONE step, which no
     // run has ever shown -- so the common case reads every slot from the first 64-bit window (no per-slot window select) and a
     // wave-uniform test sends the other one through the general form
     if (N * CS_MAX_TARGETS <= 64 || __builtin_expect(__ballot(base > 64) == 0ull, 1)) {
 #pragma unroll
-        for (int i = 0; i < N; i++) {
-            hit0 = hit0 | (inr0[i] & (bool)((t64a >> rank0[i]) & 1ull));
-            hit1 = hit1 | (inr1[i] & (bool)((t64a >> rank1[i]) & 1ull));
-        }
+        for (int i = 0; i < N; i++)
+#pragma unroll
+            for (int k = 0; k < TPL; k++) hit[k] = hit[k] | (inr[i][k] & (bool)((t64a >> rank[i][k]) & 1ull));
     } else {
 #pragma unroll
-        for (int i = 0; i < N; i++) {
-            hit0 = hit0 | (inr0[i] & slot(rank0[i]));
-            hit1 = hit1 | (inr1[i] & slot(rank1[i]));
-        }
+        for (int i = 0; i < N; i++)
+#pragma unroll
+            for (int k = 0; k < TPL; k++) hit[k] = hit[k] | (inr[i][k] & slot(rank[i][k]));
     }
     e.mt_pos = wrap624(e.mt_pos + 2 * base);
     e.words += (unsigned long long)(2 * base);
     e.ahead -= 2 * base;
-    tape_shift<MAXDW>(tape, base);
+    if constexpr (LAZY) {
+        tcur += base;   // < 32 + N * CS_MAX_TARGETS: at most MAXDW + 1 whole dwords
+#pragma unroll
+        for (int r = 0; r <= MAXDW; r++) {
+            const bool out = tcur >= 32;
+            if (__ballot(out) == 0ull) break;   // wave-uniform
+#pragma unroll
+            for (int k = 0; k < TAPE_DW; k++) tape[k] = out ? (k + 1 < TAPE_DW ? tape[k + 1] : 0u) : tape[k];
+            tcur -= out ? 32 : 0;
+        }
+    } else {
+        tape_shift<MAXDW>(tape, base);
+    }
     // flight_env_easy.py:238-247
-    const bool new0 = hit0 & !((e.found >> t) & 1u), new1 = hit1 & !((e.found >> (t + OG)) & 1u);
-    const unsigned newly = oct_slice(__ballot(new0), sh8) | (oct_slice(__ballot(new1), sh8) << OG);
+    unsigned newly = 0u;
+#pragma unroll
+    for (int k = 0; k < TPL; k++) {
+        const bool nw = hit[k] & !((e.found >> (t + LG * k)) & 1u);
+        newly |= oct_slice<LG>(__ballot(nw), sh8) << (LG * k);
+    }
     int r = 0;
     if (stepping) {
         const int cnt = __popc(newly);
@@ -3305,19 +3386,25 @@ __device__ __forceinline__ int oct_detect(const DevParams &p, const double2 (*po
     }
     return r;
 }
+template <int N, int LG = OG, int AP = OCT_PAD>
+__device__ __forceinline__ int oct_detect(const DevParams &p, const double2 (*pos)[AP], int o, int t, int sh8, bool stepping,
+                                          EnvO<N, LG> &e, unsigned (&tape)[TAPE_DW]) {
+    int zero = 0;
+    return oct_detect_impl<N, LG, AP, false>(p, pos, o, t, sh8, stepping, e, tape, zero);
+}
 
 // The wavefront tops up the MT19937 rows of those of its 8 envs that have fewer than `min_ahead` twisted words left or no
 // matching tape -- whole wavefront on one row at a time, like group_wave_advance -- and hands the new tape to the env's
 // octet by ballot.
 // DRAIN: end with nothing of its own in flight (callers whose steady-state loop waits for loads, see drain_vmem).
-template <int N, bool DRAIN = true>
+template <int N, bool DRAIN = true, int LG = OG>
 __device__ __forceinline__ void oct_wave_advance(const DevParams &p, int wave_b0, int nvalid, int lane, int min_ahead,
-                                                 unsigned *rowbuf, EnvO<N> &e, unsigned (&tape)[TAPE_DW], bool &tape_ok) {
-    const int o = lane >> 3;
+                                                 unsigned *rowbuf, EnvO<N, LG> &e, unsigned (&tape)[TAPE_DW], bool &tape_ok) {
+    const int o = OctLay<LG>::valid(lane) ? OctLay<LG>::env(lane) : -1;
 #pragma unroll 1
-    for (int g = 0; g < OCT_ENVS; g++) {
-        const int pos = __shfl(e.mt_pos, OG * g), a = __shfl(e.ahead, OG * g);
-        const int ok = __shfl(tape_ok ? 1 : 0, OG * g);
+    for (int g = 0; g < OctLay<LG>::ENVS; g++) {
+        const int pos = __shfl(e.mt_pos, OctLay<LG>::first_of(g)), a = __shfl(e.ahead, OctLay<LG>::first_of(g));
+        const int ok = __shfl(tape_ok ? 1 : 0, OctLay<LG>::first_of(g));
         if (g >= nvalid || (ok && a >= min_ahead)) continue;   // wave-uniform
         unsigned *m = p.mt + (size_t)(wave_b0 + g) * MT_STRIDE;
         RowRegs rr;
@@ -3350,11 +3437,11 @@ __device__ __forceinline__ void oct_wave_advance(const DevParams &p, int wave_b0
 // step ago straight into `rowbuf` (global_load_lds) and has arrived (the caller waited for it); it is twisted ahead of the
 // env's cursor in LDS, the new words go back to the state blob, and the env's octet receives its new hit tape.  Same work
 // as oct_wave_advance for one env, minus the wait for the row.
-template <int N>
+template <int N, int LG = OG>
 __device__ __forceinline__ void oct_advance_finish(const DevParams &p, int wave_b0, int g, int lane, unsigned *rowbuf,
-                                                   EnvO<N> &e, unsigned (&tape)[TAPE_DW], bool &tape_ok) {
-    const int o = lane >> 3;
-    const int pos = __shfl(e.mt_pos, OG * g), a = __shfl(e.ahead, OG * g);
+                                                   EnvO<N, LG> &e, unsigned (&tape)[TAPE_DW], bool &tape_ok) {
+    const int o = OctLay<LG>::valid(lane) ? OctLay<LG>::env(lane) : -1;
+    const int pos = __shfl(e.mt_pos, OctLay<LG>::first_of(g)), a = __shfl(e.ahead, OctLay<LG>::first_of(g));
     row_twist_ahead(rowbuf, p.mt + (size_t)(wave_b0 + g) * MT_STRIDE, pos, a < 0 ? 0 : a, lane);
 #pragma unroll
     for (int it = 0; it < TAPE_DW / 2; it++) {
@@ -3390,13 +3477,14 @@ __device__ __forceinline__ void oct_advance_finish(const DevParams &p, int wave_
 // group and round (lane = polar attempt; `slots`: four rows of 16 positions, the hand-over from group to octet, free between
 // rounds); pre(w) may hand a group the four stream words of its FIRST batch (fetched ahead of time); before_tile() runs
 // before the first write to `tile`.
-template <int N, bool DRAIN, class BeforeTile, class Pre>
+template <int N, bool DRAIN, int LG = OG, class BeforeTile, class Pre>
 __device__ __forceinline__ void oct_place_targets(const DevParams &cp, int wave_b0, int nvalid, int lane, bool live,
                                                   unsigned long long need, const double *rtab, double2 (*slots)[G], float *tile,
-                                                  int W, unsigned *rowbuf, EnvO<N> &e, unsigned (&tape)[TAPE_DW], bool &tape_ok,
+                                                  int W, unsigned *rowbuf, EnvO<N, LG> &e, unsigned (&tape)[TAPE_DW], bool &tape_ok,
                                                   BeforeTile before_tile, Pre pre) {
+    using Lay = OctLay<LG>;
     const CS_AS4 DevParams *q = cold_params4();
-    const int t16 = lane & (G - 1), gshift16 = lane & ~(G - 1), grp = lane >> 4, sh8 = lane & ~(OG - 1), t = lane & (OG - 1);
+    const int t16 = lane & (G - 1), gshift16 = lane & ~(G - 1), grp = lane >> 4, sh8 = Lay::first(lane), t = Lay::t(lane);
     const int n_targets = q->n_targets, target_mode = q->target_mode;
     const unsigned deter_mask = q->deter_mask;
     const double mid = q->mid, inv_half = q->inv_half, L = q->L;
@@ -3411,26 +3499,31 @@ __device__ __forceinline__ void oct_place_targets(const DevParams &cp, int wave_
     int taken_env = 0;   // octet-uniform: accepted attempts of this env so far
     bool first = true;
     while (pend) {   // wave-uniform
-        const bool pending = (pend >> sh8) & 1ull;
+        const bool pending = Lay::valid(lane) && ((pend >> sh8) & 1ull);
         if (__ballot(live && pending && e.ahead < 4 * G))
-            oct_wave_advance<N, DRAIN>(cp, wave_b0, nvalid, lane, 4 * G, rowbuf, e, tape, tape_ok);
+            oct_wave_advance<N, DRAIN, LG>(cp, wave_b0, nvalid, lane, 4 * G, rowbuf, e, tape, tape_ok);
         unsigned long long m = pend;
         for (int k = 0; k < grp; k++) m &= m ? m - 1 : 0ull;   // this group's env: the grp-th pending one
         const int src = m ? __ffsll((long long)m) - 1 : -1;
         const int sl = src >= 0 ? src : lane;
         const int g_pos = __shfl(e.mt_pos, sl), g_taken = __shfl(taken_env, sl);
-        // an env back for another batch (~1 %) brings its partial placement along: target j sits in lane j % 8 of its octet
+        // an env back for another batch (~1 %) brings its partial placement along: target j sits in lane j % LG of its env, slot j / LG
         double px = 0.0, py = 0.0;
         if (__ballot(src >= 0 && g_taken > 0)) {   // wave-uniform
-            const int from = src >= 0 ? OG * (src >> 3) + (t16 & (OG - 1)) : lane;
-            const double x0 = __shfl(e.tx[0], from), x1 = __shfl(e.tx[1], from), y0 = __shfl(e.ty[0], from), y1 = __shfl(e.ty[1], from);
-            px = t16 < OG ? x0 : x1;
-            py = t16 < OG ? y0 : y1;
+            const int from = src >= 0 ? src + (t16 % LG) : lane;
+#pragma unroll
+            for (int k = 0; k < Lay::TPL; k++) {
+                const double xk = __shfl(e.tx[k], from), yk = __shfl(e.ty[k], from);
+                if (t16 / LG == k) {
+                    px = xk;
+                    py = yk;
+                }
+            }
         }
         int words = 0, taken_new = 0;
         bool fin = false;
         if (src >= 0) {
-            const int br = wave_b0 + (src >> 3);
+            const int br = wave_b0 + Lay::env_of_first(src);
             double mx = rtab[t16], my = rtab[G + t16];   // a*cx, a*cy of target t16 (flight_env_easy.py:95-113)
             fin = true;
             if (target_mode != 0 || need_total > 0) {
@@ -3485,7 +3578,7 @@ __device__ __forceinline__ void oct_place_targets(const DevParams &cp, int wave_
                 reinterpret_cast<CS_AS1 v2d *>(tgt + (size_t)br * G * 2)[t16] = v2d{mx, my};
                 before_tile();   // (the octet pair's emitting wavefront may still be reading the old rows)
                 if (t16 < n_targets) {
-                    float *rs = tile + (src >> 3) * W + 4 * N + 3 * t16;
+                    float *rs = tile + Lay::env_of_first(src) * W + 4 * N + 3 * t16;
                     rs[0] = (float)((mx - mid) * inv_half);   // norm_target
                     rs[1] = (float)((my - mid) * inv_half);
                     rs[2] = 0.0f;
@@ -3501,11 +3594,12 @@ __device__ __forceinline__ void oct_place_targets(const DevParams &cp, int wave_
         const int leader = got ? G * rank : lane;
         const int r_words = __shfl(words, leader), r_taken = __shfl(taken_new, leader), r_fin = __shfl(fin ? 1 : 0, leader);
         if (got) {
-            const double2 ta = slots[rank][t], tb = slots[rank][t + OG];
-            e.tx[0] = ta.x;
-            e.ty[0] = ta.y;
-            e.tx[1] = tb.x;
-            e.ty[1] = tb.y;
+#pragma unroll
+            for (int k = 0; k < Lay::TPL; k++) {
+                const double2 tk = slots[rank][(t + LG * k) & (G - 1)];   // (t + LG k < 16 for every lane that is `pending`)
+                e.tx[k] = tk.x;
+                e.ty[k] = tk.y;
+            }
             tape_shift<1>(tape, r_words >> 1);   // (<= 32 draw slots leave the tape)
             e.mt_pos = wrap624(e.mt_pos + r_words);
             e.words += (unsigned long long)r_words;
@@ -3584,6 +3678,7 @@ __global__ __launch_bounds__(OCT_BLOCK, CS_OCT_WAVES) void k_rollout_oct(DevPara
     }
     unsigned tape[TAPE_DW];
     bool tape_ok = tape_finish(p, traw, e, tape) || !live;
+    int tcur = 0;   // the step's detection pass leaves the tape unshifted (oct_detect_impl, LAZY): canonical again wherever else it is used
     trig_heading(T, e.yaw, e.sn, e.cs);   // what a frozen env keeps emitting
     // ---- persistent rows: agents' floats, targets' normalised coordinates and found flags (get_state, :190-216)
     float *row = sh.tile + o * W;
@@ -3652,6 +3747,7 @@ __global__ __launch_bounds__(OCT_BLOCK, CS_OCT_WAVES) void k_rollout_oct(DevPara
             const DevParams &cp = cold_params();
             const bool mine = (need >> sh8) & 1ull;
             const StartTab<N> st = start_tab<N>();
+            tape_canon(tape, tcur);
             oct_place_targets<N, true>(cp, wave_b0, nvalid, lane, live, need, rtab, sh.tgt, sh.tile, W, sh.rowbuf, e, tape, tape_ok,
                                        []() {}, [](unsigned (&)[4]) { return false; });
             if (mine) {
@@ -3708,7 +3804,7 @@ __global__ __launch_bounds__(OCT_BLOCK, CS_OCT_WAVES) void k_rollout_oct(DevPara
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // ---- detection, reward, termination
         OCT_STAMP(3);
-        const int reward = oct_detect<N>(p, sh.pos, o, t, sh8, stepping, e, tape);
+        const int reward = oct_detect_impl<N, OG, OCT_PAD, true>(p, sh.pos, o, t, sh8, stepping, e, tape, tcur);
         OCT_STAMP(4);
         bool term = true;
         if (stepping) {
@@ -3724,8 +3820,10 @@ __global__ __launch_bounds__(OCT_BLOCK, CS_OCT_WAVES) void k_rollout_oct(DevPara
         }
         OCT_STAMP(5);
         // ---- a row that is about to run out of twisted words is topped up in place (about one wave-step in 10)
-        if (__builtin_expect(__ballot(live && e.ahead < LOW) != 0ull, 0))
+        if (__builtin_expect(__ballot(live && e.ahead < LOW) != 0ull, 0)) {
+            tape_canon(tape, tcur);
             oct_wave_advance<N>(cold_params(), wave_b0, nvalid, lane, LOW, sh.rowbuf, e, tape, tape_ok);
+        }
         act = act_next;
         act_next = act_after;
         OCT_STAMP(6);
@@ -3773,6 +3871,7 @@ __global__ __launch_bounds__(OCT_BLOCK, CS_OCT_WAVES) void k_rollout_oct(DevPara
         }
         OCT_STAMP(7);
     }
+    tape_canon(tape, tcur);
     if (live) {
         const DevParams &cp = cold_params();
         if (t == 0) {
@@ -3838,6 +3937,19 @@ __global__ __launch_bounds__(OCT_BLOCK, CS_OCT_WAVES) void k_rollout_oct(DevPara
 #define CS_LEGACY_KERNELS 0
 #endif
 constexpr int OD_BLOCK = 128;
+// Teams of 5: the 5-lanes-per-env packing of the pair kernels (OctLay<5>: twelve envs per workgroup).  1: cs_rollout's pair kernels take
+// it for teams of exactly 5; 0 (default): the octet layout only, and k_rollout_od5 is not even instantiated.
+// Round 5's experiment for the 5-agent configurations, bit-identical to the step kernel (tests/test_gpu_jitter.py keeps a build of it
+// in the suite) and SLOWER where it was meant to pay (one box, us per step, packing / octet): pair kernel at 8192 envs 2.50 (8184 envs:
+// no tail) / 2.26, at 16384 envs 3.58 / 3.40; three-wavefront variant at 8192 envs 2.28 / 1.90; first ahead at 32768 envs (7.42 / 8.27),
+// which the lane kernels serve.  Why: (1) it executes 14.5 % fewer VALU instructions, not the third the idle lanes suggested -- what a
+// lane does per TARGET (three per lane instead of two) is most of the step and does not shrink, only the per-agent kinematics do
+// (SQ_INSTS_VALU at 32760 envs: 2.74e8 against 3.20e8 per 100 steps); (2) 8192 envs are 682.7 workgroups of twelve on 256 CUs: two CUs
+// in three run three workgroups, the rest two, and the step takes what the fuller ones take -- as many wavefronts per SIMD as the
+// octet's four workgroups per CU, each wavefront a quarter longer.  DESIGN.md section 9.
+#ifndef CS_OD_PENT
+#define CS_OD_PENT 0
+#endif
 // Teams from this size on divide the two components of a repulsion term with ONE reciprocal in K (div2_same_denominator: the same
 // quotients bit for bit).  Small teams keep the plain divisions: K is alone on its SIMD there and the range check in front of the
 // shared sequence lengthens its chain (c2: -1.9 %, round 4); large teams run four wavefronts per SIMD at the VALU issue limit,
@@ -3852,21 +3964,22 @@ constexpr int od_ring(bool e3) { return e3 ? CS_OD_RING_E3 : CS_OD_RING; }
 static_assert((od_ring(false) & (od_ring(false) - 1)) == 0 && od_ring(false) >= 2, "ring depth");
 static_assert((od_ring(true) & (od_ring(true) - 1)) == 0 && od_ring(true) >= 2, "ring depth");
 
-struct __attribute__((aligned(16))) OdRing {   // what K hands to D for one step
-    double2 pos[OCT_ENVS][OCT_PAD];
-    double yaw[OCT_ENVS][CS_MAX_AGENTS];
-    float2 cssn[OCT_ENVS][CS_MAX_AGENTS];
-    unsigned out[OCT_ENVS];
-    unsigned pad[OCT_ENVS];
+template <int ENVS, int AP>
+struct __attribute__((aligned(16))) OdRingT {   // what K hands to D for one step (ENVS envs per workgroup: 8, or 12 in the 5-lane packing)
+    double2 pos[ENVS][AP];                      // AP columns per env: the agents + one of padding (bank spread)
+    double yaw[ENVS][AP - 1];
+    float2 cssn[ENVS][AP - 1];
+    unsigned out[ENVS];
+    unsigned pad[ENVS];
 };
-template <int RING>
+template <int RING, int ENVS = OCT_ENVS, int AP = OCT_PAD, int TW = TILE_W>
 struct __attribute__((aligned(16))) OdSharedT {
-    OdRing ring[RING];
-    double2 kpos[OCT_ENVS][OCT_PAD];        // K: the team's current positions (the "old" ones of its next step)
-    double2 dpos[OCT_ENVS][OCT_PAD];        // D: start poses for the reset-time detection pass
-    float tile[OCT_ENVS * TILE_W];
-    float reward[OCT_ENVS];
-    int term[OCT_ENVS], win[OCT_ENVS];
+    OdRingT<ENVS, AP> ring[RING];
+    double2 kpos[ENVS][AP];        // K: the team's current positions (the "old" ones of its next step)
+    double2 dpos[ENVS][AP];        // D: start poses for the reset-time detection pass
+    float tile[ENVS * TW];
+    float reward[ENVS];
+    int term[ENVS], win[ENVS];
     // pair synchronisation (LDS words, written by one side, polled by the other; the LDS serves a workgroup's accesses in
     // order, so data written before a counter is visible to whoever has seen the counter)
     int k_steps;                             // K: steps produced so far (slot s is valid once k_steps > s)
@@ -3957,10 +4070,11 @@ __device__ __forceinline__ void lds_peek2_wait(int2 &v) {
 // ~3500 cycles per step, D ~2650 + ~1450 of events); without the emission it has the slack to absorb its events.  D hands each
 // step's reward / terminated / win / found mask to E through a ring of OdOut records; E reads the agents' floats from K's
 // ring slot.  Three wavefronts of 128 VGPRs and 32 KB of LDS: four workgroups per CU, so this variant serves batches up to 8192 envs.
-struct __attribute__((aligned(16))) OdOut {
-    float reward[OCT_ENVS];
-    int term[OCT_ENVS], win[OCT_ENVS];
-    unsigned found[OCT_ENVS];
+template <int ENVS>
+struct __attribute__((aligned(16))) OdOutT {
+    float reward[ENVS];
+    int term[ENVS], win[ENVS];
+    unsigned found[ENVS];
 };
 // -DCS_JITTER (test builds only, tests/test_gpu_jitter.py): a pseudo-random pause of 0..1800 cycles -- up to two thirds of a step --
 // in each role at every hand-shake of the pair's protocol (before a counter is read, before it is posted, around a fix request and
@@ -3976,12 +4090,32 @@ struct __attribute__((aligned(16))) OdOut {
 #else
 #define OD_JITTER(salt) do {} while (0)
 #endif
+// (the 5-lane packing is compiled for THREE wavefronts per SIMD -- 168 VGPRs: a third target per lane is 15 more ranks and masks, and
+// its workgroups of 12 envs are fewer: 16384 envs are six two-wavefront workgroups per CU, 8192 three three-wavefront ones.  The
+// compiler derives a kernel's occupancy from its LDS use and would otherwise give these kernels the registers of two wavefronts.)
+template <int N, bool VEC, bool EMIT, bool E3, int LG>
+__device__ __forceinline__ void rollout_od_body(const DevParams &p, const StepIO &io);
 template <int N, bool VEC, bool EMIT, bool E3>
 __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_rollout_od(DevParams p, StepIO io) {
+    rollout_od_body<N, VEC, EMIT, E3, OG>(p, io);
+}
+template <int N, bool E3>
+__global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, 3) void k_rollout_od5(DevParams p, StepIO io) {
+    rollout_od_body<N, true, true, E3, 5>(p, io);
+}
+template <int N, bool VEC, bool EMIT, bool E3, int LG>
+__device__ __forceinline__ void rollout_od_body(const DevParams &p, const StepIO &io) {
     static_assert(!E3 || (VEC && EMIT), "the emitting wavefront has the full-wavefront, obs + state stores only");
+    static_assert(LG == OG || (LG == 5 && N == 5 && VEC && EMIT), "the 5-lane packing: teams of 5, full wavefronts, obs + state written");
+    using Lay = OctLay<LG>;
+    constexpr int ENVS = Lay::ENVS;   // envs per workgroup (= per wavefront of each role)
+    constexpr int AP = LG == OG ? OCT_PAD : N + 1;                                  // columns of the per-agent LDS rows
+    constexpr int TW = LG == OG ? TILE_W : 4 * N + 3 * (CS_MAX_TARGETS - 1);       // widest get_state row (the packing: <= 15 targets)
     __shared__ double T[TRIG_ROWS * TRIG_COLS];
     constexpr int OD_RING = od_ring(E3);
-    using OdShared = OdSharedT<OD_RING>;
+    using OdShared = OdSharedT<OD_RING, ENVS, AP, TW>;
+    using OdRing = OdRingT<ENVS, AP>;
+    using OdOut = OdOutT<ENVS>;
     __shared__ OdShared sh;
     __shared__ OdOut outs[E3 ? OD_RING : 1];
     constexpr bool EREF = E3 && (CS_OD_E_REFRESH != 0);
@@ -4000,19 +4134,20 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
     const int role = E3 ? (CS_ODE_ROLES >> (4 * wv)) & 15 : wv;   // 0: K, 1: D, 2: E
     const bool is_k = role == 0;
     SPIN_DECL;
-    const int o = lane >> 3, sh8 = lane & ~(OG - 1);
-    int t = lane & (OG - 1);   // (made opaque once per step: lane predicates are recomputed, not held in SGPR pairs)
-    const int wave_b0 = io.env0 + blockIdx.x * OCT_ENVS;
+    const int o = Lay::env(lane), sh8 = Lay::first(lane);
+    int t = Lay::t(lane);   // (made opaque once per step: lane predicates are recomputed, not held in SGPR pairs)
+    const int tc = t < AP ? t : AP - 1;   // column of the per-agent LDS rows (a lane that holds nothing: the padding column)
+    const int wave_b0 = io.env0 + blockIdx.x * ENVS;
     const int b_end = io.env0 + io.env_n;
     const int b = wave_b0 + o;
-    const bool live = VEC || b < b_end;
+    const bool live = (VEC || b < b_end) && Lay::valid(lane);
     if (role < 2) BLK_STAMP(is_k ? 0 : 4);
-    const int nvalid = b_end - wave_b0 < OCT_ENVS ? b_end - wave_b0 : OCT_ENVS;   // >= 1: the grid covers env_n exactly
+    const int nvalid = b_end - wave_b0 < ENVS ? b_end - wave_b0 : ENVS;   // >= 1: the grid covers env_n exactly
     const int W = 4 * N + 3 * p.n_targets;
     bool ag = t < N;
     const bool auto_reset = io.flags & CS_AUTO_RESET, freeze = io.flags & CS_FREEZE_DONE;
     const size_t bl = live ? (size_t)b : (size_t)io.env0;
-    EnvO<N> e;
+    EnvO<N, LG> e;
     {
         const int4 *h4 = reinterpret_cast<const int4 *>(p.hdr + bl * CS_H_WORDS);
         const int4 h0 = h4[0], h1 = h4[1], h2 = h4[2];
@@ -4042,7 +4177,7 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
 #endif
         if (E3) __builtin_amdgcn_s_setprio(CS_ODE_KPRIO);
         {
-            const double4 a = reinterpret_cast<const double4 *>(p.agent + bl * CS_MAX_AGENTS * 4)[t];
+            const double4 a = reinterpret_cast<const double4 *>(p.agent + bl * CS_MAX_AGENTS * 4)[t < CS_MAX_AGENTS ? t : 0];
             e.x = a.x;
             e.y = a.y;
             e.yaw = a.z;
@@ -4057,7 +4192,7 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
         if (io.T > 2) ap += astep;
         load_trig_to_lds(T);
         trig_heading(T, e.yaw, e.sn, e.cs);   // what a frozen env keeps emitting
-        sh.kpos[o][t] = make_double2(e.x, e.y);
+        sh.kpos[o][tc] = make_double2(e.x, e.y);
         bool k_done = live && (e.target_find >= p.n_targets || e.time_step >= p.time_limit);   // exact at launch
         int k_time = e.time_step;
         unsigned k_out = ((unsigned)e.flags >> 8) & 0xffu;
@@ -4075,7 +4210,7 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
                     const StartTab<N> st = start_tab<N>();
                     start_pick<N>(st, ag ? t : 0, e.x, e.y);
                     e.yaw = st.yaw;
-                    sh.kpos[o][t] = make_double2(e.x, e.y);
+                    sh.kpos[o][tc] = make_double2(e.x, e.y);
                     k_out = 0u;
                     k_time = 0;
                     k_done = false;
@@ -4088,7 +4223,7 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
 #ifdef CS_OD_ABL_NOKIN   /* experiment: what D alone sustains */
             const unsigned out = 0u;
 #else
-            const unsigned out = oct_kinematics<N, (N >= CS_OD_SHARED_DIV_FROM_N)>(p, T, sh.kpos, o, t, sh8, stepping, a, e, sp);
+            const unsigned out = oct_kinematics<N, (N >= CS_OD_SHARED_DIV_FROM_N), LG, AP>(p, T, sh.kpos, o, t, sh8, stepping, a, e, sp);
 #endif
             KIN_STAMP_SP(6);
             between();   // (the main loop issues its next flow-control read here)
@@ -4100,7 +4235,7 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();   // every lane has read the old positions
             OdRing &r = sh.ring[sp & (OD_RING - 1)];
-            if (sel) {
+            if (sel && Lay::valid(lane)) {
                 const double2 xy = make_double2(e.x, e.y);
                 sh.kpos[o][t] = xy;
                 r.pos[o][t] = xy;
@@ -4130,7 +4265,7 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
                     e.y = xy.y;
                     e.yaw = r.yaw[o][t];
                     trig_heading(T, e.yaw, e.sn, e.cs);
-                    sh.kpos[o][t] = xy;
+                    sh.kpos[o][tc] = xy;
                     k_out = r.out[o];
                     k_done = true;
                 }
@@ -4208,32 +4343,33 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
     if (E3 && role == 2) {
         // ------------------------------------------------------------------------------------------ E: emission
         const double2 *t2 = reinterpret_cast<const double2 *>(p.tgt + bl * G * 2);
-        const double2 ta = t2[t], tb = t2[t + OG];
+        double2 tk[Lay::TPL];
+#pragma unroll
+        for (int k = 0; k < Lay::TPL; k++) tk[k] = t2[(t + LG * k) & (G - 1)];
         load_trig_to_lds(T);   // (K's table: E only joins the barrier; D zeroed the counters before it)
         float *row = sh.tile + o * W;
         // persistent rows: targets' normalised coordinates (rewritten by D when an env resets) and found flags (get_state, :190-216)
-        if (t < p.n_targets) {
-            row[4 * N + 3 * t + 0] = (float)((ta.x - p.mid) * p.inv_half);   // norm_target
-            row[4 * N + 3 * t + 1] = (float)((ta.y - p.mid) * p.inv_half);
-        }
-        if (t + OG < p.n_targets) {
-            row[4 * N + 3 * (t + OG) + 0] = (float)((tb.x - p.mid) * p.inv_half);
-            row[4 * N + 3 * (t + OG) + 1] = (float)((tb.y - p.mid) * p.inv_half);
+#pragma unroll
+        for (int k = 0; k < Lay::TPL; k++) {
+            if (t + LG * k < p.n_targets) {
+                row[4 * N + 3 * (t + LG * k) + 0] = (float)((tk[k].x - p.mid) * p.inv_half);   // norm_target
+                row[4 * N + 3 * (t + LG * k) + 1] = (float)((tk[k].y - p.mid) * p.inv_half);
+            }
         }
         auto peek = [](const int *w) __attribute__((always_inline)) { return lds_peek(w); };
         constexpr int W_MAX = 4 * N + 3 * CS_MAX_TARGETS;
-        constexpr int Q = (OCT_ENVS * W_MAX / 4 + 63) / 64;   // float4 chunks per lane of the largest tile
-        const int ol = lane < OCT_ENVS * N ? lane : OCT_ENVS * N - 1;
+        constexpr int Q = (ENVS * W_MAX / 4 + 63) / 64;   // float4 chunks per lane of the largest tile
+        const int ol = lane < ENVS * N ? lane : ENVS * N - 1;
         const int orow = ol / N, oag = ol - orow * N;
         const int obs_lds = orow * W + 4 * oag;
-        const int rtw = lane & 7;
+        const int rtw = lane < ENVS ? lane : ENVS - 1;   // (duplicates write the same value)
         float *p_rew = io.reward + wave_b0 + rtw;
         uint8_t *p_term = io.terminated + wave_b0 + rtw, *p_win = io.win + wave_b0 + rtw;
         v4f *p_obs = reinterpret_cast<v4f *>(io.obs + (size_t)wave_b0 * N * 4) + ol;
         v4f *p_st = reinterpret_cast<v4f *>(io.state + (size_t)wave_b0 * W);
         int chunk[Q];
 #pragma unroll
-        for (int q = 0; q < Q; q++) chunk[q] = lane + 64 * q < OCT_ENVS * W / 4 - 1 ? lane + 64 * q : OCT_ENVS * W / 4 - 1;
+        for (int q = 0; q < Q; q++) chunk[q] = lane + 64 * q < ENVS * W / 4 - 1 ? lane + 64 * q : ENVS * W / 4 - 1;
         int rf_served = 0;
         auto rf_serve = [&]() __attribute__((always_inline)) {   // EREF: a row refresh for D, if one is asked for
             const int seq = peek(&rf.rf_req);
@@ -4287,8 +4423,9 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
                 row[4 * t + 3] = cs.y;
             }
             const unsigned found = d.found[o];
-            if (t < p.n_targets) row[4 * N + 3 * t + 2] = ((found >> t) & 1u) ? 1.0f : 0.0f;
-            if (t + OG < p.n_targets) row[4 * N + 3 * (t + OG) + 2] = ((found >> (t + OG)) & 1u) ? 1.0f : 0.0f;
+#pragma unroll
+            for (int k = 0; k < Lay::TPL; k++)
+                if (t + LG * k < p.n_targets) row[4 * N + 3 * (t + LG * k) + 2] = ((found >> (t + LG * k)) & 1u) ? 1.0f : 0.0f;
             const float o_rew = d.reward[rtw];
             const int o_term = d.term[rtw], o_win = d.win[rtw];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -4343,11 +4480,12 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
     e.ahead = live ? p.ahead[bl] : (1 << 20);
     {
         const double2 *t2 = reinterpret_cast<const double2 *>(p.tgt + bl * G * 2);
-        const double2 ta = t2[t], tb = t2[t + OG];
-        e.tx[0] = ta.x;
-        e.ty[0] = ta.y;
-        e.tx[1] = tb.x;
-        e.ty[1] = tb.y;
+#pragma unroll
+        for (int k = 0; k < Lay::TPL; k++) {
+            const double2 tk = t2[(t + LG * k) & (G - 1)];
+            e.tx[k] = tk.x;
+            e.ty[k] = tk.y;
+        }
     }
     const TapeRaw traw = tape_fetch(p, (int)bl);
     if (lane == 0) {   // the pair's counters: zero before the barrier below lets K start
@@ -4365,19 +4503,24 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
     load_trig_to_lds(T);   // (K's table; D only joins its barrier -- after which K produces ahead, up to OD_RING steps)
     unsigned tape[TAPE_DW];
     bool tape_ok = tape_finish(p, traw, e, tape) || !live;
+#ifndef CS_OD_LAZY_TAPE
+#define CS_OD_LAZY_TAPE 1   /* the step's detection pass leaves the tape unshifted (oct_detect_impl, LAZY); 0: shifted every step */
+#endif
+    int tcur = 0;   // the cursor's bit within tape[0]; 0 = canonical, which everything but the step's own pass expects
+    auto canon = [&]() __attribute__((always_inline)) { if (CS_OD_LAZY_TAPE) tape_canon(tape, tcur); };
     float *row = sh.tile + o * W;
     auto put_found = [&]() __attribute__((always_inline)) {
-        if (t < p.n_targets) row[4 * N + 3 * t + 2] = ((e.found >> t) & 1u) ? 1.0f : 0.0f;
-        if (t + OG < p.n_targets) row[4 * N + 3 * (t + OG) + 2] = ((e.found >> (t + OG)) & 1u) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int k = 0; k < Lay::TPL; k++)
+            if (t + LG * k < p.n_targets) row[4 * N + 3 * (t + LG * k) + 2] = ((e.found >> (t + LG * k)) & 1u) ? 1.0f : 0.0f;
     };
     if (!E3) {   // (E3: the tile is E's)
-        if (t < p.n_targets) {
-            row[4 * N + 3 * t + 0] = (float)((e.tx[0] - p.mid) * p.inv_half);   // norm_target
-            row[4 * N + 3 * t + 1] = (float)((e.ty[0] - p.mid) * p.inv_half);
-        }
-        if (t + OG < p.n_targets) {
-            row[4 * N + 3 * (t + OG) + 0] = (float)((e.tx[1] - p.mid) * p.inv_half);
-            row[4 * N + 3 * (t + OG) + 1] = (float)((e.ty[1] - p.mid) * p.inv_half);
+#pragma unroll
+        for (int k = 0; k < Lay::TPL; k++) {
+            if (t + LG * k < p.n_targets) {
+                row[4 * N + 3 * (t + LG * k) + 0] = (float)((e.tx[k] - p.mid) * p.inv_half);   // norm_target
+                row[4 * N + 3 * (t + LG * k) + 1] = (float)((e.ty[k] - p.mid) * p.inv_half);
+            }
         }
         put_found();
     }
@@ -4419,7 +4562,7 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
     //  * -DCS_OD_SAFE_WAIT turns the counted wait into a full drain and -DCS_OD_ASYNC=0 removes the requests altogether: both builds
     //    must reproduce the shipped one bit for bit (tests/test_gpu_jitter.py builds and compares them).
     constexpr int W_MAX = 4 * N + 3 * CS_MAX_TARGETS;
-    constexpr int Q = (OCT_ENVS * W_MAX / 4 + 63) / 64;   // float4 chunks per lane of the largest tile = state stores per step
+    constexpr int Q = (ENVS * W_MAX / 4 + 63) / 64;   // float4 chunks per lane of the largest tile = state stores per step
     constexpr int STEP_STORES = 3 + 1 + Q;                // reward, terminated, win | obs | state
     static_assert(Q >= 1 && STEP_STORES == 4 + Q, "STEP_STORES counts the stores of the VEC && EMIT step: keep it next to them");
     auto wait_for_requests = [&]() __attribute__((always_inline)) {
@@ -4449,6 +4592,7 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
             return;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        canon();
         unsigned nt[TAPE_DW];
 #pragma unroll
         for (int k = 0; k < TAPE_DW; k++) nt[k] = rf.rf_tape[k];
@@ -4464,13 +4608,13 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
     };
     unsigned long long pre_need = 0ull;  // the reset mask sh.prebuf was filled for
     unsigned pre_valid = 0u;             // bit g: 16-lane group g's attempt batch is (on its way) in sh.prebuf
-    oct_wave_advance<N, CS_OD_DRAIN != 0>(p, wave_b0, nvalid, lane, io.min_ahead > LOW ? io.min_ahead : LOW, sh.rowbuf, e, tape, tape_ok);   // while K produces step 0
+    oct_wave_advance<N, CS_OD_DRAIN != 0, LG>(p, wave_b0, nvalid, lane, io.min_ahead > LOW ? io.min_ahead : LOW, sh.rowbuf, e, tape, tape_ok);   // while K produces step 0
     // ---- write-out plan (loop invariant)
     const int rows_valid = nvalid;
     const int ol = lane < rows_valid * N ? lane : rows_valid * N - 1;
     const int orow = ol / N, oag = ol - orow * N;
     const int obs_lds = orow * W + 4 * oag;
-    const int rtw = (lane & 7) < rows_valid ? (lane & 7) : rows_valid - 1;
+    const int rtw = lane < rows_valid ? lane : rows_valid - 1;   // (duplicates write the same value)
     const int t16 = lane & (G - 1), gshift16 = lane & ~(G - 1), grp = lane >> 4;
     float *p_rew = io.reward + wave_b0 + rtw;
     uint8_t *p_term = io.terminated + wave_b0 + rtw, *p_win = io.win + wave_b0 + rtw;
@@ -4478,7 +4622,7 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
     v4f *p_st = reinterpret_cast<v4f *>(io.state + (size_t)wave_b0 * W);
     int chunk[Q];
 #pragma unroll
-    for (int q = 0; q < Q; q++) chunk[q] = lane + 64 * q < OCT_ENVS * W / 4 - 1 ? lane + 64 * q : OCT_ENVS * W / 4 - 1;
+    for (int q = 0; q < Q; q++) chunk[q] = lane + 64 * q < ENVS * W / 4 - 1 ? lane + 64 * q : ENVS * W / 4 - 1;
     BLK_STAMP(5);
     for (int s = 0; s < io.T; s++) {
         asm volatile("" : "+v"(t));
@@ -4486,14 +4630,16 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
         DUO_STAMP(8);
         if (__builtin_expect(cand >= 0, 0)) {   // wave-uniform: the row requested a step ago is in sh.rowbuf
             wait_for_requests();
-            oct_advance_finish<N>(OD_COLD(), wave_b0, cand, lane, sh.rowbuf, e, tape, tape_ok);
+            canon();
+            oct_advance_finish<N, LG>(OD_COLD(), wave_b0, cand, lane, sh.rowbuf, e, tape, tape_ok);
             cand = -1;
         }
         if (EREF) rf_poll(false);
         if (__builtin_expect(__ballot(live && e.ahead < LOW) != 0ull, 0)) {   // could not wait for its turn
             if (EREF) rf_poll(true);   // (E may be at this very row; and its answer may be all that was needed)
+            canon();
             if (!EREF || __ballot(live && e.ahead < LOW) != 0ull)
-                oct_wave_advance<N, CS_OD_DRAIN != 0>(OD_COLD(), wave_b0, nvalid, lane, LOW, sh.rowbuf, e, tape, tape_ok);
+                oct_wave_advance<N, CS_OD_DRAIN != 0, LG>(OD_COLD(), wave_b0, nvalid, lane, LOW, sh.rowbuf, e, tape, tape_ok);
         }
         bool done = e.target_find >= p.n_targets || e.time_step >= p.time_limit;
         e.flags &= ~(FLAG_DIRTY | FLAG_RESET_PASS);
@@ -4503,12 +4649,13 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
         if (__builtin_expect(need != 0ull, 0)) {
             DUO_STAMP(13);
             if (EREF) rf_poll(true);   // a reset tops rows up on the spot and reads stream words: not beside E's refresh
+            canon();
             const DevParams &cp = OD_COLD();
-            const bool mine = (need >> sh8) & 1ull;
+            const bool mine = Lay::valid(lane) && ((need >> sh8) & 1ull);
             const StartTab<N> st = start_tab<N>();
             // round 0's attempt batches were requested when the envs' steps terminated (same mask -> same groups)
             // (E3: the tile still holds the rows of step s - 1 until E has written them out: the new targets wait for that)
-            oct_place_targets<N, CS_OD_DRAIN != 0>(cp, wave_b0, nvalid, lane, live, need, sh.rtab, sh.tgt, sh.tile, W, sh.rowbuf, e, tape, tape_ok,
+            oct_place_targets<N, CS_OD_DRAIN != 0, LG>(cp, wave_b0, nvalid, lane, live, need, sh.rtab, sh.tgt, sh.tile, W, sh.rowbuf, e, tape, tape_ok,
                                                    [&]() __attribute__((always_inline)) {
                                                        if (E3) {
                                                            while (lds_peek(&e_steps) < s) __builtin_amdgcn_s_sleep(1);
@@ -4534,10 +4681,10 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
                 e.flags = 0;
                 double sx, sy;
                 start_pick<N>(st, ag ? t : 0, sx, sy);
-                sh.dpos[o][t] = make_double2(sx, sy);
+                sh.dpos[o][tc] = make_double2(sx, sy);
             }
             DUO_STAMP(14);
-            if (__ballot(live && e.ahead < LOW)) oct_wave_advance<N, CS_OD_DRAIN != 0>(cp, wave_b0, nvalid, lane, LOW, sh.rowbuf, e, tape, tape_ok);
+            if (__ballot(live && e.ahead < LOW)) oct_wave_advance<N, CS_OD_DRAIN != 0, LG>(cp, wave_b0, nvalid, lane, LOW, sh.rowbuf, e, tape, tape_ok);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -4548,12 +4695,14 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
 #pragma unroll
             for (int i = 0; i < N; i++) {
                 const double sx = st.x[i], sy = st.y[i];
-                const double ax0 = e.tx[0] - sx, ay0 = e.ty[0] - sy, ax1 = e.tx[1] - sx, ay1 = e.ty[1] - sy;
-                near = near | ((t < cp.n_targets) & (ax0 * ax0 + ay0 * ay0 <= cp.view_r2)) |
-                       ((t + OG < cp.n_targets) & (ax1 * ax1 + ay1 * ay1 <= cp.view_r2));
+#pragma unroll
+                for (int k = 0; k < Lay::TPL; k++) {
+                    const double axk = e.tx[k] - sx, ayk = e.ty[k] - sy;
+                    near = near | ((t + LG * k < cp.n_targets) & (axk * axk + ayk * ayk <= cp.view_r2));
+                }
             }
             if (__ballot(mine && near)) {
-                oct_detect<N>(p, sh.dpos, o, t, sh8, mine, e, tape);
+                oct_detect<N, LG, AP>(p, sh.dpos, o, t, sh8, mine, e, tape);
                 if (!E3) put_found();
             } else if (mine) {   // what the pass does when no pair is in range: no draw, reward -1
                 e.newly = 0u;
@@ -4561,7 +4710,7 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
                 e.flags |= FLAG_DIRTY;
             }
             done = done && !mine;
-            if (__ballot(live && e.ahead < LOW)) oct_wave_advance<N, CS_OD_DRAIN != 0>(cp, wave_b0, nvalid, lane, LOW, sh.rowbuf, e, tape, tape_ok);
+            if (__ballot(live && e.ahead < LOW)) oct_wave_advance<N, CS_OD_DRAIN != 0, LG>(cp, wave_b0, nvalid, lane, LOW, sh.rowbuf, e, tape, tape_ok);
         }
         const bool stepping = live && !(done && freeze);
         DUO_STAMP(9);
@@ -4589,7 +4738,7 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
             row[4 * t + 2] = cs.x;
             row[4 * t + 3] = cs.y;
         }
-        const int reward = oct_detect<N>(p, r.pos, o, t, sh8, stepping, e, tape);
+        const int reward = oct_detect_impl<N, LG, AP, CS_OD_LAZY_TAPE != 0>(p, r.pos, o, t, sh8, stepping, e, tape, tcur);
         DUO_STAMP(10);
         bool term = true, mispredicted = false;
         if (stepping) {
@@ -4602,7 +4751,7 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
         if (__builtin_expect(mb != 0ull, 0)) {   // K has stepped these envs on as if nothing had happened: have it redo them
             unsigned m8 = 0;
 #pragma unroll
-            for (int q = 0; q < OCT_ENVS; q++) m8 |= (unsigned)((mb >> (OG * q)) & 1ull) << q;
+            for (int q = 0; q < ENVS; q++) m8 |= (unsigned)((mb >> Lay::first_of(q)) & 1ull) << q;
             if (lane == 0) sh.fix_mask = m8;
             OD_JITTER(8);
             post(&sh.fix_req, s + 1);
@@ -4651,7 +4800,7 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
         if (CS_OD_ASYNC && s + 1 < io.T) {   // requests for the next step, before this step's stores
             // (a) the row of the env running lowest on twisted words, if any is below REQ: ten dword columns -> sh.rowbuf
             const unsigned long long lowb = (EREF && rf_pending >= 0) ? 0ull : __ballot(live && e.ahead < REQ && t == 0);
-            cand = lowb ? __builtin_amdgcn_readfirstlane((__ffsll((long long)lowb) - 1) >> 3) : -1;
+            cand = lowb ? __builtin_amdgcn_readfirstlane(Lay::env_of_first(__ffsll((long long)lowb) - 1)) : -1;
             if (EREF && cand >= 0) {   // E's job: post the request, go on with the old tape
                 if (o == cand && t == 0) {
                     rf.rf_env = cand;
@@ -4684,7 +4833,7 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
                 const int ppos = __shfl(e.mt_pos, sl), pah = __shfl(e.ahead, sl);
                 const bool okg = src >= 0 && pah >= 4 * G;   // its words are twisted already: their stored values are final
                 if (okg) {
-                    const unsigned *m = OD_COLD().mt + (size_t)(wave_b0 + (src >> 3)) * MT_STRIDE;
+                    const unsigned *m = OD_COLD().mt + (size_t)(wave_b0 + Lay::env_of_first(src)) * MT_STRIDE;
                     const int i0 = wrap624(ppos + 4 * t16);
 #pragma unroll
                     for (int q = 0; q < 4; q++)
@@ -4736,6 +4885,7 @@ __global__ __launch_bounds__(E3 ? OD_BLOCK + 64 : OD_BLOCK, CS_OD_WAVES) void k_
         rf_poll(true);
         post(&rf.d_done, 1);
     }
+    canon();
     if (live) {   // header, cursor and tape are D's part of the state; targets were stored at each reset
         const DevParams &cp = OD_COLD();
         if (t == 0) {
@@ -5450,19 +5600,87 @@ void launch_oct(const cs_config *cfg, const DevParams &p, StepIO io, hipStream_t
         hipLaunchKernelGGL((k_rollout_oct<N, false, false>), dim3((unsigned)((p.B - full + EPB - 1) / EPB)), dim3(OCT_BLOCK), 0, s, p, io);
     }
 }
+// A second stream per device for launches that must run BESIDE the caller's (launch_od: the tail of the 5-lane packing), with the two
+// events of the fork / join.  Created on first use, kept for the life of the process.
+struct SideStream {
+    hipStream_t stream;
+    hipEvent_t fork, join;
+};
+inline SideStream *side_stream() {
+    static std::mutex mu;
+    static SideStream per_dev[64];
+    static bool made[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!made[dev]) {
+        SideStream sd{};
+        if (hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        per_dev[dev] = sd;
+        made[dev] = true;
+    }
+    return &per_dev[dev];
+}
 // Octet-pair launch(es): like launch_oct, one workgroup (K + D wavefront) per 8 envs.
 template <int N>
 void launch_od(const cs_config *cfg, const DevParams &p, StepIO io, hipStream_t s) {
     const size_t W = 4 * (size_t)cfg->n_agents + 3 * (size_t)cfg->n_targets;
     const bool aligned = !io.state || ((reinterpret_cast<size_t>(io.state) & 15) == 0 && ((size_t)p.B * W) % 4 == 0);
-    const int full = aligned ? (p.B / OCT_ENVS) * OCT_ENVS : 0;
+    // three wavefronts per 8 envs (K, D and the emitting E) while five such workgroups per CU hold the batch in one round
+    const bool e3 = (io.flags & CS_KERNEL_ODE) || (!(io.flags & CS_KERNEL_OD) && p.B <= CS_ODE_UPTO);
     io.min_ahead = 2 * cfg->n_agents * CS_MAX_TARGETS;  // rows are topped up in place whenever one runs low
+    // teams of exactly 5 with at most 15 targets, obs and state both written: FIVE lanes per env, twelve envs per workgroup (OctLay<5>)
+    if constexpr (N == 5 && CS_OD_PENT != 0) {
+        if (aligned && io.obs && io.state && cfg->n_targets <= 15 && p.B >= 12) {
+            const int full5 = (p.B / 12) * 12;
+            io.env0 = 0;
+            io.env_n = full5;
+            const dim3 grid((unsigned)(full5 / 12));
+            // The last < 12 envs go through the octet kernels -- on a SIDE stream, beside the main launch: one workgroup running T steps
+            // takes as long as the whole grid (a step is latency-, not throughput-bound), so queued behind the main launch it would
+            // double the call.  fork: side waits for everything queued on s so far; join: s waits for the side launches.
+            const int tail = p.B - full5;
+            SideStream *sd = tail > 0 ? side_stream() : nullptr;
+            if (tail > 0 && sd) {
+                (void)hipEventRecord(sd->fork, s);
+                (void)hipStreamWaitEvent(sd->stream, sd->fork, 0);
+                StepIO it = io;
+                const int t8 = tail >= OCT_ENVS ? OCT_ENVS : 0;   // a full octet: the same variant as the main launch
+                if (t8) {
+                    it.env0 = full5;
+                    it.env_n = t8;
+                    if (e3) hipLaunchKernelGGL((k_rollout_od<N, true, true, true>), dim3(1), dim3(OD_BLOCK + 64), 0, sd->stream, p, it);
+                    else hipLaunchKernelGGL((k_rollout_od<N, true, true, false>), dim3(1), dim3(OD_BLOCK), 0, sd->stream, p, it);
+                }
+                if (tail - t8 > 0) {
+                    it.env0 = full5 + t8;
+                    it.env_n = tail - t8;
+                    hipLaunchKernelGGL((k_rollout_od<N, false, false, false>), dim3(1), dim3(OD_BLOCK), 0, sd->stream, p, it);
+                }
+                (void)hipEventRecord(sd->join, sd->stream);
+            }
+            if (e3) hipLaunchKernelGGL((k_rollout_od5<N, true>), grid, dim3(OD_BLOCK + 64), 0, s, p, io);
+            else hipLaunchKernelGGL((k_rollout_od5<N, false>), grid, dim3(OD_BLOCK), 0, s, p, io);
+            if (tail > 0 && sd) {
+                (void)hipStreamWaitEvent(s, sd->join, 0);
+            } else if (tail > 0) {   // no side stream to be had: behind the main launch
+                io.env0 = full5;
+                io.env_n = tail;
+                hipLaunchKernelGGL((k_rollout_od<N, false, false, false>), dim3((unsigned)((tail + OCT_ENVS - 1) / OCT_ENVS)), dim3(OD_BLOCK), 0, s, p, io);
+            }
+            return;
+        }
+    }
+    const int full = aligned ? (p.B / OCT_ENVS) * OCT_ENVS : 0;
     if (full > 0) {
         io.env0 = 0;
         io.env_n = full;
         const dim3 grid((unsigned)(full / OCT_ENVS));
-        // three wavefronts per 8 envs (K, D and the emitting E) while five such workgroups per CU hold the batch in one round
-        const bool e3 = (io.flags & CS_KERNEL_ODE) || (!(io.flags & CS_KERNEL_OD) && p.B <= CS_ODE_UPTO);
         if (io.obs && io.state && e3) hipLaunchKernelGGL((k_rollout_od<N, true, true, true>), grid, dim3(OD_BLOCK + 64), 0, s, p, io);
         else if (io.obs && io.state) hipLaunchKernelGGL((k_rollout_od<N, true, true, false>), grid, dim3(OD_BLOCK), 0, s, p, io);
         else hipLaunchKernelGGL((k_rollout_od<N, true, false, false>), grid, dim3(OD_BLOCK), 0, s, p, io);

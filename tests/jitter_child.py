@@ -1,5 +1,5 @@
-"""Child of tests/test_gpu_jitter.py: runs with COOPSEARCH_LIB pointing at one of its -DCS_ONLY_N=3 builds (-DCS_JITTER, -DCS_OD_SAFE_WAIT,
--DCS_OD_ASYNC=0).  The octet pair
+"""Child of tests/test_gpu_jitter.py: runs with COOPSEARCH_LIB pointing at one of its one-team-size builds (-DCS_JITTER,
+-DCS_OD_SAFE_WAIT, -DCS_OD_ASYNC=0, -DCS_LEGACY_KERNELS=1 for teams of 3; -DCS_OD_PENT=1 for teams of 5).  The octet pair
 kernels (K + D, and K + D + E) -- their hand-shakes stretched by pseudo-random pauses -- against the 16-lane step kernel of the
 same library, bit for bit, on a scenario where nearly every episode ends with a win K could not predict (fix request, restore
 from the ring, redo, acknowledge: every other step) and on the shipped configuration."""
@@ -13,8 +13,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cooperative_search_amd as cs  # noqa: E402
 
 
+N_AGENTS = 5 if os.path.basename(os.environ.get("COOPSEARCH_LIB", "")).endswith("_n5.so") else 3
+
+
 def custom(**kw):
-    a = cs.make_env_args("flight_easy", n_agents=3)
+    a = cs.make_env_args("flight_easy", n_agents=N_AGENTS)
     for k, v in kw.items():
         setattr(a, k, v)
     return a
@@ -45,17 +48,22 @@ def run(kernel, args, B, lengths, mode):
 
 def main():
     name = os.path.basename(cs.lib.library_path())
-    assert name in ("jitter_n3.so", "odsafe_n3.so", "odsync_n3.so", "legacy_n3.so") or os.environ.get("CS_CHILD_ANY_LIB") == "1", cs.lib.library_path()
+    assert name in ("jitter_n3.so", "odsafe_n3.so", "odsync_n3.so", "legacy_n3.so", "pent_n5.so") or os.environ.get("CS_CHILD_ANY_LIB") == "1", cs.lib.library_path()
     # legacy_n3.so (-DCS_LEGACY_KERNELS=1): the 16-lane rollout kernels of rounds 1-2, which the default build no longer holds
     kernels = ("solo", "duo") if name == "legacy_n3.so" else ("od", "ode")
     if name == "legacy_n3.so":
         assert cs.lib.has_legacy_kernels()
+    # pent_n5.so (-DCS_OD_PENT=1): twelve envs per workgroup; 1000 and 520 envs leave 4 to the octet kernel on the second stream,
+    # 4096 envs leave 4, 1004 envs leave a full octet (the vector variant) -- and 996 none
     for kernel in kernels:
+        if name == "pent_n5.so":
+            for B in (1004, 996):
+                run(kernel, custom(), B, (30, 7), dict(freeze_done=False, auto_reset=True))
         w = run(kernel, custom(target_num=2, target_mode=1, detect_prob=1.0, view_range=25), 1000, (7, 64, 3, 100, 26),
                 dict(freeze_done=False, auto_reset=True))
         assert w > 5000, w   # tens of unpredicted wins per env
         run(kernel, custom(target_num=2, target_mode=1, detect_prob=1.0, view_range=25), 520, (40, 9), dict(freeze_done=True))
-        run(kernel, cs.make_env_args("flight_easy", n_agents=3), 4096, (100, 20), dict(freeze_done=False, auto_reset=True))
+        run(kernel, custom(), 4096, (100, 20), dict(freeze_done=False, auto_reset=True))
         # every target within view of every agent most of the time: up to 90 stream words per env-step, a row refresh every few
         # steps (the three-wavefront variant hands those to E: request, old tape meanwhile, adoption -- and the waits for an
         # outstanding refresh in front of resets and on-the-spot top-ups), short and long launches

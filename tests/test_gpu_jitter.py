@@ -12,7 +12,11 @@ If the shipped kernel ever read LDS before a request had landed, it would differ
 The three-wavefront variant's row refreshes run in its emitting wavefront (request / old tape meanwhile / adoption, CS_OD_E_REFRESH):
 the jitter build pauses at those hand-shakes too, and the child's last scenario makes every env refresh its row every few steps.
   legacy_n3   -DCS_LEGACY_KERNELS=1  (round 5) k_rollout ("solo") and k_rollout_duo, the 16-lane rollout kernels of rounds 1-2 that no dispatch
-                                 row selects and the default build leaves out: the same scenarios, so they stay compiling and bit-exact."""
+                                 row selects and the default build leaves out: the same scenarios, so they stay compiling and bit-exact.
+  pent_n5     -DCS_OD_PENT=1     (round 5, teams of 5) the 5-lanes-per-env packing of the pair kernels -- twelve envs per workgroup, three
+                                 targets per lane, the last envs of a batch on the octet kernels beside it on a second stream -- which
+                                 the default build leaves out (measured slower): the same scenarios at batches
+                                 that leave 0, 4 and 8 envs to the octet kernels."""
 import concurrent.futures
 import os
 import subprocess
@@ -24,7 +28,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VARIANTS = {"jitter_n3": ["-DCS_JITTER"], "odsafe_n3": ["-DCS_OD_SAFE_WAIT"], "odsync_n3": ["-DCS_OD_ASYNC=0"],
             # (round 5) the 16-lane rollout kernels of rounds 1-2, retired from the default build: kept compiling and bit-exact here
-            "legacy_n3": ["-DCS_LEGACY_KERNELS=1"]}
+            "legacy_n3": ["-DCS_LEGACY_KERNELS=1"],
+            # (round 5) the 5-lanes-per-env packing of the pair kernels, an experiment the default build leaves out
+            "pent_n5": ["-DCS_OD_PENT=1"]}
+
+
+def team_size(name):
+    return int(name.rsplit("_n", 1)[1])
 
 
 def variant_path(name):
@@ -37,16 +47,16 @@ def build_variant(name):
     variants travel to the GPU box): compiled with -DCS_SOURCE_HASH=<hash of sources + flags>, current when its recorded hash is
     that -- never by mtime.  None when it is missing and there is no hipcc."""
     from cooperative_search_amd import build as b
-    return b.build_variant(name, VARIANTS[name], only_n=3)
+    return b.build_variant(name, VARIANTS[name], only_n=team_size(name))
 
 
 def expected_hash(name):
     from cooperative_search_amd import build as b
-    return b.variant_hash(VARIANTS[name], 3)
+    return b.variant_hash(VARIANTS[name], team_size(name))
 
 
 def build_all_variants():
-    """All three, side by side (each is one single-threaded hipcc run of ~2 minutes)."""
+    """All of them, side by side (each is one single-threaded hipcc run of ~2 minutes)."""
     with concurrent.futures.ThreadPoolExecutor(max_workers=len(VARIANTS)) as ex:
         return list(ex.map(build_variant, VARIANTS))
 

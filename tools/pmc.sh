@@ -2,7 +2,7 @@
 # rocprofv3 PMC passes (one counter group per run, no tracing flags) over a python script of this repo.
 #   usage: tools/pmc.sh <tag> <kernel-substring> <script relative to the repo root> [script args...]
 # Writes gpurun_out/pmc_<tag>/summary.json with the per-launch average of every counter for kernels whose name contains
-# the substring.  FETCH_SIZE / WRITE_SIZE are collected in separate passes (MI355X_MICROARCH.md, PMC slots).
+# the substring (PMC_ONLY="2 3" runs only those groups).  FETCH_SIZE / WRITE_SIZE are collected in separate passes (MI355X_MICROARCH.md, PMC slots).
 set -u
 R="${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (gpurun exports it)}"
 TAG="${1:?tag}"; KPAT="${2:?kernel substring}"; SCRIPT="${3:?script}"; shift 3
@@ -16,6 +16,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ
            "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_SMEM GRBM_GUI_ACTIVE" \
            "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
+  case " ${PMC_ONLY:-1 2 3 4 5 6} " in *" $i "*) ;; *) continue ;; esac
   timeout 600 rocprofv3 --pmc $grp --output-format csv -d "$OUT/g$i" -- python3 "$R/$SCRIPT" "$@" > "$OUT/g$i.log" 2>&1
   rc=$?
   echo "group $i ($grp) rc=$rc"
