@@ -5601,7 +5601,12 @@ void launch_oct(const cs_config *cfg, const DevParams &p, StepIO io, hipStream_t
     }
 }
 // A second stream per device for launches that must run BESIDE the caller's (launch_od: the tail of the 5-lane packing), with the two
-// events of the fork / join.  Created on first use, kept for the life of the process.
+// events of the fork / join.  Created on first use, kept for the life of the process.  The events are shared by every caller on the
+// device: a fork .. join sequence is enqueued under side_order() so that two host threads cannot interleave their records and waits.
+inline std::mutex &side_order() {
+    static std::mutex mu;
+    return mu;
+}
 struct SideStream {
     hipStream_t stream;
     hipEvent_t fork, join;
@@ -5646,7 +5651,9 @@ void launch_od(const cs_config *cfg, const DevParams &p, StepIO io, hipStream_t 
             // double the call.  fork: side waits for everything queued on s so far; join: s waits for the side launches.
             const int tail = p.B - full5;
             SideStream *sd = tail > 0 ? side_stream() : nullptr;
+            std::unique_lock<std::mutex> order(side_order(), std::defer_lock);
             if (tail > 0 && sd) {
+                order.lock();   // (until the join below has been enqueued)
                 (void)hipEventRecord(sd->fork, s);
                 (void)hipStreamWaitEvent(sd->stream, sd->fork, 0);
                 StepIO it = io;
