@@ -4470,9 +4470,13 @@ __device__ __forceinline__ void rollout_od_body(const DevParams &p, const StepIO
     }
 
     // ---------------------------------------------------------------------------------------------- D: detection
-#ifdef CS_OD_DPRIO
-    if (!E3) __builtin_amdgcn_s_setprio(CS_OD_DPRIO);
+    // The pair variant (two K and two D wavefronts per SIMD at 16384 envs): D ahead of K in the issue arbitration.  One box, two passes,
+    // us per step at 16384 envs, priority 0 / 1 / 2 / 3: 5 agents 3.29-3.31 / 3.18 / 3.18-3.19 / 3.15-3.22, 3 agents 2.35-2.36 / 2.29-2.31 /
+    // 2.30-2.34 / 2.28-2.31 (8192 envs, 3: 2.17 -> 2.08 / 1.64 -> 1.55); K at 3 instead: 3.25 / 2.38, and slower at 8192 and 32768 envs.
+#ifndef CS_OD_DPRIO
+#define CS_OD_DPRIO 1
 #endif
+    if (!E3) __builtin_amdgcn_s_setprio(CS_OD_DPRIO);
 #ifndef CS_ODE_DPRIO
 #define CS_ODE_DPRIO 2   /* three-wavefront variant: K (3) > D (2) > E (0) where wavefronts share a SIMD: -3 % per step at 8192 envs */
 #endif
