@@ -96,6 +96,111 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+# ---------------------------------------------------------------------------------------------- the one stdout line
+MAX_LINE = 6000          # hard ceiling of the stdout line in characters (a consumer that keeps the last 8 KB still parses it)
+CPU_SAMPLE_MAX = 300     # cpu_baseline.sample in the line; the long form is in the detail file
+DETAIL_NAME = "bench_detail.json"
+
+
+def sig(x, digits=6):
+    """Floats of the side entries rounded to `digits` significant digits (the headline keeps every digit)."""
+    if isinstance(x, float) and math.isfinite(x) and x != 0.0:
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, (list, tuple)):
+        return [sig(v, digits) for v in x]
+    if isinstance(x, dict):
+        return {k: sig(v, digits) for k, v in x.items()}
+    return x
+
+
+def compact_line(full, detail_path=None):
+    """The line that goes to stdout, built from the full record: the contract's headline fields untouched, `config`, `timing`,
+    `roofline`, `eval`, `per_rank_value` and `cpu_baseline` cut down to their numbers, and every secondary workload as one
+    `also_summary` pair {key: [env-steps/s, roofline fraction]}.  The full record (every `also` entry with its own roofline
+    object, the CPU baseline's thread scaling and pinning) goes to `detail_path`.  Never longer than MAX_LINE characters:
+    optional blocks are dropped, least important first, until it fits (r05's 21.8 KB line was cut by its consumer)."""
+    line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                 "scaling", "vs_baseline", "dtype", "data") if k in full}
+    if full.get("dry_run"):
+        line["dry_run"] = True
+    cfg = dict(full.get("config") or {})
+    if isinstance(cfg.get("cpu_binding"), dict):
+        cfg["cpu_binding"] = {k: cfg["cpu_binding"][k] for k in ("numa_node", "cpus") if k in cfg["cpu_binding"]}
+    if "backend_error" in cfg:
+        cfg["backend_error"] = str(cfg["backend_error"])[:160]
+    line["config"] = cfg
+    if "timing" in full:
+        t = full["timing"]
+        line["timing"] = {"clock": "HIP events, launch stream; median of repeats, max over ranks", "repeats": t["repeats"],
+                          "timed_gpu_s": sig(t["timed_gpu_s"]), "region_ms_min_median_max": sig(t["region_ms_min_median_max"]),
+                          "wall_ms_per_step": sig(t["wall_ms_per_step"])}
+    if "roofline" in full:
+        r = full["roofline"]
+        line["roofline"] = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel",
+                                             "algorithmic_bytes_per_env_step", "algorithmic_bytes_per_launch", "avg_launch_us")
+                            if k in r}
+        src = r.get("traffic_source")
+        line["roofline"]["traffic_source"] = src.split(":")[0] + " (committed --pmc passes, scaled)" if src else None
+    if "eval" in full:
+        e = dict(full["eval"])
+        if isinstance(e.get("allgather_us"), dict):
+            e["allgather_us"] = sig({k: e["allgather_us"][k] for k in ("median", "min", "max", "reps", "floats", "error")
+                                     if k in e["allgather_us"]})
+        e["reduced_by"] = "all_gather" if str(e.get("reduced_by", "")).startswith("all_gather") else e.get("reduced_by")
+        line["eval"] = sig(e)
+    if full.get("per_rank_value"):
+        line["per_rank_value"] = sig({k: v for k, v in full["per_rank_value"].items() if k != "unit"}, 7)
+    for key in ("also_at_this_n", "c5_strong_total", "c5_weak_total"):
+        if key in full:
+            line[key] = sig(full[key]) if isinstance(full[key], dict) else full[key]
+    if full.get("also"):
+        line["also_summary"] = {"_": "key: [env-steps/s, HBM roofline fraction (null: closed loop)]"}
+        for ent in full["also"]:
+            frac = (ent.get("roofline") or {}).get("frac")
+            line["also_summary"][ent.get("key") or str(ent.get("workload"))[:24]] = [sig(ent.get("value"), 4), sig(frac, 3)]
+    if full.get("cpu_baseline"):
+        c = full["cpu_baseline"]
+        line["cpu_baseline"] = {"value": sig(c.get("value"), 7), "unit": c.get("unit"), "cores": c.get("cores"),
+                                "kind": c.get("kind"), "single_thread_value": sig(c.get("single_thread_value"), 7),
+                                "sample": str(c.get("sample_short") or c.get("sample"))[:CPU_SAMPLE_MAX]}
+    if detail_path:
+        line["detail"] = detail_path
+    for victim in ("also_summary", "per_rank_value", "timing", "c5_weak_total", "c5_strong_total", "eval"):
+        if len(json.dumps(line)) <= MAX_LINE:
+            break
+        line.pop(victim, None)
+        line["dropped_to_fit"] = line.get("dropped_to_fit", []) + [victim]
+    if len(json.dumps(line)) > MAX_LINE:
+        raise RuntimeError(f"bench.py: the stdout line is {len(json.dumps(line))} characters (> {MAX_LINE})")
+    return line
+
+
+def _fits(line):
+    if len(json.dumps(line)) > MAX_LINE:
+        raise RuntimeError(f"bench.py: the stdout line is {len(json.dumps(line))} characters (> {MAX_LINE})")
+    return line
+
+
+def write_detail(full):
+    """The full record next to the run: gpurun_out/bench_detail.json under the repo root (merged back by gpurun), the system's
+    temporary directory when that is not writable.  Returns the path as the line names it (relative to the repo root when
+    inside it), or None."""
+    import tempfile
+    for d in (os.environ.get("BENCH_DETAIL_DIR"), os.path.join(ROOT, "gpurun_out"), tempfile.gettempdir()):
+        if not d:
+            continue
+        try:
+            os.makedirs(d, exist_ok=True)
+            path = os.path.join(d, DETAIL_NAME)
+            with open(path, "w") as fh:
+                json.dump(full, fh, indent=1)
+            return os.path.relpath(path, ROOT) if os.path.abspath(path).startswith(ROOT + os.sep) else path
+        except OSError:
+            continue
+    return None
+
+
+
 # ------------------------------------------------------------------------------------------------- N-rank launcher
 def _free_port():
     s = socket.socket()
@@ -344,6 +449,9 @@ def cpu_baseline_inproc(env_name, n, batch, budget_s=10.0):
     faster = {str(th): [points[th]["p10"], points[th]["median"], points[th]["p90"]] for th in top
               if th != best and points[th]["median"] > value}
     return {"value": value, "unit": "env-steps/s", "cores": best, "kind": "port",
+            "sample_short": f"C oracle (oracle/flight_oracle.c, OpenMP, env-major), {B} envs x {T * R * pt['regions']} steps on {best} "
+                            f"threads, auto-reset, obs+state emitted, {pt['wall_s']:.1f} s wall, {cpu_model()}"
+                            + (f", cgroup quota {quota:g} CPUs" if quota else ""),
             "sample": f"C oracle (oracle/flight_oracle.c orc_batch_rollout_rep: one OpenMP region per {T * R} steps, "
                       f"env-major, dynamic schedule), {B} envs x {T * R * pt['regions']} steps on {best} threads (fastest of "
                       f"{top} whose regions span < {STEADY_SPAN}x; calibrated over {cands}), auto-reset, "
@@ -635,16 +743,17 @@ def run_workload(cs, dev, comm, env_name, n, B, mode, K, W, kernel, rank=0, no_g
     return res, env
 
 
-def side_measurement(cs, dev, comm, label, env_name, n, B, mode, K, W, kernel, rank=0):
-    """Compact entry for the `also` list: another workload measured in the same run with the same protocol."""
+def side_measurement(cs, dev, comm, key, label, env_name, n, B, mode, K, W, kernel, rank=0):
+    """Entry for the `also` list (detail file; `key` names it in the line's also_summary): another workload measured in the
+    same run with the same protocol."""
     import torch
     res, env = run_workload(cs, dev, comm, env_name, n, B, mode, K, W, kernel, rank=rank)
     del env
     torch.cuda.empty_cache()
-    return {"workload": label, "mode": mode, "kernel": kernel, "steps": K, "warmup": W, **res}
+    return {"key": key, "workload": label, "mode": mode, "kernel": kernel, "steps": K, "warmup": W, **res}
 
 
-def closed_loop_measurement(cs, dev, n, B, K, W, env_name="flight_easy"):
+def closed_loop_measurement(cs, dev, key, n, B, K, W, env_name="flight_easy"):
     """`also` entry: the reference's recurrent agent network (agents.FusedAgents -> csrc/policy.hip) picks every action
     from the live obs, then env.step, nothing leaves the device."""
     import torch
@@ -681,7 +790,7 @@ def closed_loop_measurement(cs, dev, n, B, K, W, env_name="flight_easy"):
     pol_us = e0.elapsed_time(e1) * 1e3 / 200
     del env, agents
     torch.cuda.empty_cache()
-    out = {"workload": f"closed loop: {env_name} {n}a15t B={B}, recurrent policy picks every action"
+    out = {"key": key, "workload": f"closed loop: {env_name} {n}a15t B={B}, recurrent policy picks every action"
                        + (" (k_rollout_policy: network + env step fused, 100 steps per launch)" if env_name == "flight_easy"
                           else " (cs_rollout_policy_flight: conv on the map in place, network, step, map update per step; "
                                "the n observation copies of the map are not written)"),
@@ -720,14 +829,14 @@ def dry_run(a, rank, world):
         per_rank = {"min": min(rates), "median": statistics.median(rates), "max": max(rates), "slowest_rank": rates.index(min(rates)),
                     "unit": "env-steps/s per GPU (fabricated: 1e9 + rank)"}
     if rank == 0:
-        print(json.dumps({"metric": "env-steps/sec", "value": None, "unit": "env-steps/s", "n_gpus": world,
+        print(json.dumps(_fits({"metric": "env-steps/sec", "value": None, "unit": "env-steps/s", "n_gpus": world,
                           "steps": a.steps, "warmup": a.warmup, "dry_run": True,
                           "eval": {"envs": int(part[3].item()), "world_size": world, "allgather_us": allgather_us},
                           "per_rank_value": per_rank,
                           "also_at_this_n": "all" if (world == 1 or a.also) else "c5 weak + c5 strong only",
                           "c5_strong_total": {"value": None, "n_gpus": world, "envs_total": C5_GLOBAL_BATCH,
                                               "envs_per_gpu": C5_GLOBAL_BATCH // world if C5_GLOBAL_BATCH % world == 0 else None},
-                          "c5_weak_total": {"value": None, "n_gpus": world, "envs_total": 8192 * world, "envs_per_gpu": 8192}}),
+                          "c5_weak_total": {"value": None, "n_gpus": world, "envs_total": 8192 * world, "envs_per_gpu": 8192}})),
               flush=True)
     if world > 1:
         dist.barrier()
@@ -909,40 +1018,40 @@ def main():
     if not a.no_also and a.workload == "c2" and not a.batch:
         # c5 (BASELINE config 5: flight_easy 5a15t, 65536 envs over the node) at every N: the weak point (8192 per GPU,
         # = the 8-GPU configuration's per-GPU share) and the strong point (65536 / N per GPU)
-        also.append(side_measurement(cs, dev, comm, "c5 weak: flight_easy 5a15t, 8192 envs per GPU", "flight_easy", 5,
+        also.append(side_measurement(cs, dev, comm, "c5w", "c5 weak: flight_easy 5a15t, 8192 envs per GPU", "flight_easy", 5,
                                      8192, "rollout", 1000, 100, "auto", rank=rank))
         if C5_GLOBAL_BATCH % world == 0:
-            also.append(side_measurement(cs, dev, comm, f"c5 strong: flight_easy 5a15t, 65536 envs over {world} GPU(s)",
+            also.append(side_measurement(cs, dev, comm, "c5s", f"c5 strong: flight_easy 5a15t, 65536 envs over {world} GPU(s)",
                                          "flight_easy", 5, C5_GLOBAL_BATCH // world, "rollout", 400, 100, "auto", rank=rank))
         if world == 1 or a.also:
             also += [
-                side_measurement(cs, dev, comm, "c2 flight_easy 3a15t B=4096, one launch per step (hipGraph)",
+                side_measurement(cs, dev, comm, "c2_step", "c2 flight_easy 3a15t B=4096, one launch per step (hipGraph)",
                                  "flight_easy", 3, 4096, "step", 2000, 200, "auto"),
-                side_measurement(cs, dev, comm, "c3 flight_easy 5a15t B=16384", "flight_easy", 5, 16384, "rollout",
+                side_measurement(cs, dev, comm, "c3", "c3 flight_easy 5a15t B=16384", "flight_easy", 5, 16384, "rollout",
                                  1000, 100, "auto"),
-                side_measurement(cs, dev, comm, "flight_easy 3a15t B=16384 (the 8192..65536 valley of round 2)", "flight_easy", 3,
+                side_measurement(cs, dev, comm, "fe3_16384", "flight_easy 3a15t B=16384 (the 8192..65536 valley of round 2)", "flight_easy", 3,
                                  16384, "rollout", 1000, 100, "auto"),
-                side_measurement(cs, dev, comm, "flight_easy 3a15t B=32768 (one-wavefront octet kernel)", "flight_easy", 3,
+                side_measurement(cs, dev, comm, "fe3_32768", "flight_easy 3a15t B=32768 (one-wavefront octet kernel)", "flight_easy", 3,
                                  32768, "rollout", 400, 100, "auto"),
-                side_measurement(cs, dev, comm, "flight_easy 5a15t B=32768 (one-wavefront octet kernel)", "flight_easy", 5,
+                side_measurement(cs, dev, comm, "fe5_32768", "flight_easy 5a15t B=32768 (one-wavefront octet kernel)", "flight_easy", 5,
                                  32768, "rollout", 400, 100, "auto"),
-                side_measurement(cs, dev, comm, "c4 flight 3a15t B=8192, cs_step per step (hipGraph): k_step then k_map",
+                side_measurement(cs, dev, comm, "c4_step", "c4 flight 3a15t B=8192, cs_step per step (hipGraph): k_step then k_map",
                                  "flight", 3, 8192, "step", 400, 100, "auto"),
-                side_measurement(cs, dev, comm, "c4 flight 3a15t B=8192 (cs_rollout: sweep of step t beside step t + 1)",
+                side_measurement(cs, dev, comm, "c4", "c4 flight 3a15t B=8192 (cs_rollout: sweep of step t beside step t + 1)",
                                  "flight", 3, 8192, "rollout", 400, 100, "auto"),
-                side_measurement(cs, dev, comm, "flight 3a15t B=32768 (cs_rollout; 328 MB of maps: past the 256 MiB Infinity Cache)",
+                side_measurement(cs, dev, comm, "c4_32768", "flight 3a15t B=32768 (cs_rollout; 328 MB of maps: past the 256 MiB Infinity Cache)",
                                  "flight", 3, 32768, "rollout", 40, 20, "auto"),
-                side_measurement(cs, dev, comm, "flight_easy 3a15t B=262144 (lane-per-env kernel: the HBM-regime kernel)",
+                side_measurement(cs, dev, comm, "fe3_2^18", "flight_easy 3a15t B=262144 (lane-per-env kernel: the HBM-regime kernel)",
                                  "flight_easy", 3, 262144, "rollout", 200, 100, "auto"),
-                side_measurement(cs, dev, comm, "flight_easy 3a15t B=1048576 (lane-per-env kernel; batch sweep asymptote)",
+                side_measurement(cs, dev, comm, "fe3_2^20", "flight_easy 3a15t B=1048576 (lane-per-env kernel; batch sweep asymptote)",
                                  "flight_easy", 3, 1048576, "rollout", 100, 100, "auto"),
-                side_measurement(cs, dev, comm, "flight_easy 5a15t B=262144 (lane-per-env kernel)",
+                side_measurement(cs, dev, comm, "fe5_2^18", "flight_easy 5a15t B=262144 (lane-per-env kernel)",
                                  "flight_easy", 5, 262144, "rollout", 400, 100, "auto"),
-                side_measurement(cs, dev, comm, "flight_easy 5a15t B=1048576 (lane-per-env kernel)",
+                side_measurement(cs, dev, comm, "fe5_2^20", "flight_easy 5a15t B=1048576 (lane-per-env kernel)",
                                  "flight_easy", 5, 1048576, "rollout", 200, 100, "auto"),
-                closed_loop_measurement(cs, dev, 3, 4096, 2000, 200),
-                closed_loop_measurement(cs, dev, 3, 65536, 400, 100),
-                closed_loop_measurement(cs, dev, 3, 8192, 400, 100, "flight"),
+                closed_loop_measurement(cs, dev, "loop3_4096", 3, 4096, 2000, 200),
+                closed_loop_measurement(cs, dev, "loop3_65536", 3, 65536, 400, 100),
+                closed_loop_measurement(cs, dev, "loop_flight_8192", 3, 8192, 400, 100, "flight"),
             ]
     if rank == 0:
         if also:
@@ -958,7 +1067,15 @@ def main():
                                  "roofline_frac_per_gpu": ent["roofline"]["frac"]}
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(env_name, n, B)
-        emit_line(line)
+        # stdout carries the compact line (<= MAX_LINE characters); the full record goes to gpurun_out/bench_detail.json and,
+        # one entry per row, to stderr BEFORE the line (so the line stays the last thing this process prints)
+        detail = write_detail(line)
+        for ent in also:
+            fr = (ent.get("roofline") or {}).get("frac")
+            sys.stderr.write(f"bench.py: also {ent.get('key'):>16}  {ent['value']:.4g} env-steps/s  "
+                             f"{'frac %.3f' % fr if fr is not None else 'closed loop'}  {ent.get('workload')}\n")
+        sys.stderr.flush()
+        emit_line(compact_line(line, detail))
     if pg:
         dist.barrier()
         dist.destroy_process_group()

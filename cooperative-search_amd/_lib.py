@@ -196,6 +196,9 @@ def has_legacy_kernels():
     return bool(L.cs_has_legacy_kernels())
 
 
+OP_NO_CHECK_ACTIONS = 1 << 30   # torch op layer only (csrc/torch_ops.cpp): 'the caller decided: no check'; never reaches the C ABI
+
+
 def check(rc):
     if rc != 0:
         msg = load().cs_last_error().decode()

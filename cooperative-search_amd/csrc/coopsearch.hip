@@ -4278,7 +4278,7 @@ __device__ __forceinline__ void rollout_od_body(const DevParams &p, const StepIO
             }
         };
 #ifndef CS_OD_EARLY_PEEK
-#define CS_OD_EARLY_PEEK 1
+#define CS_OD_EARLY_PEEK 0
 #endif
         constexpr int OFF_FIX = (int)(offsetof(OdShared, fix_req) - offsetof(OdShared, d_steps)) / 4;
         constexpr int OFF_E = (int)(offsetof(OdShared, e_steps) - offsetof(OdShared, d_steps)) / 4;
@@ -5327,20 +5327,16 @@ __global__ void k_eps_step(DevParams p, int flags, double *eps, double anneal, d
     if (executed) eps[b] = v > min_eps ? v - anneal : v;   // common/rollout.py:75-76
 }
 
-// CS_CHECK_ACTIONS: every action of a call must index dyaw = [0, pi/18, -pi/18] (flight_env_easy.py:259-262).  The first
-// offender (lowest flat index wins a compare-and-swap) is reported through four host-mapped words: flag, index lo / hi, value.
-__global__ void k_check_actions(const void *actions, unsigned long long count, int i64, int n_actions, int *report) {
+// CS_CHECK_ACTIONS: every action of a call must index dyaw = [0, pi/18, -pi/18] (flight_env_easy.py:259-262).  The offender with the
+// LOWEST flat index -- the one the reference's sequential loops would raise on -- is reported through one host-mapped 64-bit word
+// (atomic minimum over all offenders; ~0 = none).
+__global__ void k_check_actions(const void *actions, unsigned long long count, int i64, int n_actions, unsigned long long *first_bad) {
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count;
          i += (unsigned long long)gridDim.x * blockDim.x) {
         const long long v = i64 ? static_cast<const long long *>(actions)[i] : (long long)static_cast<const int *>(actions)[i];
         if (v < 0 || v >= n_actions) {
-            if (atomicCAS_system(report, 0, 1) == 0) {
-                report[1] = (int)(unsigned)(i & 0xffffffffull);
-                report[2] = (int)(unsigned)(i >> 32);
-                report[3] = (int)(v < -2147483647ll ? -2147483647ll : (v > 2147483647ll ? 2147483647ll : v));
-                __threadfence_system();
-            }
-            return;
+            atomicMin_system(first_bad, i);
+            return;   // this thread's later indices are all higher
         }
     }
 }
@@ -5466,21 +5462,28 @@ int make_params(const cs_config *c, void *state, DevParams *p) {
 // stream capture, not for the production loop.
 int check_actions(const void *actions_dev, size_t count, int flags, int n_agents, size_t B, hipStream_t s) {
     static std::mutex mu;
-    static int *report = nullptr;   // four host-mapped words
+    static unsigned long long *report[64] = {};   // one host-mapped word per device, visible to every device (portable)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return CS_OK;   // a captured call cannot synchronise: unchecked
-    (void)hipGetLastError();
+    // a captured call cannot synchronise, and asking about a stream while ANOTHER one is in a global-mode capture is an error that
+    // can invalidate that capture: in both cases the call goes unchecked
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return CS_OK;
+    }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail(CS_E_LAUNCH, "CS_CHECK_ACTIONS: no current device");
     std::lock_guard<std::mutex> lock(mu);
-    if (!report) {
-        if (hipHostMalloc((void **)&report, 4 * sizeof(int), hipHostMallocMapped) != hipSuccess) {
-            report = nullptr;
+    if (!report[dev]) {
+        if (hipHostMalloc((void **)&report[dev], sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
+            report[dev] = nullptr;
             (void)hipGetLastError();
-            return fail(CS_E_LAUNCH, "CS_CHECK_ACTIONS: cannot allocate the report words");
+            return fail(CS_E_LAUNCH, "CS_CHECK_ACTIONS: cannot allocate the report word");
         }
     }
-    report[0] = report[1] = report[2] = report[3] = 0;
-    int *report_dev = nullptr;
-    if (hipHostGetDevicePointer((void **)&report_dev, report, 0) != hipSuccess) return fail(CS_E_LAUNCH, "CS_CHECK_ACTIONS: no device view of the report words");
+    volatile unsigned long long *rep = report[dev];
+    *rep = ~0ull;
+    unsigned long long *report_dev = nullptr;
+    if (hipHostGetDevicePointer((void **)&report_dev, report[dev], 0) != hipSuccess) return fail(CS_E_LAUNCH, "CS_CHECK_ACTIONS: no device view of the report word");
     const unsigned blocks = (unsigned)((count + 255) / 256 < 4096 ? (count + 255) / 256 : 4096);
     hipLaunchKernelGGL(k_check_actions, dim3(blocks ? blocks : 1), dim3(256), 0, s, actions_dev, (unsigned long long)count,
                        (flags & CS_ACTIONS_I64) ? 1 : 0, 3, report_dev);
@@ -5488,11 +5491,18 @@ int check_actions(const void *actions_dev, size_t count, int flags, int n_agents
         snprintf(g_err, sizeof(g_err), "CS_CHECK_ACTIONS: %s", hipGetErrorString(hipGetLastError()));
         return CS_E_LAUNCH;
     }
-    if (report[0]) {
-        const unsigned long long i = (unsigned long long)(unsigned)report[1] | ((unsigned long long)(unsigned)report[2] << 32);
+    const unsigned long long i = *rep;
+    if (i != ~0ull) {
+        long long v = 0;
+        int v32 = 0;
+        const bool wide = (flags & CS_ACTIONS_I64) != 0;
+        const hipError_t e = wide ? hipMemcpy(&v, static_cast<const long long *>(actions_dev) + i, sizeof(v), hipMemcpyDeviceToHost)
+                                  : hipMemcpy(&v32, static_cast<const int *>(actions_dev) + i, sizeof(v32), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) (void)hipGetLastError();
+        if (!wide) v = v32;
         const unsigned long long per_step = (unsigned long long)B * (unsigned long long)n_agents;
-        snprintf(g_err, sizeof(g_err), "list index out of range: action %d of step %llu, env %llu, agent %llu is not in 0..2 "
-                 "(dyaw[act], flight_env_easy.py:262; the batched path takes no negative indices)", report[3],
+        snprintf(g_err, sizeof(g_err), "list index out of range: action %lld of step %llu, env %llu, agent %llu is not in 0..2 "
+                 "(dyaw[act], flight_env_easy.py:262; the batched path takes no negative indices)", v,
                  i / per_step, (i % per_step) / (unsigned long long)n_agents, i % (unsigned long long)n_agents);
         return CS_E_ARG;
     }
@@ -5719,7 +5729,7 @@ inline long long lane_from(const cs_config *c) {
 // env per lane (no replicated arithmetic; wins once the batch gives every SIMD a wavefront anyway).
 inline bool use_lane_kernel(const cs_config *c, int flags, bool rollout) {
     if (flags & (CS_KERNEL_LANE | CS_KERNEL_LANEV)) return true;
-    if (flags & CS_KERNEL_GROUP) return false;
+    if (flags & (CS_KERNEL_GROUP | CS_KERNEL_SOLO | CS_KERNEL_DUO)) return false;   // a forced 16-lane kernel is never replaced by another one
     if (rollout && (flags & (CS_KERNEL_OCT | CS_KERNEL_OD | CS_KERNEL_ODE))) return false;
     // single steps have no octet variant: the lane kernel takes over from the 16-lane step kernel at 32768 envs as before
     return c->batch >= (rollout ? lane_from(c) : 32768);

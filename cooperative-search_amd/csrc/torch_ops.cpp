@@ -117,8 +117,12 @@ void env_reset(const Tensor &cfg, Tensor state, const c10::optional<Tensor> &mas
                 stream_of(state)));
 }
 
-// CS_CHECK_ACTIONS is on by default for batches of up to 64 envs (the B = 1 adapters, debugging sessions: a stream
-// synchronisation costs nothing there); COOPSEARCH_CHECK_ACTIONS=0 / 1 turns it off / on for every batch.
+// CS_CHECK_ACTIONS through the op layer: a caller that has decided says so -- CS_CHECK_ACTIONS in `flags` = on, OP_NO_CHECK_ACTIONS
+// (a bit of this layer, stripped before the C ABI sees the flags) = off; with neither, the default applies: on for batches of up to
+// 64 envs (debugging sessions; a stream synchronisation costs nothing there), COOPSEARCH_CHECK_ACTIONS=0 / 1 turns the DEFAULT off /
+// on for every batch.  (BatchedFlightEnv always decides: its check_actions argument is what runs.)  Under stream capture the check
+// is skipped silently -- a captured call cannot synchronise -- see CS_CHECK_ACTIONS in include/coopsearch.h.
+constexpr int64_t OP_NO_CHECK_ACTIONS = int64_t(1) << 30;
 bool check_actions_default(int64_t batch) {
     static const int mode = [] {
         const char *e = getenv("COOPSEARCH_CHECK_ACTIONS");
@@ -130,8 +134,10 @@ bool check_actions_default(int64_t batch) {
 int action_flags(const Tensor &actions, int64_t flags, int64_t batch) {
     TORCH_CHECK(actions.scalar_type() == at::kInt || actions.scalar_type() == at::kLong,
                 "coopsearch: actions must be int32 or int64, got ", actions.scalar_type());
-    return (int)(flags & ~(int64_t)CS_ACTIONS_I64) | (actions.scalar_type() == at::kLong ? CS_ACTIONS_I64 : 0) |
-           (check_actions_default(batch) ? CS_CHECK_ACTIONS : 0);
+    const bool decided = (flags & (CS_CHECK_ACTIONS | OP_NO_CHECK_ACTIONS)) != 0;
+    const bool check = decided ? (flags & OP_NO_CHECK_ACTIONS) == 0 : check_actions_default(batch);
+    return (int)(flags & ~(int64_t)(CS_ACTIONS_I64 | CS_CHECK_ACTIONS | OP_NO_CHECK_ACTIONS)) |
+           (actions.scalar_type() == at::kLong ? CS_ACTIONS_I64 : 0) | (check ? CS_CHECK_ACTIONS : 0);
 }
 
 // env.step(act_list) -- flight_env_easy.py:303-314, flight_env.py:357-368

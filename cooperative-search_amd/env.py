@@ -266,6 +266,8 @@ class BatchedFlightEnv:
             f |= _lib.ACTIONS_I64
         if self.check_actions:
             f |= _lib.CHECK_ACTIONS
+        elif self.binding == "torch":   # the op layer applies its own default unless told: off means off (csrc/torch_ops.cpp)
+            f |= _lib.OP_NO_CHECK_ACTIONS
         if self.kernel == "group":
             f |= _lib.KERNEL_GROUP
         elif self.kernel == "solo":

@@ -84,7 +84,8 @@ enum {
                             of range": dyaw[act], flight_env_easy.py:259-262) and leaves the env state untouched.  Without the
                             flag the kernels treat any value other than 1 / 2 as 0 (no bounds check in the hot loops).  Python's
                             negative indices (dyaw[-1]) are NOT accepted by the batched path; the B = 1 adapter maps them like the
-                            reference.  Synchronises the stream: not for stream capture.  A library built with
+                            reference.  Synchronises the stream: a call made while the stream is being captured (or while the
+                            capture state cannot be queried) is NOT checked, silently.  A library built with
                             -DCS_CHECK_ACTIONS_ALWAYS checks every call; the torch op layer sets the flag for batches of up to
                             64 envs (COOPSEARCH_CHECK_ACTIONS=0 / 1 turns that off / on for every batch). */
 };

@@ -2,6 +2,7 @@
 (the path's only collective).  The env kernels themselves need a GPU and are covered by the shard-invariance test in
 test_gpu_parity.py; here each rank fabricates the per-env counters of its shard deterministically from the global
 env index, so the reduced result must not depend on the sharding."""
+import json
 import os
 import socket
 
@@ -106,12 +107,55 @@ def test_bench_gpus_flag_spawns_that_many_ranks():
     assert line["steps"] == 20 and line["warmup"] == 5
 
 
+def test_bench_line_is_compact_whatever_the_record_holds():
+    """the stdout line never exceeds 6000 characters.  compact_line() on the 21.8 KB record of round 5 (17
+    secondary workloads with a roofline object each, the CPU baseline's whole calibration) keeps every contract field, turns
+    the secondary workloads into [value, fraction] pairs and cuts cpu_baseline to six fields; a record that is too big even
+    then loses optional blocks, never the headline; the dry-run line goes through the same ceiling."""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod4", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    full = json.load(open(os.path.join(root, "profiles", "r05_bench_driver_args.json")))
+    assert len(json.dumps(full)) > 20000
+    for i, ent in enumerate(full["also"]):
+        ent["key"] = f"workload_{i:02d}"
+    line = bench.compact_line(full, "gpurun_out/bench_detail.json")
+    text = json.dumps(line)
+    assert len(text) < 4000 < bench.MAX_LINE <= 6000 and json.loads((" " * 9000 + text)[-8000:]) == line
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data"):
+        assert line[key] == full[key], key
+    assert line["config"]["workload"] == full["config"]["workload"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert line["roofline"][key] == full["roofline"][key], key
+    cb = line["cpu_baseline"]
+    assert set(cb) == {"value", "unit", "cores", "kind", "single_thread_value", "sample"} and len(cb["sample"]) <= 300
+    assert cb["cores"] == 14 and cb["kind"] == "port" and cb["value"] == pytest.approx(full["cpu_baseline"]["value"], rel=1e-6)
+    assert len(line["also_summary"]) == 18 and line["also_summary"]["workload_03"] == [pytest.approx(5.118e9, rel=1e-3),
+                                                                                        pytest.approx(0.234, abs=1e-3)]
+    assert line["detail"] == "gpurun_out/bench_detail.json" and "dropped_to_fit" not in line
+    # a record with 400 secondary workloads: the summary goes, the contract fields stay, the ceiling holds
+    full["also"] = [dict(full["also"][0], key=f"workload_{i:03d}") for i in range(400)]
+    line = bench.compact_line(full, None)
+    assert len(json.dumps(line)) <= bench.MAX_LINE and line["dropped_to_fit"][0] == "also_summary"
+    assert line["value"] == full["value"] and line["roofline"]["frac"] == full["roofline"]["frac"] and "cpu_baseline" in line
+    with pytest.raises(RuntimeError):
+        bench._fits({"x": "y" * bench.MAX_LINE})
+    # sig(): six significant digits, ints / None / strings untouched
+    assert bench.sig(1234567.891) == 1234570.0 and bench.sig(None) is None and bench.sig(7) == 7 and bench.sig("a") == "a"
+    assert bench.sig([0.123456789, {"a": 2.0000001}]) == [0.123457, {"a": 2.0}]
+
+
 def test_bench_eight_rank_control_flow():
     """The driver's 8-GPU launch, as far as a GPU-less container can take it: eight rank processes over gloo, the all-gather
     sees all eight shards, and BASELINE config 5 shows up as fields of its own (65536 envs = 8 x 8192: the strong and the
     weak point coincide at N = 8)."""
     p, line = _run_bench(["--gpus", "8", "--dry-run", "--steps", "20", "--warmup", "5"], timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
+    assert len(p.stdout) < 6000 and json.loads(p.stdout[-8000:]) == line   # what a consumer of the last 8 KB reads
     assert line["n_gpus"] == 8 and line["eval"]["envs"] == 8 * 4096 and line["eval"]["world_size"] == 8
     # VERDICT r4 #6: the metric all-gather has a number of its own, every rank's rate is reported (not only the slowest's),
     # and a scaling run measures the headline + the two c5 lines only

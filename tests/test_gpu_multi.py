@@ -60,19 +60,54 @@ def _bench(args, env_extra, timeout=900):
     return p, (json.loads(lines[-1]) if lines else None)
 
 
-def test_bench_two_ranks_share_one_gpu_through_the_launcher():
+def _tail_line(p, keep=8000):
+    """The line as a consumer that keeps only the last `keep` characters of stdout reads it (VERDICT r5 #1)."""
+    tail = p.stdout[-keep:]
+    start = tail.find('{"metric"')
+    assert start >= 0, f"no whole JSON line in the last {keep} characters of stdout ({len(p.stdout)} in all)"
+    return json.loads(tail[start:].splitlines()[0])
+
+
+def test_bench_two_ranks_share_one_gpu_through_the_launcher(tmp_path):
     p, line = _bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--min-gpu-s", "0.05"],
-                     {"BENCH_SHARE_GPU": "1"})
+                     {"BENCH_SHARE_GPU": "1", "BENCH_DETAIL_DIR": str(tmp_path)})
     assert p.returncode == 0, p.stderr[-3000:]
     assert line["n_gpus"] == 2 and line["steps"] == 20 and line["warmup"] == 5
     assert line["eval"]["envs"] == 2 * 4096 and line["eval"]["world_size"] == 2      # the all-gather saw both ranks
     assert line["value"] > 1e6 and abs(line["ms_per_step"] * line["value"] / 1e3 - 2 * 4096) < 1e-6 * 8192
     assert line["roofline"]["frac"] == pytest.approx(
         line["roofline"]["algorithmic_bytes_per_env_step"] * 4096 / (line["ms_per_step"] / 1e3) / 1e9 / 8000.0, rel=1e-9)
-    labels = [e["workload"] for e in line["also"]]
+    assert len(p.stdout) < 6000 and _tail_line(p) == line
+    # N > 1: the headline and the two c5 points only; each as a [value, fraction] pair in the line, in full in the detail file
+    assert set(line["also_summary"]) - {"_"} == {"c5w", "c5s"} and line["also_summary"]["c5s"][0] > 1e6
+    assert line["c5_strong_total"]["value"] == pytest.approx(line["also_summary"]["c5s"][0], rel=1e-3)
+    detail = json.load(open(line["detail"]))
+    labels = [e["workload"] for e in detail["also"]]
     assert any(lb.startswith("c5 weak") for lb in labels) and any(lb.startswith("c5 strong") for lb in labels)
-    strong = [e for e in line["also"] if e["workload"].startswith("c5 strong")][0]
+    strong = [e for e in detail["also"] if e["key"] == "c5s"][0]
     assert strong["value"] > 1e6 and strong["roofline"]["algorithmic_bytes_per_env_step"] == 366
+    assert detail["value"] == line["value"] and detail["roofline"]["frac"] == line["roofline"]["frac"]
+
+
+def test_bench_default_line_fits_a_tail_consumer(tmp_path):
+    """The driver's own command shape (every secondary workload on, no --no-also): stdout is ONE line of less than 6000
+    characters that parses from the last 8000 characters of stdout; the 17 secondary workloads are [value, fraction] pairs in
+    it and full entries in the detail file it names (r05: a 21.8 KB line, cut by its consumer, parsed = null)."""
+    p, line = _bench(["--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--min-gpu-s", "0.05"],
+                     {"BENCH_DETAIL_DIR": str(tmp_path)})
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert p.stdout.count("\n") == 1 and len(p.stdout) < 6000 and _tail_line(p) == line
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in line, key
+    assert "dropped_to_fit" not in line
+    summ = {k: v for k, v in line["also_summary"].items() if k != "_"}
+    assert {"c3", "c4", "c5w", "c5s", "fe3_2^18", "fe5_2^18"} <= set(summ) and len(summ) == 17
+    assert all(v[0] > 1e6 for v in summ.values())
+    detail = json.load(open(line["detail"]))
+    assert [e["key"] for e in detail["also"]] == list(summ)
+    c3 = next(e for e in detail["also"] if e["key"] == "c3")
+    assert c3["roofline"]["frac"] == pytest.approx(summ["c3"][1], rel=2e-3) and c3["roofline"]["kernel"] == "k_rollout_od<5>"
 
 
 def test_bench_single_gpu_line_is_single_clocked():
