@@ -1,0 +1,644 @@
+// cooperative-search_amd/csrc/rollout_lane.h -- k_rollout_lane: the lane-per-env rollout kernel, first generation (teams of 6 to 8 from 2^20 envs; kernel="lane").
+// Included by coopsearch.hip inside its anonymous namespace, after the 16-lane group code.  Not a translation unit of its own.
+
+// =========================================================================================================
+// Lane-per-env path (flight_easy): one environment per LANE, 64 per wavefront.
+//
+// The 16-lane-group kernels above minimise the latency of one step when the batch is small (every SIMD gets a
+// wave even at B = 4096) but replicate the kinematics 16 times.  For larger batches this path does each env's
+// arithmetic exactly once and is built to keep TWO wavefronts per SIMD resident (<= 256 VGPRs, 2 x 4 staging
+// tiles in LDS) so that one wavefront's memory waits hide behind the other's arithmetic:
+//   * the agents live in the lane's registers; the targets do NOT: their normalised fp32 coordinates sit in the
+//     lane's row of the staging tile anyway (get_state emits them every step), and the n*m sensor tests are
+//     decided from those in fp32 whenever the fp32 distance is clear of the threshold by more than its error
+//     bound -- the few pairs that are not (~2e-6 of them) re-read the fp64 target and run the reference's exact
+//     comparison, so the outcome is the exact one in every case;
+//   * MT19937: the state is regenerated AHEAD of consumption, 192 words of one env at a time by the whole
+//     wavefront (three coalesced 256-byte loads and one store per 64 words instead of per-lane gathers),
+//     `cs_layout.ahead_off` counting the words that are twisted but not yet consumed; a draw is then two loaded
+//     words and a temper, and the 32 words a step may need are requested at the top of the step;
+//   * the in-range pairs form a per-lane bitmask consumed in agent-major order (bit 16*i + j), get_state rows
+//     leave through the per-wave LDS tile as one contiguous block;
+//   * resets (data-dependent length) are done wave-cooperatively, four envs at a time, by the four 16-lane groups
+//     of the wavefront running the group code above.
+// Results are bit-identical to the group kernels (same per-env arithmetic, same MT19937 word order);
+// tests/test_gpu_parity.py runs both.
+// =========================================================================================================
+#ifndef CS_LANE_REFRESH_MAX_N
+#define CS_LANE_REFRESH_MAX_N 5   /* measured at B = 262144: 4 agents 29.9 -> 34-38 %, 5 agents 23.5 -> 28 % */
+#endif
+#ifndef CS_LANE_FROM_LARGE_TEAMS
+#define CS_LANE_FROM_LARGE_TEAMS 1048576   /* ... for teams of 5 and more agents (lane_from) */
+#endif
+#ifndef CS_LANE_FROM
+#define CS_LANE_FROM 131072     /* default kernel of cs_rollout from this many envs: one env per lane (65536: octet 7.6e9
+                                   against lane 7.1e9 env-steps/s at 3 agents, 5.0e9 against 4.8e9 at 5; 262144: 8.0 / 10.4) */
+#endif
+#ifndef CS_LANEV_DEFAULT
+#define CS_LANEV_DEFAULT 1      /* the lane-per-env kernel of teams of up to 5 is k_rollout_lanev (rollout_lanev.h) */
+#endif
+#ifndef CS_ODE_UPTO
+#define CS_ODE_UPTO 8192        /* ... up to this many envs with the third (emitting) wavefront: four 3-wavefront workgroups per CU (32 KB of LDS each since E refreshes the rows: 10240 envs would need a fifth and run 3.7e9 against the pair variant's 5.0e9) x 256 CUs x 8 envs */
+#endif
+#ifndef CS_OD_UPTO
+#define CS_OD_UPTO 16384        /* cs_rollout up to this many envs: the octet pair kernel */
+#endif
+#ifndef CS_OCT_FROM
+#define CS_OCT_FROM 16384       /* cs_rollout above this many envs (and below CS_LANE_FROM): one env per 8 lanes, one wavefront */
+#endif
+constexpr int LANE_REFILL = 192;   // words twisted per refill (<= 227: independent of each other)
+constexpr int LANE_REFILL_MAX = 192;
+#ifndef CS_LANE_CHUNK
+#define CS_LANE_CHUNK 64
+#endif
+constexpr int LANE_CHUNK = CS_LANE_CHUNK;     // steps per launch of the lane kernel: cs_rollout twists every row ahead in between
+
+template <int N>
+struct EnvL {
+    double ax[N], ay[N], yaw[N], cs[N], sn[N];
+    unsigned found, newly, newly_reset;
+    int target_find, flags, time_step, total_reward, mt_pos, episodes, curr_reward, ahead;
+    unsigned long long words;
+};
+
+template <int N>
+__device__ __forceinline__ void envl_zero(EnvL<N> &e) {
+#pragma unroll
+    for (int i = 0; i < N; i++) e.ax[i] = e.ay[i] = e.yaw[i] = e.cs[i] = e.sn[i] = 0.0;
+    e.found = e.newly = e.newly_reset = 0u;
+    e.target_find = e.flags = e.time_step = e.total_reward = e.mt_pos = e.episodes = e.curr_reward = 0;
+    e.ahead = 1 << 20;  // a lane without an env never asks for a refill
+    e.words = 0ull;
+}
+
+// hdr / agents of env b into the lane's registers, its targets (normalised, fp32) into the lane's tile row
+template <int N>
+__device__ __forceinline__ void envl_load(const DevParams &p, int b, const double *T, float *row, EnvL<N> &e) {
+    const int4 *h4 = reinterpret_cast<const int4 *>(p.hdr + (size_t)b * CS_H_WORDS);
+    int4 h0 = h4[0], h1 = h4[1], h2 = h4[2];
+    e.found = (unsigned)h0.x;
+    e.newly = (unsigned)h0.y;
+    e.target_find = h0.z;
+    e.flags = h0.w;
+    e.time_step = h1.x;
+    e.total_reward = h1.y;
+    e.mt_pos = h1.z;
+    e.episodes = h1.w;
+    e.words = (unsigned long long)(unsigned)h2.x | ((unsigned long long)(unsigned)h2.y << 32);
+    e.curr_reward = h2.z;
+    e.newly_reset = (unsigned)h2.w;
+    e.ahead = p.ahead[b];
+    const double4 *a4 = reinterpret_cast<const double4 *>(p.agent + (size_t)b * CS_MAX_AGENTS * 4);
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        double4 a = a4[i];
+        e.ax[i] = a.x;
+        e.ay[i] = a.y;
+        e.yaw[i] = a.z;
+    }
+    const double2 *t2 = reinterpret_cast<const double2 *>(p.tgt + (size_t)b * G * 2);
+#pragma unroll
+    for (int j = 0; j < CS_MAX_TARGETS; j++) {
+        if (j < p.n_targets) {
+            const double2 tt = t2[j];
+            row[4 * N + 3 * j + 0] = (float)((tt.x - p.mid) * p.inv_half);   // what get_state emits (norm_target)
+            row[4 * N + 3 * j + 1] = (float)((tt.y - p.mid) * p.inv_half);
+            row[4 * N + 3 * j + 2] = ((e.found >> j) & 1u) ? 1.0f : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) trig_heading(T, e.yaw[i], e.sn[i], e.cs[i]);
+}
+
+template <int N>
+__device__ __forceinline__ void envl_store(const DevParams &p, int b, const EnvL<N> &e) {
+    int4 *h4 = reinterpret_cast<int4 *>(p.hdr + (size_t)b * CS_H_WORDS);
+    h4[0] = make_int4((int)e.found, (int)e.newly, e.target_find, e.flags);
+    h4[1] = make_int4(e.time_step, e.total_reward, e.mt_pos, e.episodes);
+    h4[2] = make_int4((int)(unsigned)(e.words & 0xffffffffull), (int)(unsigned)(e.words >> 32), e.curr_reward,
+                      (int)e.newly_reset);
+    p.ahead[b] = e.ahead;
+    double4 *a4 = reinterpret_cast<double4 *>(p.agent + (size_t)b * CS_MAX_AGENTS * 4);
+#pragma unroll
+    for (int i = 0; i < N; i++) a4[i] = make_double4(e.ax[i], e.ay[i], e.yaw[i], 0.0);
+}
+
+// Kinematics of one lane's env: same contract as kinematics<> above, organised for 64 DIFFERENT envs per
+// wavefront.  The repulsion of agent i (flight_env_easy.py:293-301) is a loop over the neighbours that ARE within
+// force_dist, in ascending j like the reference's, instead of n-1 predicated copies of the two fp64 divisions:
+// with 64 envs per wavefront some lane has a close pair almost every step, so every predicated copy would run.
+template <int N>
+__device__ __forceinline__ void kinematics_lane(const DevParams &p, const double *T, const int (&act)[N], EnvL<N> &e) {
+    const double PI = 3.141592653589793, TWO_PI = 2.0 * 3.141592653589793, THREE_PI = 3.0 * 3.141592653589793;
+    const double DYAW = 3.141592653589793 / 18.0;
+    double yw[N], s1[N], c1[N], yr[N], s2[N], c2[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        double yaw = e.yaw[i];
+        yaw = act[i] == 1 ? yaw + DYAW : (act[i] == 2 ? yaw + -DYAW : yaw);  // dyaw = [0, pi/18, -pi/18][act]
+        yaw = yaw > TWO_PI ? yaw - TWO_PI : (yaw < 0.0 ? yaw + TWO_PI : yaw);
+        yw[i] = yaw;
+        yr[i] = (yaw <= PI) ? PI - yaw : THREE_PI - yaw;
+        // (evaluating the 2n headings branch-free in one basic block so that their chains interleave was
+        // measured: 39.1 -> 39.1 % at 2^18 envs, 41.7 -> 42.2 % at 2^20, for 32 more VGPRs: not kept here)
+        trig_heading(T, yaw, s1[i], c1[i]);
+        trig_heading(T, yr[i], s2[i], c2[i]);
+    }
+    unsigned out = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const double x0 = e.ax[i], y0 = e.ay[i];
+        unsigned pend = 0;
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            if (j == i) continue;
+            const double xa = e.ax[j], ya = e.ay[j];  // already moved if j < i (quirk Q7)
+            const double d2 = (xa - x0) * (xa - x0) + (ya - y0) * (ya - y0);
+            pend |= (d2 < p.force_d2 && (xa != x0 || ya != y0)) ? (1u << j) : 0u;
+        }
+        double fx = 0.0, fy = 0.0;
+        while (pend) {
+            const int j = __ffs((int)pend) - 1;
+            pend &= pend - 1;
+            double xa = 0.0, ya = 0.0;
+#pragma unroll
+            for (int q = 0; q < N; q++) {
+                xa = q == j ? e.ax[q] : xa;
+                ya = q == j ? e.ay[q] : ya;
+            }
+            const double den = (x0 - xa) * (x0 - xa) + (y0 - ya) * (y0 - ya);
+            fx += p.force_k * (x0 - xa) / den;
+            fy += p.force_k * (y0 - ya) / den;
+        }
+        const double x = (x0 + p.velocity * c1[i]) + fx;
+        const double y = (y0 + p.velocity * s1[i]) + fy;
+        const bool hit = (x < 0.0) | (x > p.L) | (y < 0.0) | (y > p.L);    // flight_env_easy.py:278
+        e.ax[i] = hit ? fmin(fmax(x, 0.0), p.L) : x;
+        e.ay[i] = hit ? fmin(fmax(y, 0.0), p.L) : y;
+        e.yaw[i] = hit ? yr[i] : yw[i];
+        e.cs[i] = hit ? c2[i] : c1[i];
+        e.sn[i] = hit ? s2[i] : s1[i];
+        out |= hit ? (1u << i) : 0u;
+    }
+    e.flags = (e.flags & ~0xff00) | (int)(out << 8);
+}
+
+// Fallback of the lane kernel (rare once cs_rollout's pre-pass has run): for every lane whose bit is set in `need`,
+// the whole wavefront twists LANE_REFILL more words of that lane's env (when there is room) and rebuilds the env's hit
+// tape from its cursor -- in the state blob and, through the ballots, in the lane's registers.
+template <int N>
+__device__ __forceinline__ void lane_rebuild(const DevParams &p, int b0, int lane, unsigned long long need, EnvL<N> &e,
+                                             unsigned (&tape)[TAPE_DW]) {
+    while (need) {
+        const int src = __ffsll((long long)need) - 1;
+        need &= need - 1;
+        const int pos = __shfl(e.mt_pos, src);
+        int a = __shfl(e.ahead, src);
+        const unsigned wlo = (unsigned)__shfl((int)(unsigned)(e.words & 0xffffffffull), src);
+        const unsigned whi = (unsigned)__shfl((int)(unsigned)(e.words >> 32), src);
+        unsigned *m = p.mt + (size_t)(b0 + src) * MT_STRIDE;
+        if (a <= MT_N - LANE_REFILL) {   // wave-uniform
+            const int g = wrap624(pos + a);
+            unsigned nw[3];
+            int idx[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {   // word j needs stored words j, j+1, j+397: none written by this batch (192 <= 227)
+                const int j = wrap624(g + 64 * c + lane);
+                idx[c] = j;
+                nw[c] = mt_mix(m[j], m[wrap624(j + 1)], m[wrap624(j + MT_M)]);
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) mt_store(m, idx[c], nw[c]);
+            a += LANE_REFILL;
+        }
+        unsigned *tp = p.tape + (size_t)(b0 + src) * TAPE_STRIDE;
+#pragma unroll
+        for (int it = 0; it < TAPE_DW / 2; it++) {
+            const int r = 64 * it + lane;   // draw slot from the cursor: words pos + 2r, pos + 2r + 1 (pos is even)
+            bool hit = false;
+            if (2 * r < a) {
+                const U2 w = *reinterpret_cast<const U2 *>(m + wrap624(pos + 2 * r));
+                hit = draw_hits(p, w.x, w.y);
+            }
+            const unsigned long long bm = __ballot(hit);
+            if (lane == src) {
+                tape[2 * it] = (unsigned)(bm & 0xffffffffull);
+                tape[2 * it + 1] = (unsigned)(bm >> 32);
+            }
+            if (lane == 0) *reinterpret_cast<U2 *>(tp + 2 * it) = U2{(unsigned)(bm & 0xffffffffull), (unsigned)(bm >> 32)};
+        }
+        if (lane == 0) {
+            *reinterpret_cast<U2 *>(tp + 10) = U2{wlo, whi};
+            *reinterpret_cast<U2 *>(tp + 12) = U2{(unsigned)(p.detect_K & 0xffffffffull), (unsigned)(p.detect_K >> 32)};
+        }
+        if (lane == src) e.ahead = a;
+    }
+    drain_vmem();   // rare path: joins the steady-state path with nothing of its own in flight
+}
+
+// In-loop refresh of the lane kernel (teams of up to 3): instead of a separate pre-pass over every row, each wavefront
+// tops up ONE of its 64 envs per step -- the one running lowest on twisted words: the env's row is requested at the end
+// of a step (ten coalesced dwords per lane, held in registers), and after the next step's kinematics the wavefront
+// copies it to LDS, twists everything that is not yet twisted (row_twist_ahead: new words go to the state blob) and
+// rebuilds the env's hit tape straight into its lane's registers (ballots).  Each env comes round about every 64 steps,
+// having consumed ~400 words: the MT19937 traffic (2.5 KB read + ~1.6 KB written per refresh) is spread under the
+// arithmetic of the whole rollout, and no lane waits for words.
+template <int N>
+__device__ __forceinline__ void lane_advance_finish(const DevParams &p, int b0, int lane, int src, const RowRegs &rr,
+                                                    unsigned *rowbuf, EnvL<N> &e, unsigned (&tape)[TAPE_DW]) {
+    row_to_lds(rr, rowbuf, lane);
+    const int pos = __shfl(e.mt_pos, src);
+    const int a = __shfl(e.ahead, src);
+    row_twist_ahead(rowbuf, p.mt + (size_t)(b0 + src) * MT_STRIDE, pos, a < 0 ? 0 : a, lane);
+#pragma unroll
+    for (int it = 0; it < TAPE_DW / 2; it++) {
+        const unsigned long long bm = row_slot_hits(p, rowbuf, pos, it, lane);
+        if (lane == src) {
+            tape[2 * it] = (unsigned)(bm & 0xffffffffull);
+            tape[2 * it + 1] = (unsigned)(bm >> 32);
+        }
+    }
+    if (lane == src) e.ahead = MT_N;
+}
+
+// the same, start to finish, for every lane in `need` (kernel entry, or a lane that could not wait for its turn)
+template <int N>
+__device__ __forceinline__ void lane_advance_now(const DevParams &p, int b0, int lane, unsigned long long need, unsigned *rowbuf,
+                                                 EnvL<N> &e, unsigned (&tape)[TAPE_DW]) {
+    while (need) {
+        const int src = __ffsll((long long)need) - 1;
+        need &= need - 1;
+        RowRegs rr;
+        row_load(p.mt + (size_t)(b0 + src) * MT_STRIDE, lane, rr);
+        lane_advance_finish<N>(p, b0, lane, src, rr, rowbuf, e, tape);
+    }
+    drain_vmem();   // rare path: joins the steady-state path with nothing of its own in flight
+}
+
+// Ordering inside one step (gfx9 has ONE in-order counter for vector loads and stores: waiting for a load also waits
+// for every store issued before it): the only loads of the steady-state loop -- the next step's actions -- are requested
+// before the step's output stores, and the number of stores between any load and its use is a compile-time constant, so
+// no wait of the loop ever needs a store to have been acknowledged by the memory system.  Rare paths (reset, tape
+// rebuild) end with nothing of their own in flight.
+//
+// VEC (every wavefront of the launch is full and every step's block of rows is 16-byte aligned; the host splits a batch
+// into a VEC launch and, for the last < 64 envs or an unaligned tensor, a plain one): the 64 get_state rows of step s
+// leave the tile as float4 chunks DURING step s + 1 -- a third after the kinematics, a third after the sensor tests, a
+// third after the draws -- so the write stream of a wavefront is spread over its arithmetic instead of arriving as
+// one burst per step.
+template <int N, bool VEC>
+__global__ __launch_bounds__(BLOCK, 2) void k_rollout_lane(DevParams p, StepIO io) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *T = reinterpret_cast<double *>(smem);                                   // trig table (2072 B)
+    const int W = 4 * N + 3 * p.n_targets;
+    float *tiles = reinterpret_cast<float *>(smem + ((TRIG_ROWS * TRIG_COLS * 8 + 15) / 16) * 16);
+    int lane = threadIdx.x & 63;   // (made opaque once per step, see the loop)
+    const int wave = threadIdx.x >> 6;
+    float *tile = tiles + (size_t)wave * 64 * W;
+    float *row = tile + (size_t)lane * W;   // W is odd for m = 15: conflict-free column accesses
+    const int b = io.env0 + blockIdx.x * BLOCK + threadIdx.x;
+    const int b0 = b - lane;  // first env of this wavefront
+    const int b_end = io.env0 + io.env_n;
+    const bool live = b < b_end;
+    __shared__ double rtab[4 * G];   // the reset's target tables (load_reset_tab)
+    if (wave == 0) load_reset_tab(rtab, lane);
+    load_trig_to_lds(T);
+    if (b0 >= b_end) return;  // whole wavefront out of range
+    const int t16 = lane & (G - 1), gshift = lane & ~(G - 1), grp = lane >> 4;
+    const unsigned tmask = p.n_targets >= 16 ? 0xffffu : ((1u << p.n_targets) - 1u);
+    constexpr int LOW = 2 * N * CS_MAX_TARGETS;   // words one step can consume: every lane enters a step with that many twisted
+    constexpr bool REFRESH = N <= CS_LANE_REFRESH_MAX_N;   // in-loop refresh (above); larger teams rely on cs_rollout's pre-pass
+    unsigned *rowbuf = reinterpret_cast<unsigned *>(tiles + (size_t)(BLOCK / 64) * 64 * W) + wave * MT_N;
+    RowRegs rr;
+    int cand = -1;                                // env (lane) whose row is in flight in `rr`
+    EnvL<N> e;
+    int act[N];
+    unsigned tape[TAPE_DW];
+    const size_t arow = live ? (size_t)b : 0;
+    bool tape_ok = true;
+    if (live) {
+        envl_load<N>(p, b, T, row, e);
+        tape_ok = tape_load(p, b, e, tape);
+    } else {
+        envl_zero<N>(e);
+#pragma unroll
+        for (int k = 0; k < TAPE_DW; k++) tape[k] = 0u;
+    }
+    if (REFRESH) {   // (an advance also rebuilds a tape that does not match the cursor or the detection threshold)
+        const unsigned long long low = __ballot(live && (!tape_ok || e.ahead < LOW));
+        if (low) lane_advance_now<N>(p, b0, lane, low, rowbuf, e, tape);
+    } else {
+        while (const unsigned long long low = __ballot(live && (!tape_ok || e.ahead < LOW))) {
+            lane_rebuild<N>(p, b0, lane, low, e, tape);
+            tape_ok = true;
+        }
+    }
+    load_actions<N>(io, arow, act);
+    const int rows_valid = b_end - b0 < 64 ? b_end - b0 : 64;
+    constexpr int W_MAX = 4 * N + 3 * CS_MAX_TARGETS;
+    constexpr int Q = (16 * W_MAX + 63) / 64;   // float4 chunks per lane of the largest tile
+    // float4 chunks [q0, q1) of the tile -> rows of step `step`.  Chunk k = min(lane + 64 q, last): surplus lanes repeat
+    // the last chunk (same value, same address), so every lane stores every time.
+    auto copy_chunks = [&](int q0, int q1, size_t step) __attribute__((always_inline)) {
+        const float4 *src4 = reinterpret_cast<const float4 *>(tile);
+        float4 *dst4 = reinterpret_cast<float4 *>(io.state + (step * p.B + b0) * W);
+        const int last = 16 * W - 1;
+        int l0 = lane;
+        asm volatile("" : "+v"(l0));   // the address pairs are recomputed at every use (hoisted out of the loop they spill)
+#pragma unroll
+        for (int q = q0; q < q1; q++) {
+            const int k = l0 + 64 * q < last ? l0 + 64 * q : last;
+            const float4 v = src4[k];
+            const v4f nv = {v.x, v.y, v.z, v.w};   // write-once stream: non-temporal (+6 % on the whole kernel)
+            __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(dst4 + k));
+        }
+    };
+    bool flushed = true;   // VEC: the tile holds no step that still has to be written out
+    for (int s = 0; s < io.T; s++) {
+        asm volatile("" : "+v"(lane));   // lane predicates are recomputed per step instead of being held (and spilled) as SGPR pairs
+        const size_t slot = (size_t)s * p.B + arow;
+        LANE_STAMP(0);
+        REAL_STAMP(8);
+        bool done = live && (e.target_find >= p.n_targets || e.time_step >= p.time_limit);
+        // ---- auto-reset: the four 16-lane groups of the wavefront each take one resetting env per round.  The env's
+        //      cursor goes to its group by shuffle, the new targets come back through the lane's tile row (fp64 copies
+        //      go to the state blob without anybody waiting for them), the counters by shuffle: the only memory round
+        //      trip of a reset is the MT19937 words of its polar-gaussian attempts.
+        const unsigned long long need = __ballot(done && (io.flags & CS_AUTO_RESET));
+        if (need) {
+            if (VEC && !flushed) copy_chunks(0, Q, (size_t)(s - 1));   // the resets rewrite rows of the tile
+            flushed = true;
+            if (REFRESH && cand >= 0 && ((need >> cand) & 1ull)) cand = -1;   // its cursor moves: the row in flight is void
+            const bool mine = (need >> lane) & 1ull;
+            const int my_rank = __popcll(need & ((1ull << lane) - 1ull));
+            unsigned long long pend = need;
+            for (int round = 0; pend; round++) {
+                unsigned long long m = pend;
+                for (int q = 0; q < grp; q++) m &= m ? m - 1 : 0ull;   // this group's env: the grp-th pending one
+                const int src = m ? __ffsll((long long)m) - 1 : -1;
+                for (int q = 0; q < 4; q++) pend &= pend ? pend - 1 : 0ull;
+                const int sl = src >= 0 ? src : lane;
+                Env<N> g;
+                g.mt_pos = __shfl(e.mt_pos, sl);
+                g.ahead = __shfl(e.ahead, sl);
+                g.episodes = __shfl(e.episodes, sl);
+                g.words = (unsigned long long)(unsigned)__shfl((int)(unsigned)(e.words & 0xffffffffull), sl) |
+                          ((unsigned long long)(unsigned)__shfl((int)(unsigned)(e.words >> 32), sl) << 32);
+                g.newly_reset = 0u;
+                g.curr_reward = 0;
+                g.tx = g.ty = 0.0;
+                if (src >= 0) {
+                    const int br = b0 + src;
+                    const DevParams &cp = cold_params();
+                    // (with 64 envs per wavefront there is a reset in nearly every step: through env_reset alone they cost 16 %
+                    // of the kernel at 2^18 envs; env_reset_fast: the lean path for the usual case)
+                    env_reset_fast<N, false>(cp, T, rtab, br, t16, gshift, g);
+                    reinterpret_cast<double2 *>(cp.tgt + (size_t)br * G * 2)[t16] = make_double2(g.tx, g.ty);
+                    if (t16 < p.n_targets) {
+                        float *rs = tile + (size_t)src * W + 4 * N + 3 * t16;
+                        rs[0] = g.ntx;
+                        rs[1] = g.nty;
+                        rs[2] = ((g.found >> t16) & 1u) ? 1.0f : 0.0f;
+                    }
+                }
+                // the q-th pending env of this round was reset by group q: its (group-uniform) counters come back
+                const int q = my_rank - 4 * round;
+                const bool got = mine && q >= 0 && q < 4;
+                const int leader = got ? 16 * q : lane;
+                const int r_pos = __shfl(g.mt_pos, leader), r_ahead = __shfl(g.ahead, leader);
+                const int r_epi = __shfl(g.episodes, leader), r_tf = __shfl(g.target_find, leader);
+                const int r_flags = __shfl(g.flags, leader), r_cr = __shfl(g.curr_reward, leader);
+                const int r_found = __shfl((int)g.found, leader), r_newly = __shfl((int)g.newly, leader);
+                const int r_wlo = __shfl((int)(unsigned)(g.words & 0xffffffffull), leader);
+                const int r_whi = __shfl((int)(unsigned)(g.words >> 32), leader);
+                if (got) {
+                    const unsigned long long w_new = (unsigned long long)(unsigned)r_wlo | ((unsigned long long)(unsigned)r_whi << 32);
+                    // the reset consumed (w_new - words) stream words, twisted ones first: their draw slots leave the tape
+                    const unsigned long long used = w_new - e.words;
+                    tape_shift<8>(tape, used < 2ull * 319ull ? (int)(used >> 1) : 319);
+                    e.mt_pos = r_pos;
+                    e.ahead = r_ahead;
+                    e.episodes = r_epi;
+                    e.target_find = r_tf;
+                    e.flags = r_flags;
+                    e.curr_reward = r_cr;
+                    e.found = (unsigned)r_found;
+                    e.newly = (unsigned)r_newly;
+                    e.words = w_new;
+                    e.time_step = 0;
+                    e.total_reward = 0;
+                    {   // start poses: the host's table; every agent starts with the same heading: one evaluation
+                        const StartTab<N> st = start_tab<N>();
+                        double s0, c0;
+                        trig_heading(T, st.yaw, s0, c0);
+#pragma unroll
+                        for (int i = 0; i < N; i++) {
+                            e.ax[i] = st.x[i];
+                            e.ay[i] = st.y[i];
+                            e.yaw[i] = st.yaw;
+                            e.sn[i] = s0;
+                            e.cs[i] = c0;
+                        }
+                    }
+                    done = false;
+                }
+            }
+            // a reset that ran past the twisted words leaves its lane without a tape for this step: rebuild
+            if (REFRESH) {
+                const unsigned long long low = __ballot(e.ahead < LOW);
+                if (low) {
+                    if (cand >= 0 && ((low >> cand) & 1ull)) cand = -1;
+                    lane_advance_now<N>(p, b0, lane, low, rowbuf, e, tape);
+                }
+            } else {
+                while (const unsigned long long low = __ballot(e.ahead < LOW)) lane_rebuild<N>(p, b0, lane, low, e, tape);
+            }
+            drain_vmem();
+        }
+        // rows still to be written out: step s - 1's; after a flush (or at s = 0) the same chunks go to step s's own
+        // slot instead, which this wavefront overwrites with the real rows one step later
+        const size_t cstep = (size_t)(flushed ? s : s - 1);
+        LANE_STAMP(1);
+        int reward = 0;
+        bool term = true;
+        const bool stepping = live && !(done && (io.flags & CS_FREEZE_DONE));
+        e.flags &= ~(FLAG_DIRTY | FLAG_RESET_PASS);
+        if (stepping) kinematics_lane<N>(p, T, act, e);
+        if (VEC) copy_chunks(0, Q / 3, cstep);
+        if (REFRESH && cand >= 0) {   // wave-uniform: the row requested a step ago has long arrived
+            lane_advance_finish<N>(p, b0, lane, cand, rr, rowbuf, e, tape);
+            cand = -1;
+        }
+        LANE_STAMP(2);
+        float4 f[N];
+#pragma unroll
+        for (int i = 0; i < N; i++)
+            f[i] = make_float4((float)((e.ax[i] - p.mid) * p.inv_half), (float)((e.ay[i] - p.mid) * p.inv_half),
+                               (float)e.cs[i], (float)e.sn[i]);
+        // ---- sensor tests (flight_env_easy.py:237): fp32 pre-filter on the normalised coordinates, exact fp64
+        //      comparison for the pairs it cannot decide; bit 16*i + j = (agent i, target j) in range
+        unsigned long long lo = 0, hi = 0;  // agents 0..3 / 4..7
+        if (stepping) {
+            float ntx[CS_MAX_TARGETS], nty[CS_MAX_TARGETS];
+#pragma unroll
+            for (int j = 0; j < CS_MAX_TARGETS; j++) {
+                ntx[j] = j < p.n_targets ? row[4 * N + 3 * j + 0] : 0.0f;
+                nty[j] = j < p.n_targets ? row[4 * N + 3 * j + 1] : 0.0f;
+            }
+            const float thr_lo = p.thr32 - p.eps32, thr_hi = p.thr32 + p.eps32;
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                // sign bits of d2 - thr_lo / d2 - thr_hi, target 15 first, funnel-shifted into the masks (one
+                // v_alignbit each): bit j of `sure` = (d2 < thr - eps), of `maybe` = (d2 < thr + eps)
+                unsigned sure = 0, maybe = 0;
+#pragma unroll
+                for (int j = CS_MAX_TARGETS - 1; j >= 0; j--) {
+                    const float dx = ntx[j] - f[i].x, dy = nty[j] - f[i].y;
+                    const float d2 = __builtin_fmaf(dx, dx, dy * dy);
+                    sure = __builtin_amdgcn_alignbit(sure, __float_as_uint(d2 - thr_lo), 31);
+                    maybe = __builtin_amdgcn_alignbit(maybe, __float_as_uint(d2 - thr_hi), 31);
+                }
+                unsigned m = sure & tmask;
+                unsigned fz = maybe & ~sure & tmask;
+                while (fz) {  // (t_x-x)**2 + (t_y-y)**2 <= view_range**2 on the fp64 values
+                    const int j = __ffs((int)fz) - 1;
+                    fz &= fz - 1;
+                    const double2 tt = reinterpret_cast<const double2 *>(p.tgt + (size_t)b * G * 2)[j];
+                    const double ddx = tt.x - e.ax[i], ddy = tt.y - e.ay[i];
+                    m |= (ddx * ddx + ddy * ddy <= p.view_r2 ? 1u : 0u) << j;
+                }
+                if (i < 4) lo |= (unsigned long long)m << (16 * i);
+                else hi |= (unsigned long long)m << (16 * (i - 4));
+            }
+        }
+        if (VEC) copy_chunks(Q / 3, 2 * Q / 3, cstep);
+        LANE_STAMP(3);
+        // ---- one np.random.rand() per in-range pair, found or not (quirk Q4), in agent-major order: the r-th set bit
+        //      of (lo, hi) takes draw slot r of the tape
+        const int total = __popcll(lo) + (N > 4 ? __popcll(hi) : 0);
+        unsigned hitmask = 0;
+        {
+            unsigned w16 = tape[0];
+            for (int r0 = 0; __ballot(r0 < total); r0 += 16) {
+                const int take = total - r0;   // <= 0: nothing left for this lane
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    if (k < take) {
+                        int bit;
+                        if (N <= 4 || lo) {
+                            bit = __ffsll((long long)lo) - 1;
+                            lo &= lo - 1;
+                        } else {
+                            bit = __ffsll((long long)hi) - 1;
+                            hi &= hi - 1;
+                        }
+                        hitmask |= ((w16 >> k) & 1u) << (bit & 15);
+                    }
+                }
+                // slots r0 + 16 ..: (r0 is wave-uniform, so the tape dword is picked with uniform selects)
+                const int nx = r0 + 16;
+                unsigned nxt = 0;
+#pragma unroll
+                for (int d = 0; d < (N * CS_MAX_TARGETS + 31) / 32; d++) nxt = (nx >> 5) == d ? tape[d] : nxt;
+                w16 = nxt >> (nx & 31);
+            }
+            e.mt_pos = wrap624(e.mt_pos + 2 * total);
+            e.words += (unsigned long long)(2 * total);
+            e.ahead -= 2 * total;
+            tape_shift<(N * CS_MAX_TARGETS) / 32 < 1 ? 1 : (N * CS_MAX_TARGETS) / 32>(tape, total);
+        }
+        if (VEC) copy_chunks(2 * Q / 3, Q, cstep);
+        LANE_STAMP(4);
+        if (stepping) {
+            const unsigned newly = hitmask & ~e.found;
+            const int cnt = __popc(newly);
+            int r = -1;     // MOVE_COST
+            r += 10 * cnt;  // FIND_ONE_TGT
+            e.found |= newly;
+            e.newly = newly;
+            e.target_find += cnt;
+            if (cnt > 0 && e.target_find == p.n_targets && !(e.flags & FLAG_WIN)) {
+                r += 100;  // FIND_ALL_TGT
+                e.flags |= FLAG_WIN;
+            }
+            r -= __popc(((unsigned)e.flags >> 8) & 0xffu);  // OUT_PUNISH
+            e.curr_reward = r;
+            e.flags |= FLAG_DIRTY;
+            reward = r;
+            e.total_reward += reward;
+            e.time_step += 1;
+            term = e.target_find >= p.n_targets || e.time_step >= p.time_limit;
+            if (newly) {
+#pragma unroll
+                for (int j = 0; j < CS_MAX_TARGETS; j++)
+                    if ((newly >> j) & 1u) row[4 * N + 3 * j + 2] = 1.0f;
+            }
+        }
+        if (live && (io.state || io.obs)) {
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                row[4 * i + 0] = f[i].x;
+                row[4 * i + 1] = f[i].y;
+                row[4 * i + 2] = f[i].z;
+                row[4 * i + 3] = f[i].w;
+            }
+        }
+        LANE_STAMP(5);
+        // ---- what the next step waits for, requested BEFORE this step's stores: the row of the env to refresh next (or,
+        //      rarely, an immediate advance / tape rebuild), the next actions
+        if (REFRESH) {
+            const unsigned long long low = __ballot(e.ahead < LOW);
+            if (low) lane_advance_now<N>(p, b0, lane, low, rowbuf, e, tape);
+            const unsigned long long urgent = __ballot(e.ahead < 192), normal = __ballot(e.ahead < 352);
+            cand = urgent ? __ffsll((long long)urgent) - 1 : (normal ? __ffsll((long long)normal) - 1 : -1);
+            if (cand >= 0) row_load(p.mt + (size_t)(b0 + cand) * MT_STRIDE, lane, rr);
+        } else {
+            while (const unsigned long long low = __ballot(e.ahead < LOW)) lane_rebuild<N>(p, b0, lane, low, e, tape);
+        }
+        load_actions<N>(io, (size_t)(s + 1 < io.T ? s + 1 : s) * p.B + arow, act);
+        LANE_STAMP(6);
+        // ---- this step's outputs
+        if (live) {
+            io.reward[slot] = (float)reward;
+            io.terminated[slot] = term ? 1 : 0;
+            io.win[slot] = (e.flags & FLAG_WIN) ? 1 : 0;
+        }
+        if (io.obs) {
+            // get_obs: the wavefront's 64 N float4 are one contiguous block of the table; stored from the lanes that own the envs
+            // they would be N stores of 64 pieces at a stride of 16 N bytes each (partial sectors, which non-temporal stores do not
+            // let the L2 merge).  The agents' floats are in the tile already (the get_state rows): chunk k = (env k / N, agent k % N)
+            // is gathered from there and the block leaves as N coalesced 1 KB stores.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            v4f *o = reinterpret_cast<v4f *>(io.obs) + ((size_t)s * p.B + b0) * N;
+            v4f ov[N];
+#pragma unroll
+            for (int q = 0; q < N; q++) {
+                const int k = lane + 64 * q, r = k / N, i = k - r * N;
+                const float *src = tile + (size_t)r * W + 4 * i;
+                ov[q] = v4f{src[0], src[1], src[2], src[3]};
+            }
+#pragma unroll
+            for (int q = 0; q < N; q++)
+                if (lane + 64 * q < rows_valid * N) __builtin_nontemporal_store(ov[q], o + lane + 64 * q);
+        }
+        if (!VEC && io.state) {   // plain launch: the wave's rows (contiguous in get_state's [B][W] layout) leave now
+            float *dst = io.state + ((size_t)s * p.B + b0) * W;
+            for (int k = lane; k < rows_valid * W; k += 64) dst[k] = tile[k];
+        }
+        flushed = false;
+        LANE_STAMP(7);
+    }
+    if (VEC) copy_chunks(0, Q, (size_t)(io.T - 1));
+    if (live) {
+        envl_store<N>(p, b, e);
+        if (REFRESH) {   // the tape lives in registers here: leave it, rebased to the cursor, for the next launch
+            U4 *tp = reinterpret_cast<U4 *>(p.tape + (size_t)b * TAPE_STRIDE);
+            tp[0] = U4{tape[0], tape[1], tape[2], tape[3]};
+            tp[1] = U4{tape[4], tape[5], tape[6], tape[7]};
+            tp[2] = U4{tape[8], tape[9], (unsigned)(e.words & 0xffffffffull), (unsigned)(e.words >> 32)};
+            tp[3] = U4{(unsigned)(p.detect_K & 0xffffffffull), (unsigned)(p.detect_K >> 32), 0u, 0u};
+        }
+    }
+}

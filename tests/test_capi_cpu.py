@@ -303,7 +303,8 @@ def test_dispatch_table_matches_the_code():
     table = design[design.index("<!-- dispatch:begin -->"):design.index("<!-- dispatch:end -->")]
     doc = {m.group(1): int(m.group(2)) for m in re.finditer(r"`(CS_[A-Z_]+)` = (\d+)", table)}
     assert set(doc) == {"CS_ODE_UPTO", "CS_OD_UPTO", "CS_OCT_FROM", "CS_LANEV_FROM", "CS_LV_W_FROM", "CS_LANE_FROM_LARGE_TEAMS"}
-    src = open(os.path.join(ROOT, "cooperative-search_amd", "csrc", "coopsearch.hip")).read()
+    csrc = os.path.join(ROOT, "cooperative-search_amd", "csrc")   # coopsearch.hip and the kernel headers it includes
+    src = "\n".join(open(os.path.join(csrc, f)).read() for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".h")))
     for name, value in doc.items():
         m = re.search(r"#ifndef " + name + r"\s*\n#define " + name + r"\s+(\d+)", src)
         assert m and int(m.group(1)) == value, (name, value, m and m.group(1))

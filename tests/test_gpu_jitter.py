@@ -13,10 +13,8 @@ The three-wavefront variant's row refreshes run in its emitting wavefront (reque
 the jitter build pauses at those hand-shakes too, and the child's last scenario makes every env refresh its row every few steps.
   legacy_n3   -DCS_LEGACY_KERNELS=1  (round 5) k_rollout ("solo") and k_rollout_duo, the 16-lane rollout kernels of rounds 1-2 that no dispatch
                                  row selects and the default build leaves out: the same scenarios, so they stay compiling and bit-exact.
-  pent_n5     -DCS_OD_PENT=1     (round 5, teams of 5) the 5-lanes-per-env packing of the pair kernels -- twelve envs per workgroup, three
-                                 targets per lane, the last envs of a batch on the octet kernels beside it on a second stream -- which
-                                 the default build leaves out (measured slower): the same scenarios at batches
-                                 that leave 0, 4 and 8 envs to the octet kernels."""
+  jitter_n5   -DCS_JITTER        (round 6; replaces round 5's build of the 5-lane packing, which is gone) the jitter build for teams of
+                                 5: the pair kernels of BASELINE configs 3 and 5, whose detection pass tests in packed fp32 first."""
 import concurrent.futures
 import os
 import subprocess
@@ -29,8 +27,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VARIANTS = {"jitter_n3": ["-DCS_JITTER"], "odsafe_n3": ["-DCS_OD_SAFE_WAIT"], "odsync_n3": ["-DCS_OD_ASYNC=0"],
             # (round 5) the 16-lane rollout kernels of rounds 1-2, retired from the default build: kept compiling and bit-exact here
             "legacy_n3": ["-DCS_LEGACY_KERNELS=1"],
-            # (round 5) the 5-lanes-per-env packing of the pair kernels, an experiment the default build leaves out
-            "pent_n5": ["-DCS_OD_PENT=1"]}
+            # (round 6) the jitter build for teams of 5 (BASELINE configs 3 / 5 run the 5-agent pair kernels)
+            "jitter_n5": ["-DCS_JITTER"]}
 
 
 def team_size(name):

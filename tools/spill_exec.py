@@ -8,7 +8,7 @@ instructions.
 
 Method.  `lines_nN.so` is the shipped kernel compiled with -gline-tables-only: every instruction of the step loop carries a source
 line; a spill instruction belongs to the region of rollout_lanev.h its line falls in (instructions of inlined helpers out of
-coopsearch.hip take the region of the nearest preceding kernel-body line), and is either in the region's straight line or inside an
+coopsearch.hip and its other headers take the region of the nearest preceding kernel-body line), and is either in the region's straight line or inside an
 inner loop of it (machine-code loop structure, as tools/spill_report.py).  `count_nN.so` is the same kernel with -DCS_REGION_COUNTS:
 one atomic counter per region entry and per inner-loop iteration (LV_COUNT in rollout_lanev.h), read back after a run of the bench's
 lane workload.  executed = sum over regions of static count x measured entries (or iterations) per wavefront-step.  The VALU
@@ -86,16 +86,21 @@ def static(n):
     step = max(loops, key=lambda l: l[1] - l[0])
     # blocks of the inlined helpers that no reachable state enters: the off-grid series of trig_heading / trig_heading_pair (headings
     # leave the pi/18 grid only if the raw state is edited), the plain divisions behind div2_same_denominator's guard
-    hip = open(os.path.join(CSRC, "coopsearch.hip")).read().splitlines()
-    def hfind(s_, start=0):
-        return next(i + 1 for i in range(start, len(hip)) if s_ in hip[i])
-    never = []
-    a = hfind("if (__builtin_expect((fabs(dh[0]) > 1e-6) | (fabs(dh[1]) > 1e-6), 0)) {"); never.append((a, hfind("sa = s[0];", a) - 1))
-    a = hfind("void trig_heading(const double *T, double yaw, double &s, double &c) {"); b = hfind("void load_trig_to_lds", a)
-    a2 = next(i + 1 for i in range(a, b) if "fabs(dh) > 1e-6" in hip[i]); never.append((a2, b - 2))
-    a = hfind("    qx = nx / den;"); never.append((a, a + 1))
+    # (round 6: the helpers live in coopsearch.hip and in the headers it includes -- find each block in whichever file holds it)
+    files = {f: open(os.path.join(CSRC, f)).read().splitlines() for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))}
+    def hfind(s_, fname=None, start=0):
+        for f in ([fname] if fname else sorted(files)):
+            for i in range(start, len(files[f])):
+                if s_ in files[f][i]:
+                    return f, i + 1
+        raise KeyError(s_)
+    never = []   # (file, first line, last line)
+    f, a = hfind("if (__builtin_expect((fabs(dh[0]) > 1e-6) | (fabs(dh[1]) > 1e-6), 0)) {"); never.append((f, a, hfind("sa = s[0];", f, a)[1] - 1))
+    f, a = hfind("void trig_heading(const double *T, double yaw, double &s, double &c) {"); b = hfind("void load_trig_to_lds", f, a)[1]
+    a2 = next(i + 1 for i in range(a, b) if "fabs(dh) > 1e-6" in files[f][i]); never.append((f, a2, b - 2))
+    f, a = hfind("    qx = nx / den;"); never.append((f, a, a + 1))
     def region_of(loc):
-        if loc and loc[0] == "coopsearch.hip" and any(x <= loc[1] <= y for x, y in never):
+        if loc and any(loc[0] == f_ and x <= loc[1] <= y for f_, x, y in never):
             return "never"
         if loc and loc[0] == "rollout_lanev.h":
             for a, b, r in regs:
