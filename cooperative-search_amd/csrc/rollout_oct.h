@@ -30,6 +30,12 @@
 // round, and per-env arithmetic that is exactly the 16-lane kernels' (same functions / same expression order), so
 // the results are bit-identical (tests/test_gpu_parity.py compares every kernel with the CPU restatement of the reference and with every other kernel).
 // =========================================================================================================
+#ifndef CS_OCT_PREFILTER
+#define CS_OCT_PREFILTER 0   /* k_rollout_oct's step: packed-fp32 pre-filter of the sensor tests (oct_detect_impl, PRE); 0: fp64 only.  Measured
+                                (round 6, 32768 envs, two passes, us per step off -> on): 5 agents 6.383 / 6.339 -> 6.539 / 6.571, 3 agents 4.158 /
+                                4.100 -> 4.292 / 4.280 -- the one-wavefront kernel is at its 168-VGPR cap and the four extra registers cost
+                                more (22 -> 26 spilled VGPRs at 5 agents) than the eight instructions per agent save */
+#endif
 #ifndef CS_OCT_WAVES
 #define CS_OCT_WAVES 3                     /* wavefronts per SIMD the register budget must allow (168 VGPRs): measured 2 / 3 / 4,
                                               3 agents 16384 envs 3.00 / 3.10 / 3.25 us per step, 32768: 6.04 / 5.62 / 5.58;
@@ -70,10 +76,27 @@ template <int N, int LG = OG>
 struct EnvO {
     double x, y, yaw, cs, sn;              // this lane's agent (lanes t < N)
     double tx[OctLay<LG>::TPL], ty[OctLay<LG>::TPL];   // targets t + LG k
+    float tnx[OctLay<LG>::TPL], tny[OctLay<LG>::TPL];  // ... as get_state emits them ((x - mid) * inv_half in fp32): the sensor pre-filter's operands
     unsigned found, newly, newly_reset;    // octet-uniform from here on
     int target_find, flags, time_step, total_reward, mt_pos, episodes, curr_reward, ahead;
     unsigned long long words;
 };
+
+// tnx / tny from tx / ty (after every assignment of the targets: prologue, reset).  A slot without a target gets a coordinate far outside
+// the map: never in range, never near the threshold, no NaN whatever the padding of the target array holds.
+template <int N, int LG>
+__device__ __forceinline__ void oct_norm_targets(double mid, double inv_half, int n_targets, int t, EnvO<N, LG> &e) {
+#pragma unroll
+    for (int k = 0; k < OctLay<LG>::TPL; k++) {
+        const bool exists = t + LG * k < n_targets;
+        e.tnx[k] = exists ? (float)((e.tx[k] - mid) * inv_half) : 1.0e3f;   // norm_target, the value get_state emits
+        e.tny[k] = exists ? (float)((e.ty[k] - mid) * inv_half) : 1.0e3f;
+    }
+}
+template <int N, int LG>
+__device__ __forceinline__ void oct_norm_targets(const DevParams &p, int t, EnvO<N, LG> &e) {
+    oct_norm_targets<N, LG>(p.mid, p.inv_half, p.n_targets, t, e);
+}
 
 // The env's slice of a wavefront ballot (bit k = lane first + k)
 template <int LG = OG>
@@ -347,35 +370,69 @@ __device__ __forceinline__ void tape_canon(unsigned (&t)[TAPE_DW], int &tcur) {
     for (int k = 0; k < TAPE_DW; k++) t[k] = __builtin_amdgcn_alignbit(k + 1 < TAPE_DW ? t[k + 1] : 0u, t[k], (unsigned)tcur);
     tcur = 0;
 }
-template <int N, int LG, int AP, bool LAZY>
+// PRE (round 6; the step's pass of k_rollout_od and k_rollout_oct): the n x 2 sensor tests of a lane are decided on the packed-fp32
+// pipe first, as in the lane kernels: the lane's two targets as ONE pair of floats in normalised coordinates
+// (e.tnx / e.tny), agent i's normalised position from `nrow[nstride * i]` (the floats get_state emits; LDS), d2 = fma(dx, dx, dy * dy)
+// per element -- two packed subtractions, one packed product, one packed fma and one packed subtraction of the threshold per AGENT
+// instead of six fp64 operations per PAIR -- and the fp32 verdict `d2 < thr` stands unless some pair of the wavefront lies within
+// eps32 = 1e-6 + 4e-6 thr of the threshold (at least 4x the error bound of d2; one running minimum of |d2 - thr| per lane, one
+// wave-uniform test), in which case the whole pass is redone with the reference's fp64 comparison (about one wavefront-step in 2000
+// at the shipped configuration).  The outcome is the exact one in every case.
+template <int N, int LG, int AP, bool LAZY, bool PRE = false>
 __device__ __forceinline__ int oct_detect_impl(const DevParams &p, const double2 (*pos)[AP], int o, int t, int sh8, bool stepping,
-                                               EnvO<N, LG> &e, unsigned (&tape)[TAPE_DW], int &tcur) {
+                                               EnvO<N, LG> &e, unsigned (&tape)[TAPE_DW], int &tcur, const float *nrow = nullptr,
+                                               int nstride = 0) {
     constexpr int MAXDW = (N * CS_MAX_TARGETS) / 32 < 1 ? 1 : (N * CS_MAX_TARGETS) / 32;   // draws of one pass, in dwords
     constexpr int TPL = OctLay<LG>::TPL;   // this lane's targets: t, t + LG, ...
+    static_assert(!PRE || TPL == 2, "the packed pre-filter holds a lane's two targets in one register pair");
     bool has[TPL], inr[N][TPL];
     unsigned below[TPL];
-    unsigned long long hasm[TPL];
     int rank[N][TPL];
     int base = 0;
-    // (a ballot of a bare comparison is the comparison's own result register; the lanes that hold a target of a stepping env are
-    // the same for every agent: their mask is taken once and applied on the scalar side)
 #pragma unroll
     for (int k = 0; k < TPL; k++) {
         has[k] = stepping & (t + LG * k < p.n_targets);
         below[k] = (1u << (t + LG * k)) - 1u;
-        hasm[k] = __ballot(has[k]);
     }
+    auto exact = [&]() __attribute__((always_inline)) {   // (t_x-x)**2 + (t_y-y)**2 <= view_range**2 on the fp64 values
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const double2 a = pos[o][i];
+#pragma unroll
+            for (int k = 0; k < TPL; k++) {
+                const double dx = e.tx[k] - a.x, dy = e.ty[k] - a.y;
+                inr[i][k] = has[k] & (dx * dx + dy * dy <= p.view_r2);
+            }
+        }
+    };
+    if constexpr (PRE) {
+        typedef float pk2 __attribute__((ext_vector_type(2)));
+        const pk2 tnx = {e.tnx[0], e.tnx[1]}, tny = {e.tny[0], e.tny[1]};
+        const float thr = p.thr32;
+        float margin = 3.0e38f;   // min over this lane's pairs of |d2 - thr|
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const float ax = nrow[nstride * i], ay = nrow[nstride * i + 1];
+            const pk2 dx = tnx - pk2{ax, ax}, dy = tny - pk2{ay, ay};
+            const pk2 d2 = __builtin_elementwise_fma(dx, dx, dy * dy);
+            const pk2 u = d2 - pk2{thr, thr};
+            inr[i][0] = has[0] & (u[0] < 0.0f);
+            inr[i][1] = has[1] & (u[1] < 0.0f);
+            margin = __builtin_fminf(margin, __builtin_fminf(__builtin_fabsf(u[0]), __builtin_fabsf(u[1])));
+        }
+#ifndef CS_PREFILTER_EPS_SCALE
+#define CS_PREFILTER_EPS_SCALE 1.0f   /* test builds widen the band (tests/test_gpu_jitter.py: prewide_n5) so that both paths run often */
+#endif
+        if (__builtin_expect(__ballot(margin <= p.eps32 * CS_PREFILTER_EPS_SCALE) != 0ull, 0)) exact();   // wave-uniform
+    } else {
+        exact();
+    }
+    // (the ballot of `has & c` is the comparison's own result register and one scalar AND)
 #pragma unroll
     for (int i = 0; i < N; i++) {
-        const double2 a = pos[o][i];
         unsigned gm = 0u;
 #pragma unroll
-        for (int k = 0; k < TPL; k++) {
-            const double dx = e.tx[k] - a.x, dy = e.ty[k] - a.y;
-            const bool c = dx * dx + dy * dy <= p.view_r2;   // (t_x-x)**2 + (t_y-y)**2 <= view_range**2
-            inr[i][k] = has[k] & c;
-            gm |= oct_slice<LG>(__ballot(c) & hasm[k], sh8) << (LG * k);
-        }
+        for (int k = 0; k < TPL; k++) gm |= oct_slice<LG>(__ballot(inr[i][k]), sh8) << (LG * k);
 #pragma unroll
         for (int k = 0; k < TPL; k++) rank[i][k] = base + __popc(gm & below[k]);   // agent-major order of the reference's double loop
         base += __popc(gm);
@@ -661,6 +718,7 @@ __device__ __forceinline__ void oct_place_targets(const DevParams &cp, int wave_
                 e.tx[k] = tk.x;
                 e.ty[k] = tk.y;
             }
+            oct_norm_targets<N, LG>(mid, inv_half, n_targets, t, e);
             tape_shift<1>(tape, r_words >> 1);   // (<= 32 draw slots leave the tape)
             e.mt_pos = wrap624(e.mt_pos + r_words);
             e.words += (unsigned long long)r_words;
@@ -719,6 +777,7 @@ __global__ __launch_bounds__(OCT_BLOCK, CS_OCT_WAVES) void k_rollout_oct(DevPara
         e.ty[0] = ta.y;
         e.tx[1] = tb.x;
         e.ty[1] = tb.y;
+        oct_norm_targets<N, OG>(p, t, e);
     }
     const TapeRaw traw = tape_fetch(p, (int)bl);
     const int aidx = ag ? t : N - 1;   // lanes without an agent repeat the last agent's (valid) address
@@ -865,7 +924,7 @@ __global__ __launch_bounds__(OCT_BLOCK, CS_OCT_WAVES) void k_rollout_oct(DevPara
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // ---- detection, reward, termination
         OCT_STAMP(3);
-        const int reward = oct_detect_impl<N, OG, OCT_PAD, true>(p, sh.pos, o, t, sh8, stepping, e, tape, tcur);
+        const int reward = oct_detect_impl<N, OG, OCT_PAD, true, CS_OCT_PREFILTER != 0>(p, sh.pos, o, t, sh8, stepping, e, tape, tcur, row, 4);
         OCT_STAMP(4);
         bool term = true;
         if (stepping) {

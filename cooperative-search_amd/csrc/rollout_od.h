@@ -71,7 +71,10 @@ template <int RING, int ENVS = OCT_ENVS, int AP = OCT_PAD, int TW = TILE_W>
 struct __attribute__((aligned(16))) OdSharedT {
     OdRingT<ENVS, AP> ring[RING];
     double2 kpos[ENVS][AP];        // K: the team's current positions (the "old" ones of its next step)
-    double2 dpos[ENVS][AP];        // D: start poses for the reset-time detection pass
+    union {   // never live together: the start poses are consumed inside a step's reset block, the floats written after it
+        double2 dpos[ENVS][AP];    // D: start poses for the reset-time detection pass
+        float2 dnp[ENVS][AP];      // D: the team's normalised fp32 positions of the step (sensor pre-filter, CS_OD_PREFILTER)
+    };
     float tile[ENVS * TW];
     float reward[ENVS];
     int term[ENVS], win[ENVS];
@@ -577,6 +580,7 @@ __device__ __forceinline__ void rollout_od_body(const DevParams &p, const StepIO
             e.tx[k] = tk.x;
             e.ty[k] = tk.y;
         }
+        oct_norm_targets<N, LG>(p, t, e);
     }
     const TapeRaw traw = tape_fetch(p, (int)bl);
     if (lane == 0) {   // the pair's counters: zero before the barrier below lets K start
@@ -821,15 +825,36 @@ __device__ __forceinline__ void rollout_od_body(const DevParams &p, const StepIO
 #endif
         const OdRing &r = sh.ring[s & (OD_RING - 1)];
         if (live) e.flags = (e.flags & ~0xff00) | (int)(r.out[o] << 8);
-        if (!E3 && ag) {
+        // D decides the sensor tests in packed fp32 first (oct_detect_impl, PRE) -- in the PAIR variant only.  Measured (round 6, one box,
+        // two passes, us per step, fp64 only -> pre-filter): pair at 16384 envs 5 agents 3.206 / 3.222 -> 3.189 / 3.210, 3 agents 2.306 /
+        // 2.306 -> 2.264 / 2.250 (four wavefronts per SIMD, VALU-issue-bound: 20 instructions fewer per D wavefront-step at 5 agents);
+        // three-wavefront variant 8192 envs 5 agents 1.956 / 1.944 -> 2.055 / 2.022, c2 (4096 envs, 3 agents) 1.179 / 1.197 -> 1.302 /
+        // 1.281: there D sits on the pipeline's critical path and the floats' way through LDS (write, wave barrier, read: D does not own
+        // the tile there) lengthens its chain by ~290 cycles per step.  -DCS_OD_PREFILTER=0 / 2: nowhere / in both variants.
+#ifndef CS_OD_PREFILTER
+#define CS_OD_PREFILTER 1
+#endif
+        constexpr bool PRE = CS_OD_PREFILTER == 2 || (CS_OD_PREFILTER == 1 && !E3);
+        if ((!E3 || PRE) && ag) {   // the agents' normalised floats: get_state's (the tile is D's without E) and the pre-filter's
             const double2 xy = r.pos[o][t];
-            const float2 cs = r.cssn[o][t];
-            row[4 * t + 0] = (float)((xy.x - p.mid) * p.inv_half);
-            row[4 * t + 1] = (float)((xy.y - p.mid) * p.inv_half);
-            row[4 * t + 2] = cs.x;
-            row[4 * t + 3] = cs.y;
+            const float nx = (float)((xy.x - p.mid) * p.inv_half), ny = (float)((xy.y - p.mid) * p.inv_half);
+            if (!E3) {
+                const float2 cs = r.cssn[o][t];
+                row[4 * t + 0] = nx;
+                row[4 * t + 1] = ny;
+                row[4 * t + 2] = cs.x;
+                row[4 * t + 3] = cs.y;
+            } else {
+                sh.dnp[o][t] = make_float2(nx, ny);
+            }
         }
-        const int reward = oct_detect_impl<N, LG, AP, CS_OD_LAZY_TAPE != 0>(p, r.pos, o, t, sh8, stepping, e, tape, tcur);
+        if (PRE) {   // every lane reads the whole team's floats: written by other lanes of this wavefront
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        const int reward = oct_detect_impl<N, LG, AP, CS_OD_LAZY_TAPE != 0, PRE>(p, r.pos, o, t, sh8, stepping, e, tape, tcur,
+                                                                                 E3 ? &sh.dnp[o][0].x : row, E3 ? 2 : 4);
         DUO_STAMP(10);
         bool term = true, mispredicted = false;
         if (stepping) {

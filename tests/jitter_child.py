@@ -48,9 +48,9 @@ def run(kernel, args, B, lengths, mode):
 
 def main():
     name = os.path.basename(cs.lib.library_path())
-    assert name in ("jitter_n3.so", "odsafe_n3.so", "odsync_n3.so", "legacy_n3.so", "jitter_n5.so") or os.environ.get("CS_CHILD_ANY_LIB") == "1", cs.lib.library_path()
+    assert name in ("jitter_n3.so", "odsafe_n3.so", "odsync_n3.so", "legacy_n3.so", "jitter_n5.so", "prewide_n5.so") or os.environ.get("CS_CHILD_ANY_LIB") == "1", cs.lib.library_path()
     # legacy_n3.so (-DCS_LEGACY_KERNELS=1): the 16-lane rollout kernels of rounds 1-2, which the default build no longer holds
-    kernels = ("solo", "duo") if name == "legacy_n3.so" else ("od", "ode")
+    kernels = ("solo", "duo") if name == "legacy_n3.so" else (("od", "ode", "oct") if name == "prewide_n5.so" else ("od", "ode"))
     if name == "legacy_n3.so":
         assert cs.lib.has_legacy_kernels()
     for kernel in kernels:

@@ -14,7 +14,9 @@ the jitter build pauses at those hand-shakes too, and the child's last scenario 
   legacy_n3   -DCS_LEGACY_KERNELS=1  (round 5) k_rollout ("solo") and k_rollout_duo, the 16-lane rollout kernels of rounds 1-2 that no dispatch
                                  row selects and the default build leaves out: the same scenarios, so they stay compiling and bit-exact.
   jitter_n5   -DCS_JITTER        (round 6; replaces round 5's build of the 5-lane packing, which is gone) the jitter build for teams of
-                                 5: the pair kernels of BASELINE configs 3 and 5, whose detection pass tests in packed fp32 first."""
+                                 5: the pair kernels of BASELINE configs 3 and 5, whose detection pass tests in packed fp32 first.
+  prewide_n5  -DCS_PREFILTER_EPS_SCALE=100.0f  (round 6) that pre-filter with its fallback band a hundred times wider, so that the fp64
+                                 redo runs in a tenth of the wavefront-steps instead of one in two thousand."""
 import concurrent.futures
 import os
 import subprocess
@@ -28,7 +30,10 @@ VARIANTS = {"jitter_n3": ["-DCS_JITTER"], "odsafe_n3": ["-DCS_OD_SAFE_WAIT"], "o
             # (round 5) the 16-lane rollout kernels of rounds 1-2, retired from the default build: kept compiling and bit-exact here
             "legacy_n3": ["-DCS_LEGACY_KERNELS=1"],
             # (round 6) the jitter build for teams of 5 (BASELINE configs 3 / 5 run the 5-agent pair kernels)
-            "jitter_n5": ["-DCS_JITTER"]}
+            "jitter_n5": ["-DCS_JITTER"],
+            # (round 6) the sensor pre-filter's band a hundred times wider: a tenth of the wavefront-steps redo the pass in fp64, the rest
+            # take the packed-fp32 verdict -- both paths of oct_detect_impl<PRE> run thousands of times against the step kernel
+            "prewide_n5": ["-DCS_PREFILTER_EPS_SCALE=100.0f"]}
 
 
 def team_size(name):
@@ -75,4 +80,4 @@ def test_pair_kernel_variant_builds_equal_the_step_kernel(name):
     env = dict(os.environ, COOPSEARCH_LIB=lib, COOPSEARCH_LIB_HASH=expected_hash(name))
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "jitter_child.py")], env=env, capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
-    assert p.stdout.count("bit-identical") == 2, p.stdout
+    assert p.stdout.count("bit-identical") == (3 if name == "prewide_n5" else 2), p.stdout
