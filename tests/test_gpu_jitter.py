@@ -15,8 +15,9 @@ the jitter build pauses at those hand-shakes too, and the child's last scenario 
                                  row selects and the default build leaves out: the same scenarios, so they stay compiling and bit-exact.
   jitter_n5   -DCS_JITTER        (round 6; replaces round 5's build of the 5-lane packing, which is gone) the jitter build for teams of
                                  5: the pair kernels of BASELINE configs 3 and 5, whose detection pass tests in packed fp32 first.
-  prewide_n5  -DCS_PREFILTER_EPS_SCALE=100.0f  (round 6) that pre-filter with its fallback band a hundred times wider, so that the fp64
-                                 redo runs in a tenth of the wavefront-steps instead of one in two thousand."""
+  prewide_n5  -DCS_PREFILTER_EPS_SCALE=100.0f -DCS_OD_PREFILTER=2 -DCS_OCT_PREFILTER=1  (round 6) that pre-filter in ALL octet kernels (the
+                                 shipped build has it in the pair variant only) with its fallback band a hundred times wider, so that
+                                 the fp64 redo runs in a tenth of the wavefront-steps instead of one in two thousand."""
 import concurrent.futures
 import os
 import subprocess
@@ -33,7 +34,7 @@ VARIANTS = {"jitter_n3": ["-DCS_JITTER"], "odsafe_n3": ["-DCS_OD_SAFE_WAIT"], "o
             "jitter_n5": ["-DCS_JITTER"],
             # (round 6) the sensor pre-filter's band a hundred times wider: a tenth of the wavefront-steps redo the pass in fp64, the rest
             # take the packed-fp32 verdict -- both paths of oct_detect_impl<PRE> run thousands of times against the step kernel
-            "prewide_n5": ["-DCS_PREFILTER_EPS_SCALE=100.0f"]}
+            "prewide_n5": ["-DCS_PREFILTER_EPS_SCALE=100.0f", "-DCS_OD_PREFILTER=2", "-DCS_OCT_PREFILTER=1"]}
 
 
 def team_size(name):
