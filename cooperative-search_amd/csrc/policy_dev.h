@@ -84,7 +84,20 @@ __host__ __device__ __forceinline__ _Float16 cvt_half(float v) {
     return (_Float16)v;
 #endif
 }
+// Values beyond fp16's range SATURATE at +-65504 (round 6): unclamped, hi would be inf and lo = (v - inf) * 2048 = NaN,
+// and one such activation would turn every q-value of its row into NaN.  Weights are refused by cs_policy_pack instead (a saturated
+// weight is a different network); an ACTIVATION of that size -- only relu(fc1 x) can reach it, the recurrent state lies in (-1, 1) --
+// behaves like min(relu(.), 65504).  One v_med3_f32 per conversion; values inside the range are unchanged bit for bit.
+constexpr float F16_MAX = 65504.0f;
+__host__ __device__ __forceinline__ float clamp_f16_range(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fmed3f(v, -F16_MAX, F16_MAX);
+#else
+    return v < -F16_MAX ? -F16_MAX : (v > F16_MAX ? F16_MAX : v);
+#endif
+}
 __host__ __device__ __forceinline__ void split_f16(float v, _Float16 &hi, _Float16 &lo) {
+    v = clamp_f16_range(v);
 #if CS_SPLIT_GUARD
     const float a = v < 0.0f ? -v : v;
     hi = a < F16_MIN_NORMAL ? (_Float16)0.0f : (_Float16)v;

@@ -255,9 +255,10 @@ size_t cs_policy_packed_floats(void);
  * fc2.2.weight [n_actions][64] and their biases) -> packed_host[cs_policy_packed_floats()], to be copied to the device.
  * in_dim = [16 conv features +] 4 + n_actions + n_agents <= 32 (agent.py:41-52, base_net.py:31-39).
  * The network runs on the 16-bit matrix pipe with every fp32 operand split into two halves (csrc/policy_dev.h): a WEIGHT whose
- * magnitude exceeds 65504 (or is not finite) is refused with CS_E_ARG; an ACTIVATION (a ReLU output of fc1 / fc2) must stay below
- * 65504 too -- with |obs| <= 1 and |h| < 1 that holds whenever the rows of fc1 / fc2.0 have an L1 norm below ~6e4, as any
- * trained network's do; beyond it the value becomes inf / NaN (it is not clamped: the loop is VALU-issue bound). */
+ * magnitude exceeds 65504 (or is not finite) is refused with CS_E_ARG; an ACTIVATION (a ReLU output of fc1 / fc2) beyond 65504
+ * SATURATES there (min(relu(.), 65504): one v_med3_f32 per conversion, values inside the range unchanged bit for bit) -- with
+ * |obs| <= 1 and |h| < 1 no activation gets that far while the rows of fc1 / fc2.0 have an L1 norm below ~6e4, as any trained
+ * network's do; the q-values stay finite either way (tests/test_gpu_policy.py). */
 int cs_policy_pack(const float *fc1_w, const float *fc1_b, const float *w_ih, const float *b_ih, const float *w_hh,
                    const float *b_hh, const float *fc2a_w, const float *fc2a_b, const float *fc2b_w, const float *fc2b_b,
                    int in_dim, int n_actions, float *packed_host);

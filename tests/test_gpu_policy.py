@@ -46,6 +46,41 @@ def test_fused_forward_matches_torch_module(n, B):
         last = torch.nn.functional.one_hot(act, a.n_actions).float()
 
 
+def test_activations_beyond_the_fp16_range_saturate_instead_of_turning_into_nan():
+    """split_f16 (csrc/policy_dev.h) carries a float as hi = fp16(v), lo = fp16((v - hi) * 2048); above 65504 hi was inf
+    and lo NaN, and every q-value of the row NaN.  Activations now saturate at +-65504 (one v_med3_f32 per conversion): with an fc1
+    unit driven to 1e5 the kernel's q-values and hidden state are finite and equal those of the torch fp32 module whose relu output
+    is clamped at 65504 -- and differ from the unclamped module's, i.e. the saturating unit does matter in this network.
+    Reference network: /root/reference/network/base_net.py:5-46 (fc1 -> relu -> GRUCell -> fc2)."""
+    torch.manual_seed(11)
+    a = _args(3)
+    B = 64
+    net = AgentRNN(rnn_input_shape(a), a).cuda()
+    with torch.no_grad():
+        net.fc1.weight[0].zero_()
+        net.fc1.bias[0] = 1.0e5                 # relu(fc1 x)[0] = 1e5 for every row: beyond fp16's 65504
+        net.rnn.weight_ih[:, 0] = torch.randn(3 * a.rnn_hidden_dim, device="cuda") * 1.0e-5   # ... weighted so that it moves the gates by O(1)
+    fused = FusedAgents(a, B, net=net)
+    ref = BatchedAgents(a, B, net=net)
+    last = torch.zeros(B, 3, a.n_actions, device="cuda")
+    for t in range(4):
+        obs = torch.rand(B, 3, 4, device="cuda") * 2 - 0.5
+        act = fused.choose_action(obs, want_q=True).clone()
+        assert torch.isfinite(fused.q).all() and torch.isfinite(fused.hidden).all(), t
+        x = torch.cat([obs, last, ref.agent_ids], 2).reshape(B * 3, -1)
+        with torch.no_grad():
+            x1 = torch.relu(net.fc1(x))
+            assert float(x1[:, 0].min()) > 7.0e4
+            h_sat = net.rnn(x1.clamp(max=65504.0), ref.hidden.reshape(-1, a.rnn_hidden_dim))
+            q_sat = net.fc2(h_sat).reshape(B, 3, -1)
+            h_raw = net.rnn(x1, ref.hidden.reshape(-1, a.rnn_hidden_dim))
+        assert torch.allclose(fused.q, q_sat, atol=5e-5, rtol=5e-5), (t, (fused.q - q_sat).abs().max().item())
+        assert torch.allclose(fused.hidden.reshape(h_sat.shape), h_sat, atol=5e-5, rtol=5e-5)
+        assert (h_raw - h_sat).abs().max().item() > 1e-2      # the clamp is not a no-op here
+        ref.hidden = fused.hidden.clone()
+        last = torch.nn.functional.one_hot(act, a.n_actions).float()
+
+
 def test_fused_forward_matches_reference_fixture():
     """tests/golden/rnn_forward.npz holds the reference RNN's own (fp64) outputs for a seeded state_dict and random
     full-width input rows: the kernel's raw-input mode reproduces them to fp32 accuracy."""
