@@ -139,22 +139,6 @@ __device__ __forceinline__ int2 lds_peek2(const int *base) {
     return make_int2(v.x, v.y);
 }
 
-// The same read in two halves: issued here, waited for (lds_peek2_wait) where the words are needed -- K reads its flow-control words for
-// the NEXT loop head in the middle of a step, so the LDS round trip runs beside the step's publication instead of in front of the next
-// step.  (The compiler does not know the asm is an LDS read; its own lgkmcnt waits can only become longer by one outstanding read it
-// does not count, never shorter: LDS operations return in order.)
-template <int OFF0, int OFF1>
-__device__ __forceinline__ int2 lds_peek2_issue(const int *base) {
-    static_assert(OFF0 >= 0 && OFF0 < 256 && OFF1 >= 0 && OFF1 < 256, "ds_read2_b32 offsets are 8-bit dword counts");
-    typedef int v2i __attribute__((ext_vector_type(2)));
-    v2i v;
-    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=&v"(v) : "v"(lds_offset_of(base)), "n"(OFF0), "n"(OFF1) : "memory");
-    return make_int2(v.x, v.y);
-}
-__device__ __forceinline__ void lds_peek2_wait(int2 &v) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v.x), "+v"(v.y) : : "memory");
-}
-
 #ifndef CS_OD_COLD_PARAMS
 #define CS_OD_COLD_PARAMS 1
 #endif
@@ -316,7 +300,7 @@ __device__ __forceinline__ void rollout_od_body(const DevParams &p, const StepIO
             const unsigned out = oct_kinematics<N, (N >= CS_OD_SHARED_DIV_FROM_N), LG, AP>(p, T, sh.kpos, o, t, sh8, stepping, a, e, sp);
 #endif
             KIN_STAMP_SP(6);
-            between();   // (the main loop issues its next flow-control read here)
+            between();
             if (stepping) {
                 k_out = out;
                 k_time += 1;
@@ -367,12 +351,11 @@ __device__ __forceinline__ void rollout_od_body(const DevParams &p, const StepIO
                 post(&sh.fix_ack, req);
             }
         };
-#ifndef CS_OD_EARLY_PEEK
-#define CS_OD_EARLY_PEEK 0
-#endif
+        // (Rounds 5 / 6 tried requesting these words in the middle of the previous step so that the LDS round trip runs beside the publication:
+        // round 5 as one ds_read2_b32 split over two asm statements -- a load in flight the register allocator knew nothing of, ADVICE r5 --
+        // and round 6 as compiler-visible volatile loads: no gain, c2 1.18 -> 1.20-1.21 us per step, profiles/r06_experiments.md H.  Gone.)
         constexpr int OFF_FIX = (int)(offsetof(OdShared, fix_req) - offsetof(OdShared, d_steps)) / 4;
         constexpr int OFF_E = (int)(offsetof(OdShared, e_steps) - offsetof(OdShared, d_steps)) / 4;
-        int2 pv = make_int2(0, 0);
         for (int s = 0; s < io.T; s++) {   // (D zeroed the counters before the barrier that published the trig table)
             asm volatile("" : "+v"(t));
             ag = t < N;
@@ -384,11 +367,9 @@ __device__ __forceinline__ void rollout_od_body(const DevParams &p, const StepIO
             // s - OD_RING out; E never passes D).  The progress word and D's fix request come in ONE LDS round trip, and the
             // common case -- slot free, nothing to fix -- touches none of the fix-up code (whose state updates otherwise cost a
             // row of register copies at every pass through the loop head).
-            // (the words were requested in the middle of the previous step -- CS_OD_EARLY_PEEK -- and may be that old: both only ever
-            // grow, so an old progress word can only make K look again below, and an old fix_req only delays the fix by a step.  The
-            // slot rule holds as before: K overwrites slot s after ONE read that showed d_steps (e_steps) > s - RING, and that read
-            // also returned every fix_req posted before that progress word)
-            if (!CS_OD_EARLY_PEEK || s == 0) pv = E3 ? lds_peek2<OFF_E, OFF_FIX>(&sh.d_steps) : lds_peek2<0, OFF_FIX>(&sh.d_steps);
+            // (K overwrites slot s after ONE read that showed d_steps (e_steps) > s - RING, and that read also returned every fix_req
+            // posted before that progress word)
+            const int2 pv = E3 ? lds_peek2<OFF_E, OFF_FIX>(&sh.d_steps) : lds_peek2<0, OFF_FIX>(&sh.d_steps);
             if (__builtin_expect(pv.x <= s - OD_RING || pv.y != fix_seen, 0)) {
                 for (;;) {
                     // progress word FIRST, fix request second: the request that belongs to a progress value was posted before it,
@@ -402,16 +383,10 @@ __device__ __forceinline__ void rollout_od_body(const DevParams &p, const StepIO
                 }
             }
             DUO_STAMP(2);
-            produce(s, act, true, [&]() __attribute__((always_inline)) {
-                if (CS_OD_EARLY_PEEK) pv = E3 ? lds_peek2_issue<OFF_E, OFF_FIX>(&sh.d_steps) : lds_peek2_issue<0, OFF_FIX>(&sh.d_steps);
-            });
+            produce(s, act, true, []() {});
             DUO_STAMP(1);
             OD_JITTER(2);
             post(&sh.k_steps, s + 1);
-            // the words requested in the middle of this step arrived long ago: the wait is free here, and it sits INSIDE the iteration
-            // that issued the read -- between the two asm statements the compiler believes the registers already hold the words, so
-            // nothing but straight-line code may lie there (a copy at the loop's back edge, say, would copy them too early)
-            if (CS_OD_EARLY_PEEK) lds_peek2_wait(pv);
             act = act_next;
             act_next = act_after;
         }

@@ -505,11 +505,50 @@ class BatchedFlightEnv:
         self._call(self._L.cs_metrics, self._cfgp, self._blob.data_ptr(), self._metrics.data_ptr(), self._stream())
         return self._metrics
 
-    def render(self):
-        pass  # flight_env_easy.py:324-343 is a matplotlib scatter; not on the compute path
+    def render(self, env=0, path=None, pause=None):
+        """Host-side scatter of ONE env of the batch (default env 0), the picture of flight_env_easy.py:324-343: targets as dots
+        (found: orange, others black), agents as red triangles, title 'target_find:k/m', axes 0..map_size.  Copies that env's
+        256 + 256 + 64 bytes to the host; not on the compute path.  `path`: save the figure there instead of showing it (headless
+        boxes); `pause`: seconds for plt.pause (the reference: 3 after a full find, else 0.1).  Without matplotlib: a no-op,
+        as the batched path's render has been so far."""
+        raw = self.raw()
+        b = int(env)
+        if not 0 <= b < self.batch:
+            raise IndexError(f"render: env {env} out of range for a batch of {self.batch}")
+        hdr = raw["hdr"][b].cpu()
+        return draw_env(raw["tgt"][b, :self.target_num].cpu().numpy(), int(hdr[_lib.H_FOUND]),
+                        raw["agent"][b, :self.n_agents, :2].cpu().numpy(), int(hdr[_lib.H_TARGET_FIND]), self.target_num,
+                        self.map_size, path=path, pause=pause)
 
     def close(self):
         pass
+
+
+def draw_env(target_pos, found_mask, agent_pos, target_find, target_num, map_size, path=None, pause=None):
+    """The drawing of flight_env_easy.py:324-343 from plain host data (no device, no env object): returns the matplotlib
+    Axes, or None when matplotlib is missing.  Colours, marker and sizes are the reference's."""
+    try:
+        import matplotlib
+        if path is not None:
+            matplotlib.use("Agg", force=False)
+        import matplotlib.pyplot as plt
+    except Exception:   # noqa: BLE001  (no matplotlib, or no usable backend: rendering is optional)
+        return None
+    plt.cla()
+    for j, (x, y) in enumerate(target_pos):
+        plt.scatter(x, y, c="orange" if (found_mask >> j) & 1 else "black", s=7)
+    for x, y in agent_pos:
+        plt.scatter(x, y, c="red", marker="^")
+    plt.title("target_find:{}/{}".format(target_find, target_num))
+    plt.xlim(0, map_size)
+    plt.ylim(0, map_size)
+    ax = plt.gca()
+    if path is not None:
+        plt.savefig(path)
+    else:
+        plt.draw()
+        plt.pause(pause if pause is not None else (3 if target_find == target_num else 0.1))
+    return ax
 
 
 class _SingleEnvAdapter:
@@ -611,7 +650,8 @@ class _SingleEnvAdapter:
         return self._env.raw()["prob"][0].to(torch.float64).cpu().numpy()
 
     def render(self):
-        pass
+        """flight_env_easy.py:324-343: the reference's interactive scatter (plt.draw + plt.pause) of this env."""
+        self._env.render(0)
 
     def close(self):
         pass

@@ -1071,6 +1071,30 @@ def test_check_actions_refuses_out_of_range_values_like_the_reference(binding, c
         chk.step(a)
 
 
+def test_render_of_one_env_of_the_batch(tmp_path):
+    """Row a13: BatchedFlightEnv.render(env, path) draws that env's targets (found ones orange), agents and found count from the
+    device state -- the picture of flight_env_easy.py:324-343 -- and leaves the state untouched."""
+    pytest.importorskip("matplotlib")
+    env = cs.BatchedFlightEnv(cs.make_env_args("flight_easy", n_agents=3), batch=64, seeds=np.arange(64, dtype=np.uint32) + 3)
+    acts = torch.randint(0, 3, (120, 64, 3), dtype=torch.int32, device="cuda")
+    env.rollout(acts)
+    before = {k: v.clone() for k, v in env.raw().items()}
+    b = int(env.target_find.argmax().item())
+    ax = env.render(b, path=str(tmp_path / "e.png"))
+    assert ax is not None and (tmp_path / "e.png").exists()
+    k = int(env.target_find[b].item())
+    assert ax.get_title() == f"target_find:{k}/15" and len(ax.collections) == 15 + 3
+    import matplotlib.colors as mc
+    orange = sum(tuple(np.round(c.get_facecolor()[0][:3], 3)) == tuple(np.round(mc.to_rgb("orange"), 3)) for c in ax.collections[:15])
+    assert orange == k and k > 0
+    pos = env.raw()["agent"][b, :3, :2].cpu().numpy()
+    assert np.allclose([c.get_offsets()[0] for c in ax.collections[15:]], pos)
+    for key, v in env.raw().items():
+        assert torch.equal(v, before[key]), key
+    with pytest.raises(IndexError):
+        env.render(64, path=str(tmp_path / "x.png"))
+
+
 def test_b1_adapter_action_indices_follow_python_list_indexing():
     """dyaw[act] (flight_env_easy.py:259-262): 3 raises IndexError, -1 is dyaw[-1] = -pi/18 (action 2)."""
     args = cs.make_env_args("flight_easy", n_agents=3)

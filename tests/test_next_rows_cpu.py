@@ -103,3 +103,25 @@ def test_replay_buffer_rejects_more_episodes_than_slots():
     with pytest.raises(ValueError):
         buf._get_storage_idx(5)
     assert list(buf._get_storage_idx(4)) == [3, 0, 1, 2]
+
+
+def test_render_drawing_is_the_reference_scatter(tmp_path):
+    """Row a13's optional host render (flight_env_easy.py:324-343): found targets orange, the others black, size 7; agents red
+    triangles; title 'target_find:k/m'; axes 0..map_size -- drawn from plain host data, saved to a file on a headless box."""
+    import pytest
+    pytest.importorskip("matplotlib")
+    from cooperative_search_amd.env import draw_env
+    tgt = np.array([[5.0, 6.0], [20.0, 30.0], [44.0, 2.5]])
+    ag = np.array([[0.0, 0.0], [25.0, 0.0]])
+    out = tmp_path / "env0.png"
+    ax = draw_env(tgt, 0b101, ag, 2, 3, 50, path=str(out))
+    assert ax is not None and out.exists() and out.stat().st_size > 1000
+    assert ax.get_title() == "target_find:2/3" and ax.get_xlim() == (0.0, 50.0) and ax.get_ylim() == (0.0, 50.0)
+    cols = ax.collections
+    assert len(cols) == 5   # one scatter per target and per agent, like the reference's loops
+    import matplotlib.colors as mc
+    face = [tuple(np.round(c.get_facecolor()[0][:3], 3)) for c in cols]
+    want = [mc.to_rgb("orange"), mc.to_rgb("black"), mc.to_rgb("orange"), mc.to_rgb("red"), mc.to_rgb("red")]
+    assert face == [tuple(np.round(w, 3)) for w in want]
+    assert [float(c.get_sizes()[0]) for c in cols[:3]] == [7.0, 7.0, 7.0]
+    assert [tuple(c.get_offsets()[0]) for c in cols] == [(5.0, 6.0), (20.0, 30.0), (44.0, 2.5), (0.0, 0.0), (25.0, 0.0)]

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r05_traffic_raw.json (tools/pmc_traffic.sh: FETCH_SIZE / WRITE_SIZE sums per kernel and workload) ->
+"""profiles/r06_traffic_raw.json (tools/pmc_traffic.sh: FETCH_SIZE / WRITE_SIZE sums per kernel and workload) ->
 profiles/traffic.json (HBM bytes per env-step per bench kernel label, what bench.py's roofline.traffic reads).
     python tools/make_traffic_json.py [raw.json] [out.json]"""
 import json
@@ -7,7 +7,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-raw_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r05_traffic_raw.json")
+raw_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r06_traffic_raw.json")
 out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "traffic.json")
 raw = json.load(open(raw_path))
 
@@ -70,7 +70,7 @@ for label, tag, names, spl in LABELS:
     kernels[label] = ent
 doc = ("HBM traffic per env-step from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_traffic.sh over "
        "tools/exp_workload.py, which runs a known number of env-steps; KB units x 1024, summed over every launch of the "
-       "kernel; raw sums in r05_traffic_raw.json; this file = tools/make_traffic_json.py). FETCH_SIZE is doubled for k_map / "
+       "kernel; raw sums in r06_traffic_raw.json; this file = tools/make_traffic_json.py). FETCH_SIZE is doubled for k_map / "
        "k_flight_pipe (16 B/lane coalesced stream: gfx950 reports exactly half, MI355X_MICROARCH.md section HBM) and left raw "
        "for the other kernels (uncalibrated width). bench.py reports roofline.traffic = hbm_bytes_per_env_step x batch x "
        "steps per launch of ITS run. The rollout kernels refresh their MT19937 rows themselves (prologue / in-loop), so "
