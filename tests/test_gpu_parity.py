@@ -1069,6 +1069,18 @@ def test_check_actions_refuses_out_of_range_values_like_the_reference(binding, c
     chk = cs.BatchedFlightEnv(cs.make_env_args(variant, n_agents=n), batch=256, binding=binding, check_actions=True)
     with pytest.raises(IndexError, match="list index out of range"):
         chk.step(a)
+    #  several offenders: the one with the LOWEST flat index (step, env, agent) is reported -- the one the reference's
+    # sequential loops would raise on -- whatever order the device's threads found them in; 40 000 offenders, 20 repetitions
+    many = torch.randint(0, 3, (40, 256, n), device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    many[3:] = torch.where(torch.rand(37, 256, n, device="cuda") < 0.5, torch.full_like(many[3:], 5), many[3:])
+    many[2, 200, 1] = 4
+    for _ in range(20):
+        with pytest.raises(IndexError, match=r"action 4 of step 2, env 200, agent 1 ") as ei:
+            chk.rollout(many)
+    #  check_actions=False is honoured for a small batch too, on both bindings (the op layer applies its default only
+    # when the caller has not decided)
+    off = cs.BatchedFlightEnv(cs.make_env_args(variant, n_agents=n), batch=8, binding=binding, check_actions=False)
+    off.step(torch.full((8, n), 3, dtype=torch.int64, device="cuda"))   # no IndexError: acts as action 0
 
 
 def test_render_of_one_env_of_the_batch(tmp_path):
