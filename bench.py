@@ -76,8 +76,8 @@ def parse_args(argv=None):
     ap.add_argument("--also", action="store_true",
                     help="N > 1: run the whole list of secondary workloads on every rank too (default at N > 1: the headline and "
                          "the two c5 lines only, so that a scaling run is not 8x longer than it has to be)")
-    ap.add_argument("--kernel", default="auto", choices=["auto", "group", "solo", "duo", "od", "ode", "oct", "lane", "lanev"],
-                    help="flight_easy kernel: 16 lanes per env (solo / duo wavefront roles, or chosen by batch), 8 lanes per env "
+    ap.add_argument("--kernel", default="auto", choices=["auto", "group", "od", "ode", "oct", "lane", "lanev"],
+                    help="flight_easy kernel: 16 lanes per env (group: a rollout is T launches of the step kernel), 8 lanes per env "
                          "(od: kinematics + detection wavefront pair, oct: one wavefront), one lane per env, or everything by "
                          "batch size (auto: ode up to 8192 envs, od up to 16384, oct below 65536 -- teams of 6 to 8: below 2^20 --, lanev from 65536 "
                          "for teams of up to 5, lane from 2^20 for larger ones; DESIGN.md section 4)")
@@ -257,7 +257,7 @@ def largest_divisor_leq(k, cap):
 
 
 def kernel_label(env_name, n, B, mode, kernel):
-    """The kernel cs_step / cs_rollout dispatches to (csrc/coopsearch.hip: use_lane_kernel, duo_pays)."""
+    """The kernel cs_step / cs_rollout dispatches to (csrc/coopsearch.hip: use_lane_kernel, use_od_kernel, use_oct_kernel)."""
     lane_from = (65536 if n <= 5 else 1048576) if mode == "rollout" else 32768   # lane_from() (rollout); single steps: 32768
     lane = env_name == "flight_easy" and (kernel in ("lane", "lanev") or (kernel == "auto" and B >= lane_from))
     if env_name == "flight":   # rollout call: step t + 1 rides inside the map sweep of step t, one launch per step
@@ -272,8 +272,7 @@ def kernel_label(env_name, n, B, mode, kernel):
         return f"k_rollout_od<{n}>"
     if kernel == "oct" or kernel == "auto":                         # CS_OCT_FROM < B < CS_LANE_FROM
         return f"k_rollout_oct<{n}>"
-    duo = kernel == "duo" or (kernel == "group" and n <= 6 and B <= 4096)
-    return f"k_rollout_duo<{n}>" if duo else f"k_rollout<{n}>"
+    return f"k_step<{n},0>"   # kernel == "group": T launches of the 16-lane step kernel
 
 
 def pmc_traffic(label, B, steps_per_launch):

@@ -190,7 +190,8 @@ def pick_binding(binding=None):
 
 
 def has_legacy_kernels():
-    """The 16-lane rollout kernels of rounds 1-2 ("solo" / "duo") are in the loaded library (-DCS_LEGACY_KERNELS=1 builds only)."""
+    """cs_has_legacy_kernels() of the loaded library: False since round 6 (the 16-lane rollout kernels of rounds 1-2 were removed; the
+    entry point stays for ABI 7)."""
     L = load()
     L.cs_has_legacy_kernels.restype = C.c_int
     return bool(L.cs_has_legacy_kernels())

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(HERE)
 LIB_PATH = os.environ.get("COOPSEARCH_LIB") or os.path.join(CSRC, "libcoopsearch_hip.so")  # override: experiments only
 # torch.ops.coopsearch.*: the op layer over the C ABI (override: the sanitizer build of tests/test_sanitizers_cpu.py)
 TORCH_LIB_PATH = os.environ.get("COOPSEARCH_TORCH_LIB") or os.path.join(CSRC, "coopsearch_torch.so")
-SOURCES = ["coopsearch.hip", "rollout_duo.h", "rollout_policy.h", "rollout_lane.h", "rollout_oct.h", "rollout_od.h", "rollout_lanev.h",
+SOURCES = ["coopsearch.hip", "rollout_policy.h", "rollout_lane.h", "rollout_oct.h", "rollout_od.h", "rollout_lanev.h",
            "flight_map.h", "policy.hip", "episodes.hip", "policy_dev.h", "trig_table.inc"]
 HEADERS = [os.path.join(ROOT, "include", "coopsearch.h")]
 

@@ -1225,7 +1225,6 @@ __device__ int g_tl_step_dummy;
 // kernel actually ran at (the chip clocks to its power budget: fp64-dense kernels run well below 2.4 GHz)
 #define REAL_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && s < 64) g_stamps[s][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define DUO_STAMP(k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && s < 64) g_stamps[s][k] = __builtin_readcyclecounter(); } while (0)
-#define DUO_MARK(row, k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_stamps[row][k] = __builtin_readcyclecounter(); } while (0)
 #define OCT_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && s < 64) g_stamps[s][k] = __builtin_readcyclecounter(); } while (0)
 #define KIN_STAMP(k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && tl_step >= 0 && tl_step < 64) g_stamps[tl_step][k] = __builtin_readcyclecounter(); } while (0)
 #define KIN_STAMP_SP(k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && sp >= 0 && sp < 64) g_stamps[sp][k] = __builtin_readcyclecounter(); } while (0)
@@ -1234,7 +1233,6 @@ __device__ int g_tl_step_dummy;
 #define KIN_STAMP_SP(k) do {} while (0)
 #define OCT_STAMP(k) do {} while (0)
 #define DUO_STAMP(k) do {} while (0)
-#define DUO_MARK(row, k) do {} while (0)
 #define CS_STAMP(k) do {} while (0)
 #define LANE_STAMP(k) do {} while (0)
 #define REAL_STAMP(k) do {} while (0)
@@ -1509,72 +1507,6 @@ __global__ __launch_bounds__(BLOCK) void k_step(DevParams p, StepIO io) {
     __shared__ WaveTile tiles[BLOCK / 64];
     step_block<N, VARIANT>(p, io, T, tiles, blockIdx.x);
 }
-
-// T steps per launch, env resident in registers between steps (flight_easy).  The next step's actions and MT
-// window are requested before the current step's stores so their latency hides behind the arithmetic.
-template <int N>
-__global__ __launch_bounds__(BLOCK) void k_rollout(DevParams p, StepIO io) {
-    __shared__ double T[TRIG_ROWS * TRIG_COLS];
-    __shared__ WaveTile tiles[BLOCK / 64];
-    __shared__ unsigned rowbufs[N <= 4 ? BLOCK / 64 : 1][N <= 4 ? MT_N : 1];   // one MT19937 row per wavefront (prologue)
-    const int gid = blockIdx.x * BLOCK + threadIdx.x;
-    const int b = gid / G, t = gid % G;
-    const int lane = threadIdx.x & 63;
-    const bool live = b < p.B;
-    // the env's hit tape (cs_mt_advance), replicated in the group's lanes; teams of 5 and more keep the on-demand
-    // window instead: the ten tape registers would cost them their second wavefront per SIMD
-    constexpr bool USE_TAPE = N <= 4;
-    Env<N> e;
-    int act[N];
-    TapeRaw traw = {};
-    if (live) {   // everything the first step waits for is requested before the barrier that publishes the trig table
-        env_load<N>(p, b, t, e);
-        load_actions<N>(io, (size_t)b, act);
-        if (USE_TAPE) traw = tape_fetch(p, b);
-    }
-    load_trig_to_lds(T);
-    const int wave_b0 = (blockIdx.x * BLOCK + (threadIdx.x & ~63)) / G;
-    if (wave_b0 >= p.B) return;
-    const int nvalid = p.B - wave_b0 < 4 ? p.B - wave_b0 : 4;
-    WaveTile &tile = tiles[threadIdx.x >> 6];
-    const EmitPlan<N> plan = make_emit_plan<N>(p, lane, nvalid);
-    constexpr bool PIPE = N <= 4;
-    MtWin win = {0u, 0u};
-    unsigned tape[TAPE_DW];
-    bool tape_ok = false;
-    if (USE_TAPE) {
-        if (live) tape_ok = tape_finish(p, traw, e, tape);
-        group_wave_advance<N>(p, wave_b0, nvalid, lane, io.min_ahead, rowbufs[N <= 4 ? threadIdx.x >> 6 : 0], e, tape, tape_ok);
-    }
-    if (!USE_TAPE && live) win = mt_prefetch(p.mt + (size_t)b * MT_STRIDE, e.mt_pos, t);
-    for (int s = 0; s < io.T; s++) {
-        // (no in-loop top-up here: it would push this kernel past 256 VGPRs and cost its second wavefront per SIMD; an env
-        // that exhausts its row falls back to twisting on demand until the next launch's prologue)
-        int act_next[N];
-        const int sn = s + 1 < io.T ? s + 1 : s;
-        load_actions<N>(io, (size_t)sn * p.B + (live ? b : 0), act_next);
-        // (lane predicates -- t == i, t < n_targets ... -- are recomputed every step: hoisted out of the loop each of them is
-        // an SGPR pair the scalar file has no room for, and they came back as v_readlane pairs at every use)
-        int lane_s = lane;
-        asm volatile("" : "+v"(lane_s));
-        // n <= 4: the rows of step s are stored while step s+1 computes (costs ~12 VGPRs; larger teams have none spare)
-        step_once<N, 0>(p, T, io, tile, b, lane_s, (size_t)s * p.B + wave_b0, plan, live, act, win, s + 1 < io.T,
-                        PIPE && s > 0, (size_t)(s - 1) * p.B + wave_b0, PIPE, e, tape, USE_TAPE, tape_ok);
-#pragma unroll
-        for (int i = 0; i < N; i++) act[i] = act_next[i];
-    }
-    if (PIPE) {  // rows of the last step
-        FlushRegs<N> fr;
-        emit_flush_load<N>(tile, plan, fr);
-        emit_flush_store<N>(p, io, plan, fr, (size_t)(io.T - 1) * p.B + wave_b0);
-    }
-    if (live) {
-        env_store<N>(p, b, t, e, false);
-        if (USE_TAPE && tape_ok) group_tape_store<N>(p, b, t, e, tape);
-    }
-}
-
-#include "rollout_duo.h"
 
 #include "rollout_policy.h"
 
@@ -2073,11 +2005,6 @@ inline bool use_od_kernel(const cs_config *c, int flags) {
     return c->batch <= CS_OD_UPTO;
 }
 
-// 16-lanes-per-env rollout: the kinematics / detection wavefront pair pays while its two wavefronts per four envs still
-// find a SIMD each (1024 SIMDs x 2 wave slots at these register counts); teams of 7 and 8 spill in the pair.  Measured
-// crossover at 4096 envs (profiles/r02_batch_sweep.md; 3 agents at 4608 envs: pair 3.40 us per step, one-wavefront kernel
-// 3.18).
-inline bool duo_pays(const cs_config *c) { return c->n_agents <= 6 && c->batch <= 4096; }
 
 // Rows with at least this many twisted words ahead are left alone by the pre-pass of a T-step rollout: enough for the
 // typical draw rate (two words per draw, a few draws per step) with a step's worst case in reserve.  Short rollouts
@@ -2114,7 +2041,7 @@ int cs_abi_version(void) { return CS_ABI_VERSION; }
 #define CS_SOURCE_HASH ""
 #endif
 const char *cs_source_hash(void) { return CS_SOURCE_HASH; }
-int cs_has_legacy_kernels(void) { return CS_LEGACY_KERNELS; }
+int cs_has_legacy_kernels(void) { return 0; }   // (ABI 7 entry point; the kernels it asked about were removed in round 6)
 const char *cs_last_error(void) { return g_err; }
 
 int cs_state_layout(const cs_config *cfg, cs_layout *out) {
@@ -2289,21 +2216,9 @@ int cs_rollout(const cs_config *cfg, void *state_dev, const void *actions_dev, i
                       state_out_dev ? state_out_dev + (size_t)t0 * B * W : nullptr, flags, tc};
             CS_DISPATCH_N(cfg->n_agents, launch_lane<N>(cfg, p, it, lane_smem(cfg), s));
         }
-#if CS_LEGACY_KERNELS
-    } else if ((flags & CS_KERNEL_SOLO) || ((flags & CS_KERNEL_DUO) == 0 && !duo_pays(cfg))) {
-        io.min_ahead = prepass_min_ahead(cfg, T);   // rows are topped up in the kernels' prologue: no pre-pass launch
-        CS_DISPATCH_N(cfg->n_agents,
-                      hipLaunchKernelGGL(k_rollout<N>, dim3(env_blocks(p)), dim3(BLOCK), 0, (hipStream_t)stream, p, io));
-    } else {
-        // the pair tops rows up in place whenever one runs low (D's loop), so the prologue only has to cover one step
-        io.min_ahead = 2 * cfg->n_agents * CS_MAX_TARGETS;
-        CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL(k_rollout_duo<N>, dim3((unsigned)((p.B + DUO_ENVS - 1) / DUO_ENVS)), dim3(DUO_BLOCK),
-                                                        0, (hipStream_t)stream, p, io));
-    }
-#else
     } else if (flags & (CS_KERNEL_SOLO | CS_KERNEL_DUO)) {
-        return fail(CS_E_CONFIG, "k_rollout / k_rollout_duo (the 16-lanes-per-env rollout kernels of rounds 1-2) are not in this build: "
-                                 "compile with -DCS_LEGACY_KERNELS=1");
+        return fail(CS_E_CONFIG, "k_rollout / k_rollout_duo (the 16-lanes-per-env rollout kernels of rounds 1-2) were removed in round 6: "
+                                 "CS_KERNEL_GROUP runs a rollout as T launches of the 16-lane step kernel");
     } else {
         // CS_KERNEL_GROUP without the round-2 rollout kernels: T launches of the 16-lane step kernel, each on its own [t] slice
         hipStream_t s = (hipStream_t)stream;
@@ -2316,7 +2231,6 @@ int cs_rollout(const cs_config *cfg, void *state_dev, const void *actions_dev, i
             CS_DISPATCH_N(cfg->n_agents, hipLaunchKernelGGL((k_step<N, 0>), dim3(env_blocks(p)), dim3(BLOCK), 0, s, p, it));
         }
     }
-#endif
     return launched("cs_rollout");
 }
 

@@ -7,7 +7,7 @@
 //
 // In the octet kernel one wavefront walks the whole dependent chain of a step -- kinematics (~1800 cycles for 3 agents),
 // then detection + reward + rows (~1500) -- and at the batch sizes where every SIMD holds at most one or two wavefronts
-// nothing fills its stalls.  As in k_rollout_duo, the kinematics of step s + 1 need nothing from the detection pass of
+// nothing fills its stalls.  As in round 2's wavefront pair, the kinematics of step s + 1 need nothing from the detection pass of
 // step s (the actions are an open-loop table; the only coupling is a termination K cannot predict from the step counter:
 // an env finding its last target), so K runs AHEAD and leaves each step's positions in a ring of OD_RING LDS slots; D
 // consumes them.  A batch gets twice the wavefronts -- 4096 envs fill all 1024 SIMDs (the octet kernel: half of them) -- and
@@ -37,12 +37,6 @@
 #endif
 #ifndef CS_OD_RING_E3
 #define CS_OD_RING_E3 8   /* ring depth of the three-wavefront variant (measured at c2: 2 -> 2.74e9, 4 -> 3.07e9, 8 -> 3.15e9) */
-#endif
-// The 16-lanes-per-env ROLLOUT kernels of rounds 1-2 (k_rollout "solo", k_rollout_duo) are selected by no dispatch row any more
-// (DESIGN.md section 4); they stay in the source behind this switch for cross-kernel comparisons (CS_KERNEL_SOLO / CS_KERNEL_DUO then
-// work again) and cost 16 kernel instantiations of compile time.  Without them CS_KERNEL_GROUP rollouts are T launches of k_step.
-#ifndef CS_LEGACY_KERNELS
-#define CS_LEGACY_KERNELS 0
 #endif
 constexpr int OD_BLOCK = 128;
 // Teams from this size on divide the two components of a repulsion term with ONE reciprocal in K (div2_same_denominator: the same

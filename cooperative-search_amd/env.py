@@ -66,10 +66,8 @@ class BatchedFlightEnv:
     binding     "torch" (default): the calls go through torch.ops.coopsearch.* (csrc/torch_ops.cpp: tensor checks in C++,
                 torch's current HIP stream); "ctypes": straight to the C ABI with data_ptr()s -- same library, same
                 kernels, no torch in the call path
-    kernel      flight_easy only: "group" (16 lanes per env: lowest step latency, fills the chip from B = 4096; its
-                rollout picks between "solo" -- one wavefront per four envs does the whole step -- and "duo" -- a
-                kinematics wavefront and a detection wavefront per four envs, for batches that leave a wave slot per
-                SIMD empty), "oct" (rollout only: 8 lanes per env, lane t owns agent t and targets t, t + 8), "od"
+    kernel      flight_easy only: "group" (16 lanes per env: lowest step latency; a rollout is T launches of the step
+                kernel), "oct" (rollout only: 8 lanes per env, lane t owns agent t and targets t, t + 8), "od"
                 (rollout only: the octet layout with a kinematics wavefront running steps ahead of a detection
                 wavefront), "ode" ("od" with a third wavefront per 8 envs that writes the outputs), "lane" (one env per
                 lane: no replicated arithmetic, for large batches) or "lanev" (the second-generation lane-per-env kernel, teams of up to 5) or "auto" (rollout: "ode" up to
@@ -143,8 +141,8 @@ class BatchedFlightEnv:
             self._state = torch.zeros(B, self.state_shape, dtype=torch.float32, device=self.device)
             self._avail = torch.ones(B, self.n_actions, dtype=torch.float32, device=self.device)
             self._metrics = torch.zeros(4, dtype=torch.float64, device=self.device)
-        if kernel not in ("auto", "group", "lane", "lanev", "solo", "duo", "oct", "od", "ode"):
-            raise ValueError("kernel must be 'auto', 'group', 'lane', 'lanev', 'solo', 'duo', 'oct', 'od' or 'ode'")
+        if kernel not in ("auto", "group", "lane", "lanev", "oct", "od", "ode"):   # ("solo" / "duo", the 16-lane rollout kernels of rounds 1-2, were removed in round 6)
+            raise ValueError("kernel must be 'auto', 'group', 'lane', 'lanev', 'oct', 'od' or 'ode'")
         self.kernel = kernel
         self.freeze_done = bool(freeze_done)
         self.auto_reset = bool(auto_reset)
@@ -270,10 +268,6 @@ class BatchedFlightEnv:
             f |= _lib.OP_NO_CHECK_ACTIONS
         if self.kernel == "group":
             f |= _lib.KERNEL_GROUP
-        elif self.kernel == "solo":
-            f |= _lib.KERNEL_GROUP | _lib.KERNEL_SOLO
-        elif self.kernel == "duo":
-            f |= _lib.KERNEL_GROUP | _lib.KERNEL_DUO
         elif self.kernel == "lane":   # one env per lane, first generation (k_rollout_lane)
             f |= _lib.KERNEL_LANE
         elif self.kernel == "lanev":  # one env per lane, targets in registers (k_rollout_lanev; teams of up to 5)

@@ -65,10 +65,10 @@ enum {
     CS_KERNEL_GROUP = 8, /* flight_easy: force the 16-lanes-per-env kernels (the default of cs_step up to the lane kernels' range) */
     CS_KERNEL_LANE = 16, /* flight_easy: force the first-generation lane-per-env kernel (the default for teams of 6 to 8 at very
                             large batches; smaller teams get CS_KERNEL_LANEV's kernel); same results */
-    CS_KERNEL_SOLO = 32, /* cs_rollout, 16-lanes-per-env path: one wavefront per four envs does the whole step (this flag and the next:
-                            libraries built with -DCS_LEGACY_KERNELS=1 only, cs_has_legacy_kernels(); CS_E_CONFIG otherwise) */
-    CS_KERNEL_DUO = 64,  /* ... a kinematics wavefront and a detection wavefront per four envs (default up to 4096 envs
-                            of at most 6 agents, where the batch leaves a wave slot per SIMD empty); same results */
+    CS_KERNEL_SOLO = 32, /* (rounds 1-2: the 16-lanes-per-env ROLLOUT kernels, one wavefront or a kinematics / detection pair per four
+                            envs.  Removed in round 6 -- no dispatch row had selected them since round 3: cs_rollout answers this flag
+                            and the next with CS_E_CONFIG; the values stay reserved) */
+    CS_KERNEL_DUO = 64,
     CS_KERNEL_OCT = 128, /* cs_rollout, flight_easy: force the 8-lanes-per-env kernel (lane t owns agent t and targets t, t + 8;
                             nothing replicated but the header: four and more wavefronts per SIMD -- the default between
                             the pair kernel's range and the lane kernel's); same results */
@@ -176,9 +176,8 @@ int cs_abi_version(void);
 /* Hash of the sources this library was compiled from (cooperative-search_amd/build.py:source_hash; "" for a build that
  * did not pass it): how the loader tells a library built from other sources, instead of comparing file mtimes. */
 const char *cs_source_hash(void);
-/* 1 when the library holds the 16-lanes-per-env ROLLOUT kernels of rounds 1-2 (CS_KERNEL_SOLO / CS_KERNEL_DUO; built with
- * -DCS_LEGACY_KERNELS=1).  The default build does not: no dispatch row selects them, those two flags then make cs_rollout return
- * CS_E_CONFIG, and a CS_KERNEL_GROUP rollout is T launches of the 16-lane step kernel (same results). */
+/* 0 (since round 6: the 16-lanes-per-env ROLLOUT kernels of rounds 1-2 are gone; CS_KERNEL_SOLO / CS_KERNEL_DUO make cs_rollout
+ * return CS_E_CONFIG, a CS_KERNEL_GROUP rollout is T launches of the 16-lane step kernel).  Kept for ABI 7 callers. */
 int cs_has_legacy_kernels(void);
 const char *cs_last_error(void);
 

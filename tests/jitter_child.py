@@ -1,5 +1,5 @@
 """Child of tests/test_gpu_jitter.py: runs with COOPSEARCH_LIB pointing at one of its one-team-size builds (-DCS_JITTER,
--DCS_OD_SAFE_WAIT, -DCS_OD_ASYNC=0, -DCS_LEGACY_KERNELS=1 for teams of 3; -DCS_JITTER for teams of 5).  The octet pair
+-DCS_OD_SAFE_WAIT, -DCS_OD_ASYNC=0 for teams of 3; -DCS_JITTER and the wide-band pre-filter build for teams of 5).  The octet pair
 kernels (K + D, and K + D + E) -- their hand-shakes stretched by pseudo-random pauses -- against the 16-lane step kernel of the
 same library, bit for bit, on a scenario where nearly every episode ends with a win K could not predict (fix request, restore
 from the ring, redo, acknowledge: every other step) and on the shipped configuration."""
@@ -48,11 +48,8 @@ def run(kernel, args, B, lengths, mode):
 
 def main():
     name = os.path.basename(cs.lib.library_path())
-    assert name in ("jitter_n3.so", "odsafe_n3.so", "odsync_n3.so", "legacy_n3.so", "jitter_n5.so", "prewide_n5.so") or os.environ.get("CS_CHILD_ANY_LIB") == "1", cs.lib.library_path()
-    # legacy_n3.so (-DCS_LEGACY_KERNELS=1): the 16-lane rollout kernels of rounds 1-2, which the default build no longer holds
-    kernels = ("solo", "duo") if name == "legacy_n3.so" else (("od", "ode", "oct") if name == "prewide_n5.so" else ("od", "ode"))
-    if name == "legacy_n3.so":
-        assert cs.lib.has_legacy_kernels()
+    assert name in ("jitter_n3.so", "odsafe_n3.so", "odsync_n3.so", "jitter_n5.so", "prewide_n5.so") or os.environ.get("CS_CHILD_ANY_LIB") == "1", cs.lib.library_path()
+    kernels = ("od", "ode", "oct") if name == "prewide_n5.so" else ("od", "ode")
     for kernel in kernels:
         if name == "jitter_n5.so":   # a batch with a tail of 4 envs (the scalar-store variant beside the vector one)
             run(kernel, custom(), 1004, (30, 7), dict(freeze_done=False, auto_reset=True))

@@ -11,8 +11,6 @@
 If the shipped kernel ever read LDS before a request had landed, it would differ from the step kernel where these two do not.
 The three-wavefront variant's row refreshes run in its emitting wavefront (request / old tape meanwhile / adoption, CS_OD_E_REFRESH):
 the jitter build pauses at those hand-shakes too, and the child's last scenario makes every env refresh its row every few steps.
-  legacy_n3   -DCS_LEGACY_KERNELS=1  (round 5) k_rollout ("solo") and k_rollout_duo, the 16-lane rollout kernels of rounds 1-2 that no dispatch
-                                 row selects and the default build leaves out: the same scenarios, so they stay compiling and bit-exact.
   jitter_n5   -DCS_JITTER        (round 6; replaces round 5's build of the 5-lane packing, which is gone) the jitter build for teams of
                                  5: the pair kernels of BASELINE configs 3 and 5, whose detection pass tests in packed fp32 first.
   prewide_n5  -DCS_PREFILTER_EPS_SCALE=100.0f -DCS_OD_PREFILTER=2 -DCS_OCT_PREFILTER=1  (round 6) that pre-filter in ALL octet kernels (the
@@ -28,8 +26,6 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VARIANTS = {"jitter_n3": ["-DCS_JITTER"], "odsafe_n3": ["-DCS_OD_SAFE_WAIT"], "odsync_n3": ["-DCS_OD_ASYNC=0"],
-            # (round 5) the 16-lane rollout kernels of rounds 1-2, retired from the default build: kept compiling and bit-exact here
-            "legacy_n3": ["-DCS_LEGACY_KERNELS=1"],
             # (round 6) the jitter build for teams of 5 (BASELINE configs 3 / 5 run the 5-agent pair kernels)
             "jitter_n5": ["-DCS_JITTER"],
             # (round 6) the sensor pre-filter's band a hundred times wider: a tenth of the wavefront-steps redo the pass in fp64, the rest

@@ -51,13 +51,6 @@ def words(h):
 
 
 
-def _need_kernel(kernel):
-    """"solo" / "duo" are the 16-lane rollout kernels of rounds 1-2: in the library only when it was built with
-    -DCS_LEGACY_KERNELS=1 (no dispatch row selects them; include/coopsearch.h: cs_has_legacy_kernels)."""
-    if kernel in ("solo", "duo") and not _lib.has_legacy_kernels():
-        pytest.skip("built without the round-2 rollout kernels (-DCS_LEGACY_KERNELS=1)")
-
-
 GOLDEN_CASES = [(n, k) for n in trace_names() for k in (("group", "lane") if n.startswith("easy") else ("group",))]
 
 
@@ -211,7 +204,7 @@ def compare_with_oracle(env, ob, B, n, m, tag, check_pos=True):
             np.testing.assert_allclose(tg[b], tp, rtol=0, atol=1e-12, err_msg=f"{tag} env {b} targets")
 
 
-@pytest.mark.parametrize("kernel", ["group", "group-ondemand", "solo", "duo", "lane", "lanev"])
+@pytest.mark.parametrize("kernel", ["group", "group-ondemand", "lane", "lanev"])
 @pytest.mark.parametrize("variant,n,agent_mode,target_mode,B,T", [
     ("flight_easy", 3, 0, 0, 512, 200),
     ("flight_easy", 5, 0, 0, 256, 200),
@@ -224,7 +217,6 @@ def compare_with_oracle(env, ob, B, n, m, tag, check_pos=True):
 def test_batched_step_matches_oracle_bit_exact(variant, n, agent_mode, target_mode, B, T, kernel):
     """Frozen-when-done batch against B oracle envs, every step: outputs exact, raw state bit-identical.
     "group-ondemand": no periodic tape refresh, the step kernel twists every word it draws itself."""
-    _need_kernel(kernel)
     m = 15
     seeds = (777 + 13 * np.arange(B)).astype(np.uint32)
     args = cs.make_env_args(variant, n_agents=n, agent_mode=agent_mode, target_mode=target_mode)
@@ -251,9 +243,8 @@ def test_batched_step_matches_oracle_bit_exact(variant, n, agent_mode, target_mo
                 compare_with_oracle(env, ob, B, n, m, f"step {t}")
 
 
-@pytest.mark.parametrize("kernel", ["group", "group-ondemand", "solo", "duo", "lane", "lanev"])
+@pytest.mark.parametrize("kernel", ["group", "group-ondemand", "lane", "lanev"])
 def test_auto_reset_and_unfrozen_modes_match_oracle(kernel):
-    _need_kernel(kernel)
     B, n, m, T = 128, 5, 15, 420   # > 2 episodes per env
     seeds = np.arange(B, dtype=np.uint32) + 5
     args = cs.make_env_args("flight_easy", n_agents=n)
@@ -401,9 +392,8 @@ def test_octet_rollout_matches_oracle_bit_exact(variant, n, agent_mode, target_m
         assert hdr(env)[:, _lib.H_EPISODES].min() >= 2
 
 
-@pytest.mark.parametrize("kernel", ["group", "solo", "duo", "lane", "lanev", "oct", "od", "ode"])
+@pytest.mark.parametrize("kernel", ["group", "lane", "lanev", "oct", "od", "ode"])
 def test_rollout_kernel_equals_stepwise(kernel):
-    _need_kernel(kernel)
     B, n, T = 1000, 3, 200   # not a multiple of 64: exercises the partial last wavefront
     args = cs.make_env_args("flight_easy", n_agents=n)
     seeds = np.arange(B, dtype=np.uint32) + 99
@@ -677,7 +667,7 @@ def _custom_args(variant, **kw):
     return args
 
 
-@pytest.mark.parametrize("kernel", ["group", "solo", "duo", "lane", "lanev"])
+@pytest.mark.parametrize("kernel", ["group", "lane", "lanev"])
 @pytest.mark.parametrize("variant,kw", [
     ("flight_easy", dict(n_agents=8, target_num=16, target_mode=1)),             # maximum sizes: 8 x 16 pairs, 2-phase draws
     ("flight_easy", dict(n_agents=7, target_num=16, target_mode=1, view_range=30)),  # nearly every pair in range: > 7 draws/step
@@ -689,7 +679,6 @@ def _custom_args(variant, **kw):
     ("flight_easy", dict(n_agents=3, time_limit=7)),                             # many episode boundaries
 ])
 def test_unusual_configurations_match_oracle(variant, kw, kernel):
-    _need_kernel(kernel)
     B, T, kw = 96, 90, dict(kw)
     args = _custom_args(variant, **kw)
     n, m = args.n_agents, args.target_num
@@ -878,12 +867,11 @@ def test_flight_rollout_call_equals_stepwise(B, n, T):
         assert torch.equal(r1[k], r2[k]), k
 
 
-@pytest.mark.parametrize("kernel", ["group", "solo", "duo", "lane", "lanev", "oct", "od", "ode"])
+@pytest.mark.parametrize("kernel", ["group", "lane", "lanev", "oct", "od", "ode"])
 def test_long_horizon_matches_oracle(kernel):
     """20 000 steps per env with auto-reset: ~100+ episodes, the circular MT19937 state wraps ~70 times (cursor,
     mirrored head, reset-time batches landing anywhere in the ring).  Rewards are compared every step (in rollout
     chunks), the full raw state at the end."""
-    _need_kernel(kernel)
     B, n, m, chunk, chunks = 64, 3, 15, 250, 80
     seeds = np.arange(B, dtype=np.uint32) * 7 + 5
     env = cs.BatchedFlightEnv(cs.make_env_args("flight_easy", n_agents=n), batch=B, seeds=seeds, freeze_done=False,
@@ -1081,6 +1069,26 @@ def test_check_actions_refuses_out_of_range_values_like_the_reference(binding, c
     # when the caller has not decided)
     off = cs.BatchedFlightEnv(cs.make_env_args(variant, n_agents=n), batch=8, binding=binding, check_actions=False)
     off.step(torch.full((8, n), 3, dtype=torch.int64, device="cuda"))   # no IndexError: acts as action 0
+
+
+@pytest.mark.parametrize("flag", ["KERNEL_SOLO", "KERNEL_DUO"])
+def test_removed_rollout_kernels_are_refused_not_rerouted(flag):
+    """CS_KERNEL_SOLO / CS_KERNEL_DUO named the 16-lane rollout kernels of rounds 1-2, removed in round 6: cs_rollout answers them
+    with CS_E_CONFIG at every batch size (a forced kernel must never silently become another one -- at 65536 envs the
+    request used to fall into the lane kernel's branch), the env untouched; cs_has_legacy_kernels() says 0."""
+    assert not _lib.has_legacy_kernels()
+    for B in (64, 65536):
+        env = cs.BatchedFlightEnv(cs.make_env_args("flight_easy", n_agents=3), batch=B, binding="ctypes", kernel="group")
+        plain = env._flags
+        env._flags = lambda a: plain(a) | getattr(_lib, flag)
+        before = env.raw()["agent"].clone()
+        acts = torch.zeros(4, B, 3, dtype=torch.int32, device="cuda")
+        with pytest.raises(_lib.CoopSearchError, match="removed in round 6"):
+            env.rollout(acts)
+        assert torch.equal(env.raw()["agent"], before)
+        env._flags = plain
+        env.rollout(acts)   # "group" itself: T launches of the step kernel
+        assert not torch.equal(env.raw()["agent"], before)
 
 
 def test_render_of_one_env_of_the_batch(tmp_path):

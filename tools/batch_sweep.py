@@ -1,5 +1,5 @@
 """Batch sweep of the flight_easy rollout kernels (SURVEY.md section 8d asks for 2^12..2^22): env-steps/s and the
-algorithmic-bytes roofline fraction per batch size: the 16-lane kernels of rounds 1-2 (solo / duo), the octet kernels (ode:
+algorithmic-bytes roofline fraction per batch size: the octet kernels (ode:
 kinematics, detection and emitting wavefront per 8 envs; od: kinematics and detection wavefront; oct: one wavefront per 8 envs)
 and the lane-per-env kernels (lane: round 2's, lanev: round 4's).  Writes a markdown table."""
 import json, subprocess, sys, os
@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rows = []
 for n in (3, 5):
     for B in (1024, 2048, 4096, 8192, 16384, 32768, 65536, 262144, 1048576, 4194304):
-        for kernel in ("ode", "od", "oct", "lane", "lanev"):   # (solo / duo, rounds 1-2: -DCS_LEGACY_KERNELS=1 builds only; profiles/r04_batch_sweep.md has them)
+        for kernel in ("ode", "od", "oct", "lane", "lanev"):   # (the 16-lane rollout kernels of rounds 1-2 are gone: profiles/r04_batch_sweep.md has them)
             if kernel in ("lane", "lanev") and B < 16384:
                 continue
             if kernel in ("od", "oct") and B > (1 << 20):
