@@ -39,12 +39,16 @@
 #define CS_OD_RING_E3 8   /* ring depth of the three-wavefront variant (measured at c2: 2 -> 2.74e9, 4 -> 3.07e9, 8 -> 3.15e9) */
 #endif
 constexpr int OD_BLOCK = 128;
-// Teams from this size on divide the two components of a repulsion term with ONE reciprocal in K (div2_same_denominator: the same
-// quotients bit for bit).  Small teams keep the plain divisions: K is alone on its SIMD there and the range check in front of the
-// shared sequence lengthens its chain (c2: -1.9 %, round 4); large teams run four wavefronts per SIMD at the VALU issue limit,
-// where only the instruction count matters.
+// K divides the two components of a repulsion term with ONE reciprocal (div2_same_denominator: the same quotients bit for bit) where it
+// measured faster.  Small teams keep the plain divisions: K is alone on its SIMD there and the range check in front of the shared
+// sequence lengthens its chain (c2: -1.9 %, round 4).  The PAIR variant at 5 agents: no difference (round 5: 3.432 -> 3.438 us per step
+// at 16384 envs; round 6: 3.173 / 3.204 -> 3.203 / 3.194).  The THREE-WAVEFRONT variant at 5 agents: 1.962 -> 1.935 (round 5), 1.975 /
+// 1.981 -> 1.909 / 1.941 us per step at 8192 envs (round 6, profiles/r06_knob_sweep.log): on from teams of CS_ODE_SHARED_DIV_FROM_N.
 #ifndef CS_OD_SHARED_DIV_FROM_N
-#define CS_OD_SHARED_DIV_FROM_N 99
+#define CS_OD_SHARED_DIV_FROM_N 99   /* pair variant */
+#endif
+#ifndef CS_ODE_SHARED_DIV_FROM_N
+#define CS_ODE_SHARED_DIV_FROM_N 5   /* three-wavefront variant */
 #endif
 // steps K may be ahead of D (power of two).  The pair variant serves up to 16384 envs with eight workgroups per CU: 20 KB of LDS each,
 // four slots.  The three-wavefront variant stops at 8192 envs = four workgroups per CU, so its ring can be eight deep (30 KB + E's row buffer):
@@ -291,7 +295,7 @@ __device__ __forceinline__ void rollout_od_body(const DevParams &p, const StepIO
 #ifdef CS_OD_ABL_NOKIN   /* experiment: what D alone sustains */
             const unsigned out = 0u;
 #else
-            const unsigned out = oct_kinematics<N, (N >= CS_OD_SHARED_DIV_FROM_N), LG, AP>(p, T, sh.kpos, o, t, sh8, stepping, a, e, sp);
+            const unsigned out = oct_kinematics<N, (N >= (E3 ? CS_ODE_SHARED_DIV_FROM_N : CS_OD_SHARED_DIV_FROM_N)), LG, AP>(p, T, sh.kpos, o, t, sh8, stepping, a, e, sp);
 #endif
             KIN_STAMP_SP(6);
             between();
