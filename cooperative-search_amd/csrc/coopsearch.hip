@@ -243,9 +243,7 @@ struct RowRegs {
 
 __device__ __forceinline__ void row_load(const unsigned *m, int lane, RowRegs &r) {
 #pragma unroll
-    for (int i = 0; i < 10; i++) r.w[i] = m[lane + 64 * i];   // (unconditional: the tenth column reaches words 576..639, inside the row's 672;
-                                                               //  a predicated load with a zero default is a VALU write to a register that
-                                                               //  may still have a load in flight: the compiler waits for it, stores and all)
+    for (int i = 0; i < 10; i++) r.w[i] = m[lane + 64 * i];   // (unconditional: the tenth column reaches words 576..639, inside the row's 672)
 }
 
 // row registers -> LDS (`row`: 624 words owned by this wavefront)
@@ -1899,8 +1897,6 @@ template <int N>
 void launch_lanev(const cs_config *cfg, const DevParams &p, StepIO io, hipStream_t s) {
     const size_t W = 4 * (size_t)cfg->n_agents + 3 * (size_t)cfg->n_targets;
     const size_t smem = LV_HEAD_BYTES + (LV_BLOCK / 64) * lv_wave_bytes((int)W, cfg->n_agents);
-    // (the VEC launch of the two-wavefront build, teams of up to 5: + the refresh row's landing buffer, CS_LV_DMA)
-    const size_t smem_vec2 = LV_HEAD_BYTES + (LV_BLOCK / 64) * lv_wave_bytes((int)W, cfg->n_agents, CS_LV_DMA != 0 && N <= 5);
     const bool aligned = io.state && io.obs && (reinterpret_cast<size_t>(io.state) & 15) == 0 &&
                          (reinterpret_cast<size_t>(io.obs) & 15) == 0 && ((size_t)p.B * W) % 4 == 0;
     const int full = aligned ? (p.B / 64) * 64 : 0;
@@ -1911,9 +1907,9 @@ void launch_lanev(const cs_config *cfg, const DevParams &p, StepIO io, hipStream
             if (full >= CS_LV_W_FROM)   // three wavefronts per SIMD (see k_rollout_lanev)
                 hipLaunchKernelGGL((k_rollout_lanev<N, true, 3>), dim3((unsigned)((full + LV_BLOCK - 1) / LV_BLOCK)), dim3(LV_BLOCK), smem, s, p, io);
             else
-                hipLaunchKernelGGL((k_rollout_lanev<N, true>), dim3((unsigned)((full + LV_BLOCK - 1) / LV_BLOCK)), dim3(LV_BLOCK), smem_vec2, s, p, io);
+                hipLaunchKernelGGL((k_rollout_lanev<N, true>), dim3((unsigned)((full + LV_BLOCK - 1) / LV_BLOCK)), dim3(LV_BLOCK), smem, s, p, io);
         } else {
-            hipLaunchKernelGGL((k_rollout_lanev<N, true>), dim3((unsigned)((full + LV_BLOCK - 1) / LV_BLOCK)), dim3(LV_BLOCK), smem_vec2, s, p, io);
+            hipLaunchKernelGGL((k_rollout_lanev<N, true>), dim3((unsigned)((full + LV_BLOCK - 1) / LV_BLOCK)), dim3(LV_BLOCK), smem, s, p, io);
         }
     }
     if (p.B - full > 0) {

@@ -36,9 +36,6 @@
 // and ~240 at 5; capped at 168 (three wavefronts) the 3-agent variant spills 23 registers and runs 40.6 % of the HBM roofline at
 // 2^18 envs against 44.0 % uncapped (4096 wavefronts = 1.33 resident rounds instead of 2 full ones) but 49.3 % against 46.0 % at
 // 2^20; the 5-agent variant spills 670 and halves.  So: two.
-#ifndef CS_LV_DMA
-#define CS_LV_DMA 0   /* the refresh row requested a step ahead straight into LDS, counted wait (see k_rollout_lanev) */
-#endif
 #ifndef CS_LV_WAVES_SMALL
 #define CS_LV_WAVES_SMALL 2   /* teams of up to 3 */
 #endif
@@ -91,16 +88,12 @@ struct EnvV {
 
 // bytes of LDS per wavefront: the staging piece (aliased by the MT19937 row of the in-loop refresh and by the wavefront's block
 // of observations on its way out) + the reset hand-over + the hit tapes
-__host__ __device__ inline size_t lv_union_bytes(int W, int n_agents) {
+__host__ __device__ inline size_t lv_wave_bytes(int W, int n_agents) {
     size_t piece = (size_t)LV_PIECE * W * sizeof(float), row = (size_t)MT_N * sizeof(unsigned);
     size_t obs = (size_t)64 * n_agents * 4 * sizeof(float);
     size_t u = piece > row ? piece : row;
     u = u > obs ? u : obs;
-    return (u + 15) / 16 * 16;
-}
-constexpr size_t LV_DMA_BYTES = 10 * 64 * sizeof(unsigned);   // the refresh row on its way in (ten dword columns of 64 lanes), CS_LV_DMA
-__host__ __device__ inline size_t lv_wave_bytes(int W, int n_agents, bool dma = false) {
-    return lv_union_bytes(W, n_agents) + (dma ? LV_DMA_BYTES : 0) + LV_SLOT_FLOATS * sizeof(float) + LV_TAPE_ROWS * 64 * sizeof(unsigned);
+    return (u + 15) / 16 * 16 + LV_SLOT_FLOATS * sizeof(float) + LV_TAPE_ROWS * 64 * sizeof(unsigned);
 }
 constexpr size_t LV_HEAD_BYTES = ((TRIG_ROWS * TRIG_COLS * 8 + 15) / 16) * 16 + 4 * G * sizeof(double);   // trig table | reset tables
 
@@ -162,11 +155,12 @@ __device__ __forceinline__ void kinematics_v(const DevParams &p, const double *T
 // The hit tapes of the wavefront's envs sit in LDS (`tl`: [LV_TAPE_ROWS][64] dwords, lane l's tape in column l) with a
 // per-lane cursor `tpos` (draw slots consumed since the tape was written) instead of ten registers that are barrel-shifted
 // after every step: a step reads the few dwords at its cursor (one bank per lane: conflict-free) and adds to tpos.
-// (the row already in LDS -- `rowbuf`, 624 words in row order: lv_advance_finish below, or the DMA buffer of CS_LV_DMA)
 template <class EnvT>
-__device__ __forceinline__ void lv_advance_finish_lds(const DevParams &p, int b0, int lane, int src, unsigned *rowbuf, EnvT &e, unsigned *tl,
-                                                      int &tpos, int s = 64) {
-    (void)s;   // (timeline builds: the step the stamps belong to)
+__device__ __forceinline__ void lv_advance_finish(const DevParams &p, int b0, int lane, int src, const RowRegs &rr, unsigned *rowbuf,
+                                                  EnvT &e, unsigned *tl, int &tpos, int s = 64) {
+    (void)s;   // (timeline builds, tools/lanev_timeline.py: the step the stamps belong to)
+    LANE_STAMP(9);
+    row_to_lds(rr, rowbuf, lane);
     const int pos = __shfl(e.mt_pos, src);
     const int a = __shfl(e.ahead, src);
     LANE_STAMP(10);
@@ -187,13 +181,6 @@ __device__ __forceinline__ void lv_advance_finish_lds(const DevParams &p, int b0
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();   // the buffer is free again (it aliases the staging piece)
     LANE_STAMP(12);
-}
-template <class EnvT>
-__device__ __forceinline__ void lv_advance_finish(const DevParams &p, int b0, int lane, int src, const RowRegs &rr, unsigned *rowbuf,
-                                                  EnvT &e, unsigned *tl, int &tpos, int s = 64) {
-    LANE_STAMP(9);
-    row_to_lds(rr, rowbuf, lane);
-    lv_advance_finish_lds(p, b0, lane, src, rowbuf, e, tl, tpos, s);
 }
 template <class EnvT>
 __device__ __forceinline__ void lv_advance_now(const DevParams &p, int b0, int lane, unsigned long long need, unsigned *rowbuf, EnvT &e,
@@ -221,19 +208,10 @@ __global__ __launch_bounds__(LV_BLOCK, WV) void k_rollout_lanev(DevParams p, Ste
     const int W = 4 * N + 3 * p.n_targets;
     int lane = threadIdx.x & 63;   // (made opaque once per step, see the loop)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // CS_LV_DMA (round 6; VEC launches of the two-wavefront builds, teams of up to 5): the refresh row is requested a step AHEAD, before
-    // the previous step's output stores, straight into LDS (global_load_lds: no registers across the step), and waited for with a COUNTED
-    // s_waitcnt that leaves exactly that step's stores in flight.  gfx9 retires loads and stores through one in-order counter: a row
-    // requested behind a step's stores (round 4's order: after the kinematics) arrives only once they have drained -- 840 cycles of wait
-    // per wavefront-step at 65 536 envs and 2 000-3 000 at 2^18 envs, where the write stream is saturated
-    // (profiles/r06_lanev5_timeline.log); requested by plain loads a step ahead the compiler's own wait is vmcnt(9) -- the minimum over
-    // all paths, i.e. the first iteration's, which drains the stores just the same (measured: no gain).
-    constexpr bool DMA = CS_LV_DMA != 0 && VEC && WV == 2 && N <= 5;
-    char *wbase = smem + LV_HEAD_BYTES + (size_t)wave * lv_wave_bytes(W, N, DMA);
+    char *wbase = smem + LV_HEAD_BYTES + (size_t)wave * lv_wave_bytes(W, N);
     float *piece = reinterpret_cast<float *>(wbase);                // [LV_PIECE][W] get_state rows of half the wavefront ...
     unsigned *rowbuf = reinterpret_cast<unsigned *>(wbase);         // ... or one MT19937 row (in-loop refresh): never live together
-    unsigned *dmabuf = reinterpret_cast<unsigned *>(wbase + lv_union_bytes(W, N));   // DMA: the row requested for the next step
-    unsigned *tl = reinterpret_cast<unsigned *>(wbase + lv_wave_bytes(W, N, DMA) - LV_TAPE_ROWS * 64 * sizeof(unsigned));   // hit tapes, [dword][lane]
+    unsigned *tl = reinterpret_cast<unsigned *>(wbase + lv_wave_bytes(W, N) - LV_TAPE_ROWS * 64 * sizeof(unsigned));   // hit tapes, [dword][lane]
     float2 *slots = reinterpret_cast<float2 *>(reinterpret_cast<char *>(tl) - LV_SLOT_FLOATS * sizeof(float));      // [4][G] reset hand-over
     const int b = io.env0 + blockIdx.x * LV_BLOCK + threadIdx.x;
     const int b0 = b - lane;  // first env of this wavefront
@@ -305,40 +283,6 @@ __global__ __launch_bounds__(LV_BLOCK, WV) void k_rollout_lanev(DevParams p, Ste
     }
     int act[N], act_next[N];
     load_actions<N>(io, arow, act_next);
-    // ---- in-loop refresh: each step tops up ONE env of the wavefront, the one running lowest on twisted words: the row is twisted and
-    //      re-taped after the draws of the step.  Requested after the kinematics of the same step into ten registers (round 4), or --
-    //      DMA, see above -- at the end of the previous step straight into LDS.  A row requested a step ahead is dropped if its env is
-    //      reset or topped up on the spot before it is used (both rewrite the row in memory).
-    RowRegs rr;
-    int cand = -1;
-    auto pick_row = [&]() __attribute__((always_inline)) {
-        constexpr int URGENT = LOW + 64, NORMAL = CS_LV_NORMAL > LOW + 128 ? CS_LV_NORMAL : LOW + 128;
-        const unsigned long long urgent = __ballot(e.ahead < URGENT), normal = __ballot(e.ahead < NORMAL);
-        cand = urgent ? __ffsll((long long)urgent) - 1 : (normal ? __ffsll((long long)normal) - 1 : -1);
-    };
-    auto request_row = [&]() __attribute__((always_inline)) {
-        pick_row();
-        if (cand >= 0) row_load(p.mt + (size_t)(b0 + cand) * MT_STRIDE, lane, rr);
-    };
-    auto request_row_dma = [&]() __attribute__((always_inline)) {
-        pick_row();
-        if (cand >= 0) {   // wave-uniform
-            const unsigned *m = p.mt + (size_t)(b0 + cand) * MT_STRIDE;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wavefront's own reads of the buffer (the refresh just finished) are through
-#pragma unroll
-            for (int i = 0; i < 10; i++)   // (the tenth column reaches words 576..639: inside the row's 672, mirror included)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(m + lane + 64 * i),
-                                                 (__attribute__((address_space(3))) void *)(dmabuf + 64 * i), 4, 0, 0);
-        }
-    };
-    // The stores of one VEC step, each ONE instruction, none conditional (reward, terminated, win | N coalesced observation stores |
-    // 2 x QP float4 chunks of get_state rows): what may still be in flight when the row requested before them is waited for.
-    constexpr int W_MAX_ = 4 * N + 3 * CS_MAX_TARGETS;
-    constexpr int STEP_STORES = 3 + N + 2 * ((LV_PIECE * W_MAX_ / 4 + 63) / 64);
-    static_assert(!DMA || STEP_STORES <= 63, "vmcnt is a six-bit counter");
-    if (DMA) {
-        request_row_dma();   // step 0's: nothing but loads behind it, so step 0 waits for it with a full drain (below)
-    }
     const int rows_valid = b_end - b0 < 64 ? b_end - b0 : 64;
     constexpr int W_MAX = 4 * N + 3 * CS_MAX_TARGETS;
     constexpr int QP = (LV_PIECE * W_MAX / 4 + 63) / 64;   // float4 chunks per lane of the largest piece
@@ -497,9 +441,6 @@ __global__ __launch_bounds__(LV_BLOCK, WV) void k_rollout_lanev(DevParams p, Ste
             // a reset that ran past the twisted words leaves its lane without a tape for this step: rebuild
             const unsigned long long low = __ballot(e.ahead < LOW);
             if (low) lv_advance_now(p, b0, lane, low, rowbuf, e, tl, tpos);
-            // (a row requested a step ahead for an env that was just reset or topped up is stale: the reset's generic path and the
-            // top-up store words of that row)
-            if (DMA && cand >= 0 && (((need | low) >> cand) & 1ull)) cand = -1;
             drain_vmem();
         }
         int reward = 0;
@@ -507,13 +448,23 @@ __global__ __launch_bounds__(LV_BLOCK, WV) void k_rollout_lanev(DevParams p, Ste
         const bool stepping = live && !(done && freeze);
         LANE_STAMP(1);
         e.flags &= ~(FLAG_DIRTY | FLAG_RESET_PASS);
+        // ---- in-loop refresh, first half: the row of the env running lowest on twisted words is requested after the kinematics
+        //      and twisted after the draws of this step (each env comes round about every 64 steps)
 #ifndef CS_LV_REFRESH_EARLY
-#define CS_LV_REFRESH_EARLY 0   /* (three-wavefront build) request the refresh row BEFORE the kinematics instead of after them: measured on
-                                   one box, two runs each (tools/gpu_r4_g.sh): 5 agents no difference, 3 agents -2..-3 % */
+#define CS_LV_REFRESH_EARLY 0   /* request the refresh row BEFORE the kinematics instead of after them: measured on one box, two
+                                   runs each (tools/gpu_r4_g.sh): 5 agents no difference, 3 agents -2..-3 % */
 #endif
-        if (!DMA && CS_LV_REFRESH_EARLY) request_row();
+        RowRegs rr;
+        int cand;
+        auto request_row = [&]() __attribute__((always_inline)) {
+            constexpr int URGENT = LOW + 64, NORMAL = CS_LV_NORMAL > LOW + 128 ? CS_LV_NORMAL : LOW + 128;
+            const unsigned long long urgent = __ballot(e.ahead < URGENT), normal = __ballot(e.ahead < NORMAL);
+            cand = urgent ? __ffsll((long long)urgent) - 1 : (normal ? __ffsll((long long)normal) - 1 : -1);
+            if (cand >= 0) row_load(p.mt + (size_t)(b0 + cand) * MT_STRIDE, lane, rr);
+        };
+        if (CS_LV_REFRESH_EARLY) request_row();
         if (stepping) kinematics_v<N>(p, T, act, e);
-        if (!DMA && !CS_LV_REFRESH_EARLY) request_row();
+        if (!CS_LV_REFRESH_EARLY) request_row();
         LANE_STAMP(2);
         // ---- the agents' floats (get_obs / get_state)
         float fx[N], fy[N];
@@ -656,33 +607,14 @@ __global__ __launch_bounds__(LV_BLOCK, WV) void k_rollout_lanev(DevParams p, Ste
         // ---- in-loop refresh, second half (wave-uniform): the row has long arrived; its new tape goes to the env's lane
         if (cand >= 0) {
             LV_COUNT(5);
-            if (DMA) {
-                LANE_STAMP(9);
-                // everything issued BEFORE the previous step's STEP_STORES stores has retired once no more than that many operations
-                // are in flight (one in-order counter; extra operations of rare paths only make the wait longer).  Step 0's request
-                // has no stores behind it: full drain.  -DCS_LV_SAFE_WAIT: always a full drain (tests/test_gpu_jitter.py: lvsafe_n5).
-#ifdef CS_LV_SAFE_WAIT
-                drain_vmem();
-#else
-                if (s == 0) drain_vmem();
-                else __builtin_amdgcn_s_waitcnt(0x0F70 | (STEP_STORES & 15) | ((STEP_STORES >> 4) << 14));   // vmcnt(STEP_STORES), lgkmcnt / expcnt untouched
-#endif
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                lv_advance_finish_lds(p, b0, lane, cand, dmabuf, e, tl, tpos, s);
-            } else {
-                lv_advance_finish(p, b0, lane, cand, rr, rowbuf, e, tl, tpos, s);
-            }
+            lv_advance_finish(p, b0, lane, cand, rr, rowbuf, e, tl, tpos, s);
         }
         LANE_STAMP(13);
         {   // a lane that cannot wait for its turn (several running low at once): on the spot
             const unsigned long long low = __ballot(e.ahead < LOW);
             if (__builtin_expect(low != 0ull, 0)) lv_advance_now(p, b0, lane, low, rowbuf, e, tl, tpos);
         }
-        // ---- the next step's refresh row and actions, requested BEFORE this step's stores
-        if (DMA) {
-            cand = -1;
-            if (s + 1 < io.T) request_row_dma();
-        }
+        // ---- the next step's actions, requested BEFORE this step's stores
         load_actions<N>(io, (size_t)(s + 1 < io.T ? s + 1 : s) * p.B + arow, act_next);
         LANE_STAMP(6);
         // ---- this step's outputs
