@@ -137,7 +137,8 @@ def compact_line(full, detail_path=None):
     if "roofline" in full:
         r = full["roofline"]
         line["roofline"] = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel",
-                                             "algorithmic_bytes_per_env_step", "algorithmic_bytes_per_launch", "avg_launch_us")
+                                             "algorithmic_bytes_per_env_step", "algorithmic_bytes_per_launch", "avg_launch_us",
+                                             "context")
                             if k in r}
         src = r.get("traffic_source")
         line["roofline"]["traffic_source"] = src.split(":")[0] + " (committed --pmc passes, scaled)" if src else None
@@ -737,7 +738,10 @@ def run_workload(cs, dev, comm, env_name, n, B, mode, K, W, kernel, rank=0, no_g
                      "algorithmic_bytes_per_env_step": alg,
                      "algorithmic_bytes_per_launch": alg * B * steps_per_launch,
                      "avg_launch_us": t_ev / (K / steps_per_launch) * 1e6,
-                     "timing": "median HIP-event interval of the K-step region on the launch stream / launches"},
+                     "timing": "median HIP-event interval of the K-step region on the launch stream / launches",
+                     # (peak is the contract's 8 TB/s; what the part was measured to sustain, for scale)
+                     "context": "peak = HBM3E spec; measured on MI355X (tools/probe_write_bw.hip, profiles/r06_write_bw.log): read 6.2-6.4, "
+                                "copy 4.6-5.4, pure write 4.1-5.4 TB/s; this path writes >= 90 % of its bytes"},
     }
     return res, env
 
