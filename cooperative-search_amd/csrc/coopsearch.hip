@@ -208,6 +208,9 @@ __device__ __forceinline__ bool draw_hits(const DevParams &p, unsigned wa, unsig
 // the cursor -- words pos + a .. pos + 623 -- in place, and store the new words to the state blob `m` (mirror included).
 // Super-batches of 192 words: word j needs the stored words j, j+1, j+397, none of which another word of the same
 // super-batch writes (192 <= 227); within a wavefront LDS operations complete in order.
+// LEAN (the lane kernel's in-loop refresh, which counts no stores): the mirror of words 0..31 is stored only by the lanes that hold one --
+// mt_store's unconditional second store doubles the twist's store instructions for the sake of callers whose waits count them.
+template <bool LEAN = false>
 __device__ __forceinline__ void row_twist_ahead(unsigned *row, unsigned *m, int pos, int a, int lane) {
     while (a < MT_N) {   // wave-uniform
         const int r = MT_N - a < 192 ? MT_N - a : 192;
@@ -227,7 +230,12 @@ __device__ __forceinline__ void row_twist_ahead(unsigned *row, unsigned *m, int 
         for (int c = 0; c < 3; c++) {
             if (64 * c + lane < r) {
                 row[idx[c]] = nw[c];
-                mt_store(m, idx[c], nw[c]);
+                if (LEAN) {
+                    m[idx[c]] = nw[c];
+                    if (idx[c] < MT_PAD) m[MT_N + idx[c]] = nw[c];
+                } else {
+                    mt_store(m, idx[c], nw[c]);
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -255,16 +263,40 @@ __device__ __forceinline__ void row_to_lds(const RowRegs &r, unsigned *row, int 
     __builtin_amdgcn_wave_barrier();
 }
 
-// hit bits of draw slots 64 * it .. 64 * it + 63 from the cursor of a fully twisted row in LDS (slot r = words pos + 2r,
-// pos + 2r + 1; pos is even, so the pair never straddles the end of the row)
-__device__ __forceinline__ unsigned long long row_slot_hits(const DevParams &p, const unsigned *row, int pos, int it, int lane) {
-    const int r = 64 * it + lane;
-    bool hit = false;
-    if (2 * r < MT_N) {
-        const int i0 = wrap624(pos + 2 * r);
-        hit = draw_hits(p, row[i0], row[i0 + 1]);
+// All 312 hit bits of a fully twisted row in LDS: bm[it] = hit bits of draw slots 64 it .. 64 it + 63 from the cursor (slot r = words
+// pos + 2r, pos + 2r + 1; pos is even, so the pair never straddles the end of the row), arranged for a wavefront that has nothing
+// else to overlap the latency with (round 6; the lane kernel refreshes a row every wavefront-step at 5 agents, 2 000 cycles of it in
+// this loop: profiles/r06_lanev5_timeline.log): the five word pairs are loaded first (the first version, one 64-slot group per call,
+// left an LDS write of the caller between consecutive reads, i.e. five round trips in series), the first word decides in straight-line code, and the
+// second word -- needed only when the first one's 27 bits equal the threshold's, 2^-27 of the draws -- sits behind ONE wave-uniform
+// test instead of a divergent branch per slot.
+__device__ __forceinline__ void row_hits_all(const DevParams &p, const unsigned *row, int pos, int lane, unsigned long long (&bm)[TAPE_DW / 2]) {
+    constexpr int NIT = TAPE_DW / 2;
+    unsigned wa[NIT], wb[NIT];
+    bool valid[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int r = 64 * it + lane;
+        valid[it] = 2 * r < MT_N;
+        const int i0 = wrap624(pos + (valid[it] ? 2 * r : 0));   // (even: the pair is 8-byte aligned and never straddles the end)
+        const U2 w = *reinterpret_cast<const U2 *>(row + i0);
+        wa[it] = w.x;
+        wb[it] = w.y;
     }
-    return __ballot(hit);
+    const unsigned khi = (unsigned)(p.detect_K >> 26);
+    bool lt[NIT], eq_any = false;
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const unsigned hi = mt_temper(wa[it]) >> 5;   // u = (a >> 5) * 2^26 + (b >> 6) <= K: decided by the first word unless hi == khi
+        lt[it] = hi < khi;
+        eq_any = eq_any | (valid[it] & (hi == khi));
+    }
+    if (__builtin_expect(__ballot(eq_any) != 0ull, 0)) {   // wave-uniform, 2^-27 per draw: the exact comparison for everyone
+#pragma unroll
+        for (int it = 0; it < NIT; it++) lt[it] = draw_hits(p, wa[it], wb[it]);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; it++) bm[it] = __ballot(valid[it] & lt[it]);
 }
 
 // The hit tape of one lane: bit r = "draw slot r from the cursor hits".  Shift by n slots (n < 320), dword barrel first.
@@ -653,12 +685,13 @@ __device__ __forceinline__ void group_wave_advance(const DevParams &p, int wave_
         row_load(m, lane, rr);
         row_to_lds(rr, rowbuf, lane);
         row_twist_ahead(rowbuf, m, pos, a < 0 ? 0 : a, lane);
+        unsigned long long bm[TAPE_DW / 2];
+        row_hits_all(p, rowbuf, pos, lane, bm);
 #pragma unroll
         for (int it = 0; it < TAPE_DW / 2; it++) {
-            const unsigned long long bm = row_slot_hits(p, rowbuf, pos, it, lane);
             if (grp == g) {
-                tape[2 * it] = (unsigned)(bm & 0xffffffffull);
-                tape[2 * it + 1] = (unsigned)(bm >> 32);
+                tape[2 * it] = (unsigned)(bm[it] & 0xffffffffull);
+                tape[2 * it + 1] = (unsigned)(bm[it] >> 32);
             }
         }
         if (grp == g) {
@@ -1606,11 +1639,11 @@ __global__ __launch_bounds__(256) void k_mt_advance(DevParams p, int min_ahead) 
     row_twist_ahead(row, m, pos, a, lane);
     // hit tape: bit r = "the draw made of stream words 2r, 2r + 1 from the cursor hits" for all 312 slots of the row
     unsigned *tp = p.tape + (size_t)b * TAPE_STRIDE;
+    unsigned long long bm[TAPE_DW / 2];
+    row_hits_all(p, row, pos, lane, bm);
 #pragma unroll
-    for (int it = 0; it < TAPE_DW / 2; it++) {
-        const unsigned long long bm = row_slot_hits(p, row, pos, it, lane);
-        if (lane == 0) *reinterpret_cast<U2 *>(tp + 2 * it) = U2{(unsigned)(bm & 0xffffffffull), (unsigned)(bm >> 32)};
-    }
+    for (int it = 0; it < TAPE_DW / 2; it++)
+        if (lane == 0) *reinterpret_cast<U2 *>(tp + 2 * it) = U2{(unsigned)(bm[it] & 0xffffffffull), (unsigned)(bm[it] >> 32)};
     if (lane == 0) {
         const int *h = p.hdr + (size_t)b * CS_H_WORDS;
         *reinterpret_cast<U2 *>(tp + 10) = U2{(unsigned)h[CS_H_WORDS_LO], (unsigned)h[CS_H_WORDS_HI]};

@@ -250,9 +250,11 @@ __device__ __forceinline__ void lane_advance_finish(const DevParams &p, int b0, 
     const int pos = __shfl(e.mt_pos, src);
     const int a = __shfl(e.ahead, src);
     row_twist_ahead(rowbuf, p.mt + (size_t)(b0 + src) * MT_STRIDE, pos, a < 0 ? 0 : a, lane);
+    unsigned long long bms[TAPE_DW / 2];
+    row_hits_all(p, rowbuf, pos, lane, bms);
 #pragma unroll
     for (int it = 0; it < TAPE_DW / 2; it++) {
-        const unsigned long long bm = row_slot_hits(p, rowbuf, pos, it, lane);
+        const unsigned long long bm = bms[it];
         if (lane == src) {
             tape[2 * it] = (unsigned)(bm & 0xffffffffull);
             tape[2 * it + 1] = (unsigned)(bm >> 32);

@@ -164,11 +164,13 @@ __device__ __forceinline__ void lv_advance_finish(const DevParams &p, int b0, in
     const int pos = __shfl(e.mt_pos, src);
     const int a = __shfl(e.ahead, src);
     LANE_STAMP(10);
-    row_twist_ahead(rowbuf, p.mt + (size_t)(b0 + src) * MT_STRIDE, pos, a < 0 ? 0 : a, lane);
+    row_twist_ahead<true>(rowbuf, p.mt + (size_t)(b0 + src) * MT_STRIDE, pos, a < 0 ? 0 : a, lane);
     LANE_STAMP(11);
+    unsigned long long bms[TAPE_DW / 2];
+    row_hits_all(p, rowbuf, pos, lane, bms);
 #pragma unroll
     for (int it = 0; it < TAPE_DW / 2; it++) {
-        const unsigned long long bm = row_slot_hits(p, rowbuf, pos, it, lane);
+        const unsigned long long bm = bms[it];
         if (lane == src) {
             tl[(2 * it) * 64 + lane] = (unsigned)(bm & 0xffffffffull);
             tl[(2 * it + 1) * 64 + lane] = (unsigned)(bm >> 32);

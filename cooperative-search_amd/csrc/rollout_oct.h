@@ -529,9 +529,11 @@ __device__ __forceinline__ void oct_wave_advance(const DevParams &p, int wave_b0
         row_load(m, lane, rr);
         row_to_lds(rr, rowbuf, lane);
         row_twist_ahead(rowbuf, m, pos, a < 0 ? 0 : a, lane);
+        unsigned long long bms[TAPE_DW / 2];
+        row_hits_all(p, rowbuf, pos, lane, bms);
 #pragma unroll
         for (int it = 0; it < TAPE_DW / 2; it++) {
-            const unsigned long long bm = row_slot_hits(p, rowbuf, pos, it, lane);
+            const unsigned long long bm = bms[it];
             if (o == g) {
                 tape[2 * it] = (unsigned)(bm & 0xffffffffull);
                 tape[2 * it + 1] = (unsigned)(bm >> 32);
@@ -561,9 +563,11 @@ __device__ __forceinline__ void oct_advance_finish(const DevParams &p, int wave_
     const int o = OctLay<LG>::valid(lane) ? OctLay<LG>::env(lane) : -1;
     const int pos = __shfl(e.mt_pos, OctLay<LG>::first_of(g)), a = __shfl(e.ahead, OctLay<LG>::first_of(g));
     row_twist_ahead(rowbuf, p.mt + (size_t)(wave_b0 + g) * MT_STRIDE, pos, a < 0 ? 0 : a, lane);
+    unsigned long long bms[TAPE_DW / 2];
+    row_hits_all(p, rowbuf, pos, lane, bms);
 #pragma unroll
     for (int it = 0; it < TAPE_DW / 2; it++) {
-        const unsigned long long bm = row_slot_hits(p, rowbuf, pos, it, lane);
+        const unsigned long long bm = bms[it];
         if (o == g) {
             tape[2 * it] = (unsigned)(bm & 0xffffffffull);
             tape[2 * it + 1] = (unsigned)(bm >> 32);

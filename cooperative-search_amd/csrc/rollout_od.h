@@ -445,9 +445,11 @@ __device__ __forceinline__ void rollout_od_body(const DevParams &p, const StepIO
             row_load(m, lane, rr);
             row_to_lds(rr, rf.erow, lane);
             row_twist_ahead(rf.erow, m, pos, a < 0 ? 0 : a, lane);
+            unsigned long long bms[TAPE_DW / 2];
+            row_hits_all(OD_COLD(), rf.erow, pos, lane, bms);
 #pragma unroll
             for (int it = 0; it < TAPE_DW / 2; it++) {
-                const unsigned long long bm = row_slot_hits(OD_COLD(), rf.erow, pos, it, lane);
+                const unsigned long long bm = bms[it];
                 if (lane == 0) {
                     rf.rf_tape[2 * it] = (unsigned)(bm & 0xffffffffull);
                     rf.rf_tape[2 * it + 1] = (unsigned)(bm >> 32);
