@@ -644,6 +644,7 @@ __device__ __forceinline__ void rollout_od_body(const DevParams &p, const StepIO
 #endif
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
+    int k_seen = 0;                      // K's progress word as D last read it
     int cand = -1;                       // env (octet) of the wavefront whose row is on its way into sh.rowbuf
     int ack_wait = 0;                    // fix request of the previous step that K has yet to acknowledge (0: none)
     // EREF: the refresh E is working on
@@ -791,7 +792,15 @@ __device__ __forceinline__ void rollout_od_body(const DevParams &p, const StepIO
             while (peek(&sh.fix_ack) != ack_wait) __builtin_amdgcn_s_sleep(1);
             ack_wait = 0;
         }
-        while (peek(&sh.k_steps) <= s) { SPIN_TICK; __builtin_amdgcn_s_sleep(1); }
+        // (K's progress word only grows, and a slot K published stays published -- a redo rewrites it behind fix_ack, waited for above:
+        // the word is re-read only when the last value D saw does not cover step s.  With K a few steps ahead, as it is whenever D is the
+        // longer role, D's steady-state step has no LDS round trip in front of the ring read: CS_OD_KSEEN, round 6)
+#ifndef CS_OD_KSEEN
+#define CS_OD_KSEEN 1
+#endif
+        if (!CS_OD_KSEEN || k_seen <= s) {
+            while ((k_seen = peek(&sh.k_steps)) <= s) { SPIN_TICK; __builtin_amdgcn_s_sleep(1); }
+        }
         OD_JITTER(7);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #ifdef CS_OD_ABL_NODET   /* experiment: what K alone sustains */
