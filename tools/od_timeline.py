@@ -44,7 +44,20 @@ for st in rows:
                 val[k].append(d)
         kstep.append(int(st[s + 1, 0] - st[s, 0]))
         dstep.append(int(st[s + 1, 8] - st[s, 8]))
+rs = {"D reset: placement (oct_place_targets)": [], "D reset: state + top-up + barrier": [], "D reset: near test / reset-time pass / top-up": []}
+nres = 0
+for st in rows:
+    for s in range(3, 60):
+        if st[s, 13] > st[s, 8] and st[s, 14] > st[s, 13] and st[s, 9] > st[s, 15] > st[s, 14]:   # a reset ran in this step
+            nres += 1
+            rs["D reset: placement (oct_place_targets)"].append(int(st[s, 14] - st[s, 13]))
+            rs["D reset: state + top-up + barrier"].append(int(st[s, 15] - st[s, 14]))
+            rs["D reset: near test / reset-time pass / top-up"].append(int(st[s, 9] - st[s, 15]))
 print(f"{kernel}<{n}>, {B} envs: K step {statistics.median(kstep)} cycles, D step {statistics.median(dstep)} cycles (medians, workgroup 0)")
 for k, v in val.items():
+    if v:
+        print(f"  {k:52s} {statistics.median(v):7.0f}  (mean {statistics.fmean(v):.0f})")
+print(f"  steps with a reset: {nres} of {len(dstep)}")
+for k, v in rs.items():
     if v:
         print(f"  {k:52s} {statistics.median(v):7.0f}  (mean {statistics.fmean(v):.0f})")
