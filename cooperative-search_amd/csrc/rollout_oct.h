@@ -231,12 +231,15 @@ struct OctStage {
             const double xi = pi.x, yi = pi.y;
             const double dx = k.cx - xi, dy = k.cy - yi;
             const double d2 = dx * dx + dy * dy;
-            const bool c_lt = d2 < p.force_d2, c_nx = k.cx != xi, c_ny = k.cy != yi;
-            const bool inr = act_lane & (t != I) & c_lt & (c_nx | c_ny);
-            // "some lane is in range", from the three comparisons' own lane masks (a ballot of a bare comparison IS its result register;
-            // a ballot of the combined predicate costs a select and a compare to rebuild that mask) and the step's mask of agent lanes
+            const bool c_lt = d2 < p.force_d2;
+            // "some lane is within force_dist", from the comparison's own lane mask (a ballot of a bare comparison IS its result register)
+            // and the step's mask of agent lanes.  The coincidence test of flight_env_easy.py:298 (an agent on top of agent I exerts no
+            // force) is made inside: it can only matter where c_lt holds, and two agents clamped into one corner are rare enough that a
+            // stage entered for them alone costs less than two comparisons in every stage of every step (round 6)
             const unsigned long long not_i = ~OctLay<LG>::lanes_t(I);
-            if (__ballot(c_lt) & (__ballot(c_nx) | __ballot(c_ny)) & act_mask & not_i) {   // wave-uniform
+            if (__ballot(c_lt) & act_mask & not_i) {   // wave-uniform
+                const bool c_nx = k.cx != xi, c_ny = k.cy != yi;
+                const bool inr = act_lane & (t != I) & c_lt & (c_nx | c_ny);
                 // x_a - x = -(x - x_a) exactly (a difference and its mirror round alike; a zero difference comes out as -0.0 here where
                 // the reference has +0.0: its square is +0.0 all the same, and its term, -0.0, leaves every sum it is added to as it
                 // was -- the sums start from +0.0).  So the squared distance of the term IS the one the range test computed, and the
